@@ -1,0 +1,287 @@
+#!/usr/bin/env python
+"""Generate the committed golden vectors under tests/golden/ by EXECUTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  Nothing here travels to the GPU
+box except the resulting *.safetensors data files.
+
+How: the reference's vendored DiT file src/qflux/models/transformer_qwenimage.py is imported
+unmodified by file path.  Its third-party imports (diffusers, absent offline) are satisfied by
+a throw-away *shim* package written to a temp dir by this script: a ~150-line restatement of
+the diffusers primitives the file uses (SURVEY.md section 8(c) semantics table).  The shim is
+our code, not reference source; the reference file itself is never copied.
+
+Vectors written (all tiny; the tiny config equals the reference's own test config,
+tests/src/models/test_qwen_per_sample_rope.py:118-133):
+  qwen_tiny_fwd.safetensors     fp32: inputs, reference forward output (weights: common.fill_weights seed 1)
+  qwen_tiny_grad.safetensors    fp32: d(loss)/d(input) and d(loss)/d(to_q.weight) of the reference
+  qwen_rope.safetensors         RoPE tables of the reference for 3 shape lists (incl. 2509 3-image)
+  qwen_tiny_lora_step.safetensors  ORACLE (not reference; peft is absent => parity unpinned for the
+                                LoRA half) fp32 LoRA training step: loss, pred, dA/dB for all targets
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import torch
+from safetensors.torch import save_file
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+SHIM = {
+    "diffusers/__init__.py": "",
+    "diffusers/configuration_utils.py": '''
+import functools, inspect
+class ConfigMixin:
+    pass
+def register_to_config(init):
+    @functools.wraps(init)
+    def wrapper(self, *a, **kw):
+        sig = inspect.signature(init)
+        ba = sig.bind(self, *a, **kw); ba.apply_defaults()
+        cfg = {k: v for k, v in ba.arguments.items() if k != "self"}
+        self.config = type("Cfg", (), cfg)()
+        init(self, *a, **kw)
+    return wrapper
+''',
+    "diffusers/loaders/__init__.py": "class FromOriginalModelMixin: pass\nclass PeftAdapterMixin: pass\n",
+    "diffusers/models/__init__.py": "",
+    "diffusers/models/attention.py": '''
+import torch.nn as nn, torch.nn.functional as F
+class GELU(nn.Module):
+    def __init__(self, dim_in, dim_out, approximate="none", bias=True):
+        super().__init__(); self.proj = nn.Linear(dim_in, dim_out, bias=bias); self.approximate = approximate
+    def forward(self, x):
+        return F.gelu(self.proj(x), approximate=self.approximate)
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", bias=True):
+        super().__init__()
+        assert activation_fn == "gelu-approximate"
+        inner = int(dim * mult); dim_out = dim_out or dim
+        self.net = nn.ModuleList([GELU(dim, inner, approximate="tanh", bias=bias), nn.Dropout(dropout), nn.Linear(inner, dim_out, bias=bias)])
+    def forward(self, x, *a, **k):
+        for m in self.net: x = m(x)
+        return x
+''',
+    "diffusers/models/attention_dispatch.py": '''
+import torch.nn.functional as F
+def dispatch_attention_fn(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, backend=None, **kw):
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale)
+    return o.permute(0, 2, 1, 3)
+''',
+    "diffusers/models/attention_processor.py": '''
+import inspect, torch.nn as nn
+from .normalization import RMSNorm
+class Attention(nn.Module):
+    def __init__(self, query_dim, cross_attention_dim=None, added_kv_proj_dim=None, dim_head=64, heads=8,
+                 out_dim=None, context_pre_only=None, bias=False, processor=None, qk_norm=None, eps=1e-5):
+        super().__init__()
+        inner = out_dim if out_dim is not None else dim_head * heads
+        self.heads = inner // dim_head; self.processor = processor
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(query_dim, inner, bias=bias)
+        self.to_v = nn.Linear(query_dim, inner, bias=bias)
+        self.add_k_proj = nn.Linear(added_kv_proj_dim, inner, bias=True)
+        self.add_v_proj = nn.Linear(added_kv_proj_dim, inner, bias=True)
+        self.add_q_proj = nn.Linear(added_kv_proj_dim, inner, bias=True)
+        self.to_out = nn.ModuleList([nn.Linear(inner, out_dim or query_dim, bias=True), nn.Dropout(0.0)])
+        self.to_add_out = nn.Linear(inner, query_dim, bias=True)
+        assert qk_norm == "rms_norm"
+        self.norm_q = RMSNorm(dim_head, eps=eps); self.norm_k = RMSNorm(dim_head, eps=eps)
+        self.norm_added_q = RMSNorm(dim_head, eps=eps); self.norm_added_k = RMSNorm(dim_head, eps=eps)
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        params = set(inspect.signature(self.processor.__call__).parameters.keys())
+        kw = {k: v for k, v in kw.items() if k in params}
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=attention_mask, **kw)
+''',
+    "diffusers/models/cache_utils.py": "class CacheMixin: pass\n",
+    "diffusers/models/embeddings.py": '''
+import math, torch, torch.nn as nn
+def get_timestep_embedding(timesteps, embedding_dim, flip_sin_to_cos=False, downscale_freq_shift=1, scale=1, max_period=10000):
+    half_dim = embedding_dim // 2
+    exponent = -math.log(max_period) * torch.arange(start=0, end=half_dim, dtype=torch.float32, device=timesteps.device)
+    exponent = exponent / (half_dim - downscale_freq_shift)
+    emb = torch.exp(exponent)
+    emb = timesteps[:, None].float() * emb[None, :]
+    emb = scale * emb
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half_dim:], emb[:, :half_dim]], dim=-1)
+    return emb
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift, scale=1):
+        super().__init__(); self.num_channels = num_channels; self.flip_sin_to_cos = flip_sin_to_cos
+        self.downscale_freq_shift = downscale_freq_shift; self.scale = scale
+    def forward(self, timesteps):
+        return get_timestep_embedding(timesteps, self.num_channels, flip_sin_to_cos=self.flip_sin_to_cos,
+                                      downscale_freq_shift=self.downscale_freq_shift, scale=self.scale)
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__(); self.linear_1 = nn.Linear(in_channels, time_embed_dim); self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+    def forward(self, sample):
+        return self.linear_2(self.act(self.linear_1(sample)))
+''',
+    "diffusers/models/modeling_outputs.py": "class Transformer2DModelOutput:\n    def __init__(self, sample): self.sample = sample\n",
+    "diffusers/models/modeling_utils.py": "import torch.nn as nn\nclass ModelMixin(nn.Module): pass\n",
+    "diffusers/models/normalization.py": '''
+import torch, torch.nn as nn
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps, elementwise_affine=True, bias=False):
+        super().__init__(); self.eps = eps; self.weight = nn.Parameter(torch.ones(dim))
+    def forward(self, hidden_states):
+        input_dtype = hidden_states.dtype
+        variance = hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        hidden_states = hidden_states * torch.rsqrt(variance + self.eps)
+        if self.weight.dtype in [torch.float16, torch.bfloat16]:
+            hidden_states = hidden_states.to(self.weight.dtype)
+        return hidden_states * self.weight
+class AdaLayerNormContinuous(nn.Module):
+    def __init__(self, embedding_dim, conditioning_embedding_dim, elementwise_affine=True, eps=1e-5, bias=True, norm_type="layer_norm"):
+        super().__init__(); self.silu = nn.SiLU()
+        self.linear = nn.Linear(conditioning_embedding_dim, embedding_dim * 2, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, eps, elementwise_affine, bias)
+    def forward(self, x, conditioning_embedding):
+        emb = self.linear(self.silu(conditioning_embedding).to(x.dtype))
+        scale, shift = torch.chunk(emb, 2, dim=1)
+        return self.norm(x) * (1 + scale)[:, None, :] + shift[:, None, :]
+''',
+    "diffusers/utils/__init__.py": '''
+USE_PEFT_BACKEND = False
+class _L:
+    def get_logger(self, name):
+        import logging as _l; return _l.getLogger(name)
+logging = _L()
+def scale_lora_layers(*a, **k): pass
+def unscale_lora_layers(*a, **k): pass
+''',
+    "diffusers/utils/torch_utils.py": "def maybe_allow_in_graph(cls): return cls\n",
+}
+
+
+def import_reference_qwen():
+    tmp = tempfile.mkdtemp(prefix="qfx_shim_")
+    for rel, src in SHIM.items():
+        p = os.path.join(tmp, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(src)
+    sys.path.insert(0, tmp)
+    for name in ("qflux", "qflux.models"):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, "src", *name.split("."))]
+        sys.modules[name] = m
+    return importlib.import_module("qflux.models.transformer_qwenimage")
+
+
+sys.path.insert(0, HERE)
+from common import TINY, fill_weights, weight_checksum  # noqa: E402
+
+
+def tiny_inputs(seed=0, B=2, shapes=((1, 4, 6), (1, 4, 6)), T=5):
+    g = torch.Generator().manual_seed(seed)
+    S_i = sum(f * h * w for f, h, w in shapes)
+    return dict(
+        hidden_states=torch.randn(B, S_i, 64, generator=g),
+        encoder_hidden_states=torch.randn(B, T, 512, generator=g) * 4,
+        timestep=torch.tensor([0.7109, 0.1611][:B]),  # constants of tests/e2e/test_flux_loss.py:119
+        mask=torch.ones(B, T, dtype=torch.int64),
+    ), [list(map(tuple, shapes))] * B, [T] * B
+
+
+def main():
+    from oracle import qwen_dit as O
+
+    ref = import_reference_qwen()
+    torch.manual_seed(0)
+    model = ref.QwenImageTransformer2DModel(**TINY, guidance_embeds=False).eval()
+    fill_weights(model, seed=1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    # ---------------- forward ----------------
+    inp, img_shapes, txt_lens = tiny_inputs()
+    x = inp["hidden_states"].clone().requires_grad_(True)
+    out = model(hidden_states=x, encoder_hidden_states=inp["encoder_hidden_states"],
+                encoder_hidden_states_mask=inp["mask"], timestep=inp["timestep"],
+                img_shapes=img_shapes, txt_seq_lens=txt_lens, return_dict=False)[0]
+    tgt = torch.randn(out.shape, generator=torch.Generator().manual_seed(5))
+    loss = ((out - tgt) ** 2).mean()
+    wq = model.transformer_blocks[0].attn.to_q.weight
+    wq.requires_grad_(True)
+    gx, gw = torch.autograd.grad(loss, [x, wq])
+
+    oracle = O.OracleQwenDiT(**TINY)
+    missing, unexpected = oracle.load_state_dict(sd, strict=True)
+    xo = inp["hidden_states"].clone().requires_grad_(True)
+    oo = oracle(hidden_states=xo, encoder_hidden_states=inp["encoder_hidden_states"],
+                encoder_hidden_states_mask=inp["mask"], timestep=inp["timestep"],
+                img_shapes=img_shapes, txt_seq_lens=txt_lens)[0]
+    lo = ((oo - tgt) ** 2).mean()
+    ogx, ogw = torch.autograd.grad(lo, [xo, oracle.transformer_blocks[0].attn.to_q.weight])
+    print("oracle vs reference: fwd max|d| = %.3e  gx %.3e  gw %.3e" % (
+        (oo - out).abs().max().item(), (ogx - gx).abs().max().item(), (ogw - gw).abs().max().item()))
+    assert (oo - out).abs().max() < 1e-5 and (ogx - gx).abs().max() < 1e-6
+
+    fwd = {"w.checksum": weight_checksum(model)}
+    fwd.update({"in.hidden_states": inp["hidden_states"], "in.encoder_hidden_states": inp["encoder_hidden_states"],
+                "in.timestep": inp["timestep"], "in.mask": inp["mask"], "in.target": tgt,
+                "out.sample": out.detach().contiguous()})
+    save_file(fwd, os.path.join(HERE, "qwen_tiny_fwd.safetensors"),
+              metadata={"img_shapes": repr(img_shapes[0]), "txt_len": str(txt_lens[0]), "cfg": repr(TINY)})
+    save_file({"grad.hidden_states": gx.contiguous(), "grad.blocks0_to_q_weight": gw.contiguous(),
+               "loss": loss.detach().reshape(1)}, os.path.join(HERE, "qwen_tiny_grad.safetensors"))
+
+    # ---------------- RoPE tables of the reference ----------------
+    rope = {}
+    pe = ref.QwenEmbedRope(theta=10000, axes_dim=[16, 56, 56], scale_rope=True)
+    cases = {"a": ([[(1, 4, 6), (1, 4, 6)]], [5]), "b": ([[(1, 16, 12), (1, 16, 12)]], [7]),
+             "c": ([[(1, 6, 4), (1, 8, 8), (1, 2, 10)]], [9])}
+    for name, (shapes, tl) in cases.items():
+        v, t = pe(shapes, tl, device=torch.device("cpu"))
+        ov, ot = O.qwen_rope_tables(shapes[0], tl[0], (16, 56, 56))
+        assert torch.allclose(torch.view_as_real(v), torch.view_as_real(ov), atol=1e-6), name
+        assert torch.allclose(torch.view_as_real(t), torch.view_as_real(ot), atol=1e-6), name
+        rope[f"{name}.vid"] = torch.view_as_real(v).clone().contiguous()
+        rope[f"{name}.txt"] = torch.view_as_real(t).clone().contiguous()
+    # apply_rotary_emb_qwen known-answer: x=[0..7], angle pi/2 -> [-1,0,-3,2,-5,4,-7,6]
+    xk = torch.arange(8.0).view(1, 1, 1, 8)
+    fk = torch.polar(torch.ones(1, 4), torch.full((1, 4), torch.pi / 2))
+    rope["kat.out"] = ref.apply_rotary_emb_qwen(xk, fk, use_real=False).contiguous()
+    save_file(rope, os.path.join(HERE, "qwen_rope.safetensors"), metadata={k: repr(v) for k, v in cases.items()})
+
+    # ---------------- LoRA training step (oracle only: peft absent) ----------------
+    names = O.add_lora(oracle, r=4, lora_alpha=8, adapter_name="lora_edit", seed=7)
+    fill_weights(oracle, seed=2)
+    g = torch.Generator().manual_seed(11)
+    B, S_t = 2, 24
+    emb = dict(image_latents=torch.randn(B, S_t, 64, generator=g).half().float(),
+               control_latents=torch.randn(B, S_t, 64, generator=g).half().float(),
+               prompt_embeds=(torch.randn(B, 5, 512, generator=g) * 4).half().float(),
+               prompt_embeds_mask=torch.ones(B, 5, dtype=torch.int64),
+               img_shapes=[[(1, 4, 6), (1, 4, 6)]] * B)
+    noise = torch.randn(B, S_t, 64, generator=g)
+    u = torch.tensor([0.7109, 0.1611])
+    loss, pred = O.qwen_compute_loss(oracle, emb, noise, u, torch.float32, return_pred=True)
+    loss.backward()
+    step = {"in.image_latents": emb["image_latents"], "in.control_latents": emb["control_latents"],
+            "in.prompt_embeds": emb["prompt_embeds"], "in.noise": noise, "in.u": u,
+            "out.loss": loss.detach().reshape(1), "out.pred": pred.detach().contiguous(),
+            "w.checksum": weight_checksum(oracle)}
+    for n, p in oracle.named_parameters():
+        if "lora" in n:
+            step["g." + n] = p.grad.detach().clone().contiguous()
+    save_file(step, os.path.join(HERE, "qwen_tiny_lora_step.safetensors"),
+              metadata={"targets": repr(names), "r": "4", "lora_alpha": "8", "adapter": "lora_edit",
+                        "pinned": "oracle-only (peft unavailable offline): parity unpinned for LoRA half"})
+    print("wrote golden vectors to", HERE)
+
+
+if __name__ == "__main__":
+    main()

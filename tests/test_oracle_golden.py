@@ -1,0 +1,88 @@
+"""CPU: the oracle reproduces the vectors captured from the reference itself (tests/golden/make_golden.py)."""
+import ast
+import os
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+from common import TINY, fill_weights, weight_checksum
+from oracle import qwen_dit as O
+
+
+def _meta(path):
+    with safe_open(path, "pt") as f:
+        return f.metadata()
+
+
+def test_forward_matches_reference_vectors(golden_dir):
+    p = os.path.join(golden_dir, "qwen_tiny_fwd.safetensors")
+    t, meta = load_file(p), _meta(p)
+    model = O.OracleQwenDiT(**TINY)
+    fill_weights(model, seed=1)
+    assert torch.equal(weight_checksum(model), t["w.checksum"])
+    shapes = ast.literal_eval(meta["img_shapes"])
+    B = t["in.hidden_states"].shape[0]
+    out = model(hidden_states=t["in.hidden_states"], encoder_hidden_states=t["in.encoder_hidden_states"],
+                encoder_hidden_states_mask=t["in.mask"], timestep=t["in.timestep"],
+                img_shapes=[shapes] * B, txt_seq_lens=[int(meta["txt_len"])] * B)[0]
+    assert (out - t["out.sample"]).abs().max() < 1e-5
+
+
+def test_grads_match_reference_vectors(golden_dir):
+    t = load_file(os.path.join(golden_dir, "qwen_tiny_fwd.safetensors"))
+    g = load_file(os.path.join(golden_dir, "qwen_tiny_grad.safetensors"))
+    meta = _meta(os.path.join(golden_dir, "qwen_tiny_fwd.safetensors"))
+    model = O.OracleQwenDiT(**TINY)
+    fill_weights(model, seed=1)
+    shapes = ast.literal_eval(meta["img_shapes"])
+    x = t["in.hidden_states"].clone().requires_grad_(True)
+    out = model(hidden_states=x, encoder_hidden_states=t["in.encoder_hidden_states"],
+                encoder_hidden_states_mask=t["in.mask"], timestep=t["in.timestep"],
+                img_shapes=[shapes] * 2, txt_seq_lens=[int(meta["txt_len"])] * 2)[0]
+    loss = ((out - t["in.target"]) ** 2).mean()
+    gx, gw = torch.autograd.grad(loss, [x, model.transformer_blocks[0].attn.to_q.weight])
+    assert abs(loss.item() - g["loss"].item()) < 1e-6
+    assert (gx - g["grad.hidden_states"]).abs().max() < 1e-6
+    assert (gw - g["grad.blocks0_to_q_weight"]).abs().max() < 1e-6
+
+
+def test_rope_tables_match_reference(golden_dir):
+    p = os.path.join(golden_dir, "qwen_rope.safetensors")
+    t, meta = load_file(p), _meta(p)
+    for name in ("a", "b", "c"):
+        shapes, tl = ast.literal_eval(meta[name])
+        v, x = O.qwen_rope_tables(shapes[0], tl[0], (16, 56, 56))
+        assert torch.allclose(torch.view_as_real(v), t[f"{name}.vid"], atol=1e-6)
+        assert torch.allclose(torch.view_as_real(x), t[f"{name}.txt"], atol=1e-6)
+    # known answer from SURVEY 8(a) a4: rotate [0..7] by pi/2 -> [-1,0,-3,2,-5,4,-7,6]
+    xk = torch.arange(8.0).view(1, 1, 1, 8)
+    fk = torch.polar(torch.ones(1, 4), torch.full((1, 4), torch.pi / 2))
+    out = O.apply_rope_complex(xk, fk)
+    assert torch.allclose(out, t["kat.out"], atol=1e-6)
+    assert torch.allclose(out.flatten(), torch.tensor([-1., 0, -3, 2, -5, 4, -7, 6]), atol=1e-5)
+
+
+def test_lora_step_vectors(golden_dir):
+    p = os.path.join(golden_dir, "qwen_tiny_lora_step.safetensors")
+    t, meta = load_file(p), _meta(p)
+    model = O.OracleQwenDiT(**TINY)
+    names = O.add_lora(model, r=int(meta["r"]), lora_alpha=float(meta["lora_alpha"]), adapter_name=meta["adapter"])
+    assert names == ast.literal_eval(meta["targets"])
+    fill_weights(model, seed=2)
+    assert torch.equal(weight_checksum(model), t["w.checksum"])
+    emb = dict(image_latents=t["in.image_latents"], control_latents=t["in.control_latents"],
+               prompt_embeds=t["in.prompt_embeds"], prompt_embeds_mask=torch.ones(2, 5, dtype=torch.int64),
+               img_shapes=[[(1, 4, 6), (1, 4, 6)]] * 2)
+    loss, pred = O.qwen_compute_loss(model, emb, t["in.noise"], t["in.u"], torch.float32, return_pred=True)
+    loss.backward()
+    assert abs(loss.item() - t["out.loss"].item()) < 1e-6
+    assert (pred - t["out.pred"]).abs().max() < 1e-5
+    n = 0
+    for pn, prm in model.named_parameters():
+        if "lora" in pn:
+            assert prm.requires_grad and (prm.grad - t["g." + pn]).abs().max() < 1e-6, pn
+            n += 1
+        else:
+            assert not prm.requires_grad
+    assert n == 2 * 4 * TINY["num_layers"]
