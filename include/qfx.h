@@ -1,0 +1,216 @@
+/*
+ * qfx.h -- C ABI of libqfx.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * LoRA-training hot path of the Qwen-Image-Edit / FLUX-Kontext DiT.
+ *
+ * The reference (tsiendragon/qwen-image-finetune) has no native code and no FFI: its hot path is
+ * Python calling torch/diffusers/peft ops.  Each entry point below names the
+ * reference call sites whose device work it replaces (file:line relative to /root/reference).
+ * Callers are the torch.autograd.Function wrappers in qwen-image-finetune_amd/qflux_amd/ops.py.
+ *
+ * Conventions
+ *   - extern "C", plain device pointers + explicit sizes/strides (in ELEMENTS unless stated).
+ *   - bf16 tensors are passed as `const uint16_t*` (raw bits), fp32 as `const float*`.
+ *   - caller allocates every output and workspace; kernels are launched on `stream`
+ *     (a hipStream_t passed as void*); no global state; thread-safe for distinct streams.
+ *   - return 0 on success, a negative QFX_E* code on a rejected argument; HIP launch errors are
+ *     returned as -(1000 + hipError_t).  No exceptions cross the ABI.
+ */
+#ifndef QFX_H
+#define QFX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QFX_ABI_VERSION 1
+
+#define QFX_OK 0
+#define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
+#define QFX_EUNSUPPORTED (-2)
+
+/* ---- GEMM with fused LoRA / epilogues ------------------------------------------------------
+ * C[M,N] = A1[M,K1] * B1[N,K1]^T (+ A2[M,K2] * B2[N,K2]^T) (+ bias[N]) , then epilogue.
+ * Replaces: nn.Linear + peft lora.Linear side branch + following elementwise ops
+ *   (src/qflux/models/transformer_qwenimage.py:286-293,348,352 ; FeedForward at :479,485 ;
+ *    gated residuals at :473-474,480,486 ; LoRA call site src/qflux/trainer/base_trainer.py:929-941)
+ * and, with transposed weights, the dX GEMMs autograd runs for them.
+ * K1, K2 multiples of 64; all row strides multiples of 8 elements; pointers 16-byte aligned.
+ * Rounding points follow the reference's bf16 eager graph: if K2>0 the accumulator is rounded to
+ * bf16 after (A1*B1^T + bias) -- the base nn.Linear output -- before the LoRA segment is added.
+ */
+enum {
+  QFX_EPI_NONE = 0,      /* C = bf16(acc) */
+  QFX_EPI_GELU = 1,      /* C = bf16(acc) (pre-activation), C2 = bf16(gelu_tanh(C)) */
+  QFX_EPI_GATE_RES = 2,  /* C = bf16(aux + bf16(gate[b] * bf16(acc)))  (x + gate*y) */
+  QFX_EPI_DGELU = 3      /* C = bf16(bf16(acc) * gelu_tanh'(aux))      (backward through GELU) */
+};
+
+typedef struct qfx_gemm_args {
+  const uint16_t* A1; const uint16_t* B1; int64_t lda1; int64_t ldb1; int32_t K1;
+  const uint16_t* A2; const uint16_t* B2; int64_t lda2; int64_t ldb2; int32_t K2;
+  int32_t M; int32_t N;
+  const uint16_t* bias;            /* [N] bf16 or NULL */
+  uint16_t* C; int64_t ldc;
+  uint16_t* C2; int64_t ldc2;      /* EPI_GELU second output */
+  const uint16_t* aux; int64_t ldaux;   /* residual (GATE_RES) / pre-activation (DGELU); indexed like C */
+  const uint16_t* gate; int64_t gate_bstride; /* gate[b*gate_bstride + n], b = m / rows_per_batch */
+  int32_t rows_per_batch;          /* rows of A per batch sample (M if unused) */
+  /* row remaps (joint [text|image] buffers): row(m) = (m / rows_per_batch) * X_batch_rows + X_row_off + m % rows_per_batch */
+  int32_t a_batch_rows; int32_t a_row_off;   /* applied to A1 rows; a_batch_rows==0 => identity */
+  int32_t c_batch_rows; int32_t c_row_off;   /* applied to C/C2/aux rows; c_batch_rows==0 => identity */
+  int32_t epi;
+} qfx_gemm_args;
+
+int qfx_gemm_bf16(const qfx_gemm_args* args, void* stream);
+
+/* ---- LoRA rank-r down projection ("skinny" GEMM, HBM-bound) ----------------------------------
+ * U[M,R] (fp32) = X[M,K] (bf16) * (W_hi + W_lo)[R,K]^T   (W = fp32 LoRA weight split in two bf16)
+ * and its packed bf16 image EXT[M, 3R] = [U_hi | U_lo | U_hi] written at ext + m*ld_ext
+ * (consumed as the A2 operand of qfx_gemm_bf16 against B2 = [V_hi | V_hi | V_lo]).
+ * Replaces peft lora_A(x.float()) forward and the dY*B product of its backward. R in {16,32,48,64,96}.
+ */
+typedef struct qfx_lora_down_args {
+  const uint16_t* X; int64_t ldx; int32_t M; int32_t K;
+  const uint16_t* W_hi; const uint16_t* W_lo; int64_t ldw; int32_t R;
+  float* U; int64_t ldu;                 /* may be NULL */
+  uint16_t* ext; int64_t ld_ext;         /* may be NULL */
+  int32_t group_R; int32_t group_stride; /* ext column of U column j: (j/group_R)*group_stride + j%group_R + {0,group_R,2*group_R}
+                                            (several LoRA targets sharing X are fused in one call; group_R = R for one) */
+  int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off; /* X row remap as in gemm */
+} qfx_lora_down_args;
+
+int qfx_lora_down(const qfx_lora_down_args* args, void* stream);
+
+/* ---- LoRA weight gradients (outer-product accumulation over tokens) -------------------------
+ * G[j,k] += sum_m V[m,j] * X[m,k]   j<R, k<K ; V fp32 [M,R], X bf16 [M,K]; G fp32, atomically
+ * accumulated at G[j*g_sr + k*g_sc] (so dA [r,K] uses (K,1) and dB [N,r] uses (1,r)).
+ * Replaces autograd's dW for lora_A / lora_B (frozen base weights never get a dW at all).
+ */
+typedef struct qfx_lora_grad_args {
+  const float* V; int64_t ldv; int32_t R; int32_t r_valid;  /* only j < r_valid are written */
+  const uint16_t* X; int64_t ldx; int32_t M; int32_t K;
+  float* G; int64_t g_sr; int64_t g_sc;
+  int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off;
+} qfx_lora_grad_args;
+
+int qfx_lora_grad(const qfx_lora_grad_args* args, void* stream);
+
+/* ---- LoRA operand packing (after every optimizer step) ---------------------------------------
+ * From fp32 A[r,K], B[N,r] and scale s = lora_alpha/r build (Rp = r rounded up to 16):
+ *   A_hi/A_lo [Rp,K] bf16, Bt_hi/Bt_lo [Rp,N] bf16 (= split of s*B^T),
+ *   We  [N, Kext] = [sB_hi | sB_hi | sB_lo | 0]   (forward B2 operand)
+ *   WeT [K, Kext] = [A_hi^T | A_hi^T | A_lo^T | 0] (dX B2 operand),  Kext = roundup(3*Rp, 64).
+ */
+typedef struct qfx_lora_pack_args {
+  const float* A; const float* B; int32_t r; int32_t K; int32_t N; float scale;
+  uint16_t* A_hi; uint16_t* A_lo; int64_t ld_a;      /* [Rp,K] rows at stride ld_a */
+  uint16_t* Bt_hi; uint16_t* Bt_lo; int64_t ld_bt;   /* [Rp,N] rows at stride ld_bt */
+  uint16_t* We; int64_t ld_we;                       /* [N,Kext] */
+  uint16_t* WeT; int64_t ld_wet;                     /* [K,Kext] */
+  int32_t Rp; int32_t Kext;
+} qfx_lora_pack_args;
+
+/* descs: DEVICE array of n descriptors (one per LoRA target); one launch packs them all. */
+int qfx_lora_pack(const qfx_lora_pack_args* descs, int32_t n, int32_t max_dim, void* stream);
+
+/* ---- LayerNorm (no affine, eps) + modulation ------------------------------------------------
+ * y = bf16(bf16(bf16(LN(x)) * bf16(1+scale[b])) + shift[b])    (transformer_qwenimage.py:420-423,443-448,477-484;
+ * AdaLayerNormContinuous at :662).  x,y [rows,D]; shift/scale [B,*] with batch stride mod_bstride.
+ */
+int qfx_ln_modulate_fwd(const uint16_t* x, const uint16_t* shift, const uint16_t* scale, int64_t mod_bstride,
+                        uint16_t* y, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, void* stream);
+/* dx = bf16(dres + bf16(LN_bwd(dy * bf16(1+scale)))) ; optional dyg = bf16(gate[b] * dx) (input of the
+ * previous gated-residual GEMM's backward). dres/gate/dyg may be NULL. */
+int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* scale, int64_t mod_bstride,
+                        const uint16_t* dres, const uint16_t* gate, int64_t gate_bstride,
+                        uint16_t* dx, uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch,
+                        float eps, void* stream);
+/* dyg = bf16(gate[b] * dx) only (used where no LayerNorm precedes). */
+int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg,
+                 int32_t rows, int32_t D, int32_t rows_per_batch, void* stream);
+
+/* ---- RMSNorm over the last dim with learned weight (txt_norm, transformer_qwenimage.py:625) */
+int qfx_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, int32_t rows, int32_t D, float eps, void* stream);
+
+/* ---- modulation GEMV: out[i][b][n] = bf16( sum_k bf16(silu(temb[b][k])) * W_i[n][k] + bias_i[n] )
+ * for a list of nmat weight matrices (all [N,K]) -- every block's img_mod/txt_mod in one launch
+ * (transformer_qwenimage.py:389-392,411-414,435-436; HBM-bound). */
+int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const uint16_t* const* W, const uint16_t* const* bias,
+                 int32_t nmat, int32_t N, int32_t apply_silu, uint16_t* out, void* stream);
+/* W, bias: DEVICE arrays of nmat device pointers. apply_silu=0 gives a plain small-batch Linear
+ * (timestep_embedder.linear_1). B <= 8. */
+
+/* ---- sinusoidal timestep projection (diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0, scale);
+ * transformer_qwenimage.py:147,151-152,623-624): t is first rounded to bf16 (timestep.to(bf16)),
+ * out[b] = bf16([cos(t*scale*f_i) | sin(t*scale*f_i)]), f_i = exp(-ln(1e4) * i / (dim/2)). */
+int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, uint16_t* out, void* stream);
+
+/* ---- QK RMSNorm + RoPE on the joint [text|image] qkv buffer ---------------------------------
+ * qkv [B,S,3*H*dh] (q|k|v sections), in place on the q and k sections:
+ *   t = bf16(bf16(x * rsqrt(mean(x^2)+eps)) * w) ; out = bf16(complex(t) * rope[s])   pairs (2j,2j+1)
+ * w = w_txt_* for rows s < T, w_img_* otherwise. rope [S, dh/2, 2] fp32 (cos,sin), joint order.
+ * (transformer_qwenimage.py:305-320, apply_rotary_emb_qwen :134-140). Pre-norm q,k are first copied to
+ * `saved` [B,S,2*H*dh] (needed by the backward) when saved != NULL.
+ */
+int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope,
+                         const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,
+                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream);
+/* in place on the q,k sections of dqkv (v section untouched): un-rotate, RMSNorm backward. */
+int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope,
+                         const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,
+                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream);
+
+/* ---- [B,S,H,dh] (row stride ld_in, column offset applied by caller) -> [B,H,dh,S_pad] with zero pad */
+int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_t B, int32_t S, int32_t S_pad,
+                        int32_t H, int32_t dh, void* stream);
+
+/* ---- joint attention (non-causal flash attention, optional additive key mask) ---------------
+ * Replaces torch.cat + F.scaled_dot_product_attention (transformer_qwenimage.py:324-337) and its backward.
+ * Q,K,V: token-major [B,S,H,dh] views with row stride ld (elements); Kt,Vt,Qt,dOt: [B,H,dh,S_pad].
+ * O [B,S,H*dh] (row stride ldo). lse2 [B,H,S_pad] fp32 = log2-domain logsumexp. key_mask [B,S] fp32 additive or NULL.
+ */
+typedef struct qfx_attn_args {
+  const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ldq; int64_t ldk; int64_t ldv;
+  const uint16_t* Qt; const uint16_t* Kt; const uint16_t* Vt;   /* [B,H,dh,S_pad] */
+  uint16_t* O; int64_t ldo;
+  float* lse2; float* dsum;                                      /* [B,H,S_pad] */
+  const uint16_t* dO; int64_t lddo; const uint16_t* dOt;
+  uint16_t* dQ; uint16_t* dK; uint16_t* dV; int64_t lddq; int64_t lddk; int64_t lddv;
+  const float* key_mask;
+  int32_t B; int32_t S; int32_t S_pad; int32_t H; int32_t dh; float scale;
+} qfx_attn_args;
+
+int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,Vt -> O,lse2 */
+int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream);  /* dsum = rowsum(dO*O) */
+int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream);    /* needs Q,K,V,Kt,dO,lse2,dsum -> dQ */
+int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream);   /* needs Q,Qt,K,V,dO,dOt,lse2,dsum -> dK,dV */
+
+/* ---- flow-matching MSE criterion (src/qflux/losses/mse_loss.py:66-83 with weighting=1;
+ * caller math of src/qflux/trainer/qwen_image_edit_trainer.py:839-847) --------------------------
+ * pred [B, S_all, C] bf16 (only rows < S_t per sample enter), target [B,S_t,C] bf16.
+ * loss (fp32 scalar, must be zeroed by caller) += mean_b mean_{s,c} (pred-target)^2 ;
+ * dpred [B,S_all,C] bf16 = bf16(2*(pred-target)/(B*S_t*C) * gscale), zero for rows >= S_t. */
+int qfx_mse_loss_fwd_bwd(const uint16_t* pred, const uint16_t* target, float* loss, uint16_t* dpred,
+                         int32_t B, int32_t S_all, int32_t S_t, int32_t C, float gscale, void* stream);
+
+/* ---- flow-matching input preparation (qwen_image_edit_trainer.py:811-812,841), bf16 eager rounding:
+ * packed[b] = cat(bf16(bf16(bf16(1-sigma)*x0) + bf16(sigma*noise)), ctrl) ; target = bf16(noise - x0) */
+int qfx_flowmatch_prepare(const uint16_t* x0, const uint16_t* noise, const uint16_t* ctrl, const uint16_t* sigma,
+                          uint16_t* packed, uint16_t* target, int32_t B, int32_t S_t, int32_t S_c, int32_t C, void* stream);
+
+/* ---- fused global-norm clip + AdamW over the flat LoRA parameter buffer ----------------------
+ * (base_trainer.py:449-455 clip_grad_norm_ ; optimizer.step :531 with torch.optim.AdamW semantics) */
+int qfx_sumsq(const float* g, int64_t n, float* out /* zeroed by caller */, void* stream);
+int qfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                   const float* gnorm_sq /* may be NULL */, float max_norm, float grad_scale, void* stream);
+
+/* ---- misc ---- */
+int qfx_abi_version(void);
+const char* qfx_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QFX_H */

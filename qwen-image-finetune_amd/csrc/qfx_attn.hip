@@ -1,0 +1,493 @@
+// qfx_attn.hip -- joint [text|image] non-causal flash attention for gfx950, forward + backward.
+//
+// MFMA 16x16x32 bf16 everywhere; every operand is read K-contiguous from row-major LDS tiles:
+// the transposed views an attention backward needs (Q^T, K^T, V^T, dO^T as [B,H,dh,S_pad]) are
+// materialised once per block by qfx_transpose_heads (HBM is plentiful, LDS transposes are not).
+// Scores are computed "swapped" (S^T = K Q^T, i.e. D[i=key][j=query]) so that a lane owns ONE
+// query column: softmax statistics are lane-local plus two cross-lane steps, and the bf16-packed
+// P registers are directly the B operand of the PV MFMA under the key permutation
+//     pi(g, j) = 16*(2t) + 4g + j (j<4) ; 16*(2t+1) + 4g + (j-4) (j>=4)
+// which the V^T fragment read applies too (a consistent k-permutation leaves a contraction intact).
+// Tiles arrive by LDS-DMA with the bank swizzle applied on the global source address.
+//
+// lse2 is the log2-domain logsumexp of (scale * q.k + mask): P = exp2(scale*log2e * s + mask*log2e - lse2).
+#include "qfx_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)g, (QFX_AS3 void*)lds, 16, 0, 0);
+}
+
+template <int DH> __device__ __forceinline__ int swz_row(int row) {
+  if constexpr (DH == 128) return row & 15; else return (row >> 1) & 7;
+}
+
+// 64 rows x DH tile of a token-major tensor (rows s0..s0+63 clamped to S-1) -> LDS [64][DH], swizzled.
+// base points at element [b, 0, h, 0]; ld = row stride in elements.
+template <int DH>
+__device__ __forceinline__ void stage_rows(char* lds, const bf16_t* base, int64_t ld, int s0, int S, int w, int lane) {
+  constexpr int CPR = DH / 8;        // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;      // rows per wave-instruction
+  constexpr int NI = 16 / RPI;       // instructions per wave (16 rows per wave)
+  const int rr = lane / CPR, c = lane % CPR;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = w * 16 + i * RPI + rr;
+    int s = s0 + row; s = s < S ? s : S - 1;
+    const int sc = c ^ swz_row<DH>(row);
+    glds16(base + (int64_t)s * ld + sc * 8, lds + (w * 16 + i * RPI) * (DH * 2));
+  }
+}
+
+// DH rows x 64 tile of a [.., DH, S_pad] tensor (columns s0..s0+63) -> LDS [DH][64], swizzled.
+// base points at element [b, h, 0, 0].
+template <int DH>
+__device__ __forceinline__ void stage_cols(char* lds, const bf16_t* base, int64_t S_pad, int s0, int w, int lane) {
+  constexpr int NI = DH / 32;  // 8 rows per wave-instruction, DH/4 rows per wave
+  const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = w * (DH / 4) + i * 8 + rr;
+    const int sc = c ^ ((row >> 1) & 7);
+    glds16(base + (int64_t)row * S_pad + s0 + sc * 8, lds + (w * (DH / 4) + i * 8) * 128);
+  }
+}
+
+// fragment (16 rows x 32 k) of a [64][DH] tile: lane (g, li) gets row rf*16+li, k = kk*32 + 8g..+7
+template <int DH>
+__device__ __forceinline__ bf16x8 read_rowfrag(const char* lds, int rf, int kk, int g, int li) {
+  const int row = rf * 16 + li;
+  const int chunk = kk * 4 + g;
+  return *(const bf16x8*)(lds + row * (DH * 2) + ((chunk ^ swz_row<DH>(row)) << 4));
+}
+
+// fragment of a [DH][64] tile under the pi permutation: row df*16+li, cols {32t+4g..+3, 32t+16+4g..+3}
+__device__ __forceinline__ bf16x8 read_colfrag(const char* lds, int df, int t, int g, int li) {
+  const int row = df * 16 + li;
+  const int sw = (row >> 1) & 7;
+  const int c1 = 4 * t + (g >> 1), c2 = c1 + 2;
+  const int off = 8 * (g & 1);
+  const bf16x4 lo = *(const bf16x4*)(lds + row * 128 + ((c1 ^ sw) << 4) + off);
+  const bf16x4 hi = *(const bf16x4*)(lds + row * 128 + ((c2 ^ sw) << 4) + off);
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = (short)f2bf(a[i]); r[4 + i] = (short)f2bf(b[i]); }
+  return r;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// =============================================================================================
+// forward: block = 128 queries (4 waves x 32), loop over 64-key tiles, K/V^T double-buffered in LDS
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a) {
+  constexpr int KC = DH / 32, DF = DH / 16;
+  constexpr int TB = 64 * DH * 2;  // bytes per tile (K tile and V^T tile are the same size)
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int S = a.S;
+
+  const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
+  const bf16_t* Vtb = a.Vt + ((int64_t)b * a.H + h) * DH * a.S_pad;
+
+  bf16x8 qf[2][KC];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int q = q0 + f * 16 + li; q = q < S ? q : S - 1;
+    const bf16_t* qp = a.Q + ((int64_t)b * S + q) * a.ldq + h * DH + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) qf[f][kk] = *(const bf16x8*)(qp + kk * 32);
+  }
+  f32x4 oacc[DF][2];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) { oacc[d][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; oacc[d][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+  const float c2 = a.scale * LOG2E;
+  const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
+
+  const int ntiles = (S + 63) / 64;
+  stage_rows<DH>(smem, Kb, a.ldk, 0, S, w, lane);
+  stage_cols<DH>(smem + TB, Vtb, a.S_pad, 0, w, lane);
+  __syncthreads();
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const char* sK = smem + (jt & 1) * 2 * TB;
+    const char* sVt = sK + TB;
+    if (jt + 1 < ntiles) {
+      char* nK = smem + ((jt + 1) & 1) * 2 * TB;
+      stage_rows<DH>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
+      stage_cols<DH>(nK + TB, Vtb, a.S_pad, (jt + 1) * 64, w, lane);
+    }
+    const int j0 = jt * 64;
+    f32x4 sacc[4][2];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      sacc[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sacc[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        const bf16x8 kfr = read_rowfrag<DH>(sK, kf, kk, g, li);
+        sacc[kf][0] = MFMA(kfr, qf[0][kk], sacc[kf][0]);
+        sacc[kf][1] = MFMA(kfr, qf[1][kk], sacc[kf][1]);
+      }
+    }
+    // scale, mask, online softmax (lane owns query column li of each q-fragment; keys 16kf+4g+r)
+    float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + kf * 16 + 4 * g + r;
+        const bool ok = key < S;
+        const float mk = (maskb && ok) ? maskb[key] * LOG2E : 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const float s = ok ? sacc[kf][f][r] * c2 + mk : -INFINITY;
+          sacc[kf][f][r] = s;
+          mx[f] = fmaxf(mx[f], s);
+        }
+      }
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float m = mx[f];
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      const float mnew = fmaxf(mrow[f], m);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = exp2f(mrow[f] - msafe);
+      mrow[f] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(sacc[kf][f][r] - msafe);
+          sacc[kf][f][r] = p;
+          ps += p;
+        }
+      lrow[f] = lrow[f] * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[d][f][r] *= alpha;
+      pb[f][0] = pack8(sacc[0][f], sacc[1][f]);
+      pb[f][1] = pack8(sacc[2][f], sacc[3][f]);
+    }
+#pragma unroll
+    for (int d = 0; d < DF; ++d)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 vfr = read_colfrag(sVt, d, t, g, li);
+        oacc[d][0] = MFMA(vfr, pb[0][t], oacc[d][0]);
+        oacc[d][1] = MFMA(vfr, pb[1][t], oacc[d][1]);
+      }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    float l = lrow[f];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const int q = q0 + f * 16 + li;
+    if (q < S) {
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      bf16_t* op = a.O + ((int64_t)b * S + q) * a.ldo + h * DH + 4 * g;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        u32x2 u;
+        u[0] = pack2bf(oacc[d][f][0] * inv, oacc[d][f][1] * inv);
+        u[1] = pack2bf(oacc[d][f][2] * inv, oacc[d][f][3] * inv);
+        *(u32x2*)(op + d * 16) = u;
+      }
+      if (g == 0) a.lse2[((int64_t)b * a.H + h) * a.S_pad + q] = mrow[f] + log2f(l);
+    }
+  }
+}
+
+// =============================================================================================
+// dsum[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]
+template <int DH>
+__global__ __launch_bounds__(256) void attn_prep_kernel(const qfx_attn_args a) {
+  constexpr int LPI = DH / 8;
+  const int sub = threadIdx.x % LPI;
+  const int64_t item = (int64_t)blockIdx.x * (256 / LPI) + threadIdx.x / LPI;
+  const int64_t n = (int64_t)a.B * a.S * a.H;
+  const int64_t it = item < n ? item : n - 1;
+  const int64_t tok = it / a.H;
+  const int h = (int)(it % a.H);
+  const u32x4 uo = *(const u32x4*)(a.O + tok * a.ldo + h * DH + sub * 8);
+  const u32x4 ud = *(const u32x4*)(a.dO + tok * a.lddo + h * DH + sub * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s += __uint_as_float(uo[i] << 16) * __uint_as_float(ud[i] << 16);
+    s += __uint_as_float(uo[i] & 0xffff0000u) * __uint_as_float(ud[i] & 0xffff0000u);
+  }
+#pragma unroll
+  for (int o = 1; o < LPI; o <<= 1) s += __shfl_xor(s, o);
+  if (sub == 0 && item < n) {
+    const int bb = (int)(tok / a.S), ss = (int)(tok % a.S);
+    a.dsum[((int64_t)bb * a.H + h) * a.S_pad + ss] = s;
+  }
+}
+
+// =============================================================================================
+// dQ: block = 128 queries (4 waves x 32), loop over 64-key tiles (K, V row tiles + K^T column tile)
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args a) {
+  constexpr int KC = DH / 32, DF = DH / 16;
+  constexpr int TB = 64 * DH * 2;
+  __shared__ __attribute__((aligned(16))) char smem[3 * TB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int S = a.S;
+  const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
+  const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
+  const bf16_t* Ktb = a.Kt + ((int64_t)b * a.H + h) * DH * a.S_pad;
+  char* sK = smem; char* sV = smem + TB; char* sKt = smem + 2 * TB;
+
+  bf16x8 qf[2][KC], dof[2][KC];
+  float lse[2], dsm[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int q = q0 + f * 16 + li; q = q < S ? q : S - 1;
+    const bf16_t* qp = a.Q + ((int64_t)b * S + q) * a.ldq + h * DH + 8 * g;
+    const bf16_t* dp = a.dO + ((int64_t)b * S + q) * a.lddo + h * DH + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) { qf[f][kk] = *(const bf16x8*)(qp + kk * 32); dof[f][kk] = *(const bf16x8*)(dp + kk * 32); }
+    lse[f] = a.lse2[((int64_t)b * a.H + h) * a.S_pad + q];
+    dsm[f] = a.dsum[((int64_t)b * a.H + h) * a.S_pad + q];
+  }
+  f32x4 dq[DF][2];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) { dq[d][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq[d][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const float c2 = a.scale * LOG2E;
+  const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
+
+  const int ntiles = (S + 63) / 64;
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const int j0 = jt * 64;
+    stage_rows<DH>(sK, Kb, a.ldk, j0, S, w, lane);
+    stage_rows<DH>(sV, Vb, a.ldv, j0, S, w, lane);
+    stage_cols<DH>(sKt, Ktb, a.S_pad, j0, w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 sa[2][2], da[2][2];  // [kf local][qf]
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int kf = 2 * t + k2;
+        sa[k2][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sa[k2][1] = sa[k2][0]; da[k2][0] = sa[k2][0]; da[k2][1] = sa[k2][0];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          const bf16x8 kfr = read_rowfrag<DH>(sK, kf, kk, g, li);
+          const bf16x8 vfr = read_rowfrag<DH>(sV, kf, kk, g, li);
+          sa[k2][0] = MFMA(kfr, qf[0][kk], sa[k2][0]);
+          sa[k2][1] = MFMA(kfr, qf[1][kk], sa[k2][1]);
+          da[k2][0] = MFMA(vfr, dof[0][kk], da[k2][0]);
+          da[k2][1] = MFMA(vfr, dof[1][kk], da[k2][1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = j0 + kf * 16 + 4 * g + r;
+          const bool ok = key < S;
+          const float mk = (maskb && ok) ? maskb[key] * LOG2E : 0.f;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const float p = ok ? exp2f(sa[k2][f][r] * c2 + mk - lse[f]) : 0.f;
+            sa[k2][f][r] = ok ? p * (da[k2][f][r] - dsm[f]) : 0.f;
+          }
+        }
+      }
+      const bf16x8 ds0 = pack8(sa[0][0], sa[1][0]);
+      const bf16x8 ds1 = pack8(sa[0][1], sa[1][1]);
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const bf16x8 ktf = read_colfrag(sKt, d, t, g, li);
+        dq[d][0] = MFMA(ktf, ds0, dq[d][0]);
+        dq[d][1] = MFMA(ktf, ds1, dq[d][1]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int q = q0 + f * 16 + li;
+    if (q < S) {
+      bf16_t* op = a.dQ + ((int64_t)b * S + q) * a.lddq + h * DH + 4 * g;
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        u32x2 u;
+        u[0] = pack2bf(dq[d][f][0] * a.scale, dq[d][f][1] * a.scale);
+        u[1] = pack2bf(dq[d][f][2] * a.scale, dq[d][f][3] * a.scale);
+        *(u32x2*)(op + d * 16) = u;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// dK, dV: block = 64 keys (4 waves x 16), loop over 64-query tiles (Q, dO row tiles + Q^T, dO^T column tiles)
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const qfx_attn_args a) {
+  constexpr int KC = DH / 32, DF = DH / 16;
+  constexpr int TB = 64 * DH * 2;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int key0 = blockIdx.x * 64 + w * 16;
+  const int S = a.S;
+  const bf16_t* Qb = a.Q + (int64_t)b * S * a.ldq + h * DH;
+  const bf16_t* dOb = a.dO + (int64_t)b * S * a.lddo + h * DH;
+  const bf16_t* Qtb = a.Qt + ((int64_t)b * a.H + h) * DH * a.S_pad;
+  const bf16_t* dOtb = a.dOt + ((int64_t)b * a.H + h) * DH * a.S_pad;
+  const float* lseb = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;
+  const float* dsb = a.dsum + ((int64_t)b * a.H + h) * a.S_pad;
+  char* sQ = smem; char* sdO = smem + TB; char* sQt = smem + 2 * TB; char* sdOt = smem + 3 * TB;
+
+  bf16x8 kf[KC], vf[KC];
+  int mykey = key0 + li;
+  const bool keyok = mykey < S;
+  mykey = keyok ? mykey : S - 1;
+  {
+    const bf16_t* kp = a.K + ((int64_t)b * S + mykey) * a.ldk + h * DH + 8 * g;
+    const bf16_t* vp = a.V + ((int64_t)b * S + mykey) * a.ldv + h * DH + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) { kf[kk] = *(const bf16x8*)(kp + kk * 32); vf[kk] = *(const bf16x8*)(vp + kk * 32); }
+  }
+  const float mk = (a.key_mask && keyok) ? a.key_mask[(int64_t)b * S + mykey] * LOG2E : 0.f;
+  f32x4 dk[DF], dv[DF];
+#pragma unroll
+  for (int d = 0; d < DF; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
+  const float c2 = a.scale * LOG2E;
+
+  const int ntiles = (S + 63) / 64;
+  for (int it = 0; it < ntiles; ++it) {
+    const int i0 = it * 64;
+    stage_rows<DH>(sQ, Qb, a.ldq, i0, S, w, lane);
+    stage_rows<DH>(sdO, dOb, a.lddo, i0, S, w, lane);
+    stage_cols<DH>(sQt, Qtb, a.S_pad, i0, w, lane);
+    stage_cols<DH>(sdOt, dOtb, a.S_pad, i0, w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 sa[2], da[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int qfi = 2 * t + q2;
+        sa[q2] = (f32x4){0.f, 0.f, 0.f, 0.f}; da[q2] = sa[q2];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          sa[q2] = MFMA(read_rowfrag<DH>(sQ, qfi, kk, g, li), kf[kk], sa[q2]);     // D[i=q][j=key]
+          da[q2] = MFMA(read_rowfrag<DH>(sdO, qfi, kk, g, li), vf[kk], da[q2]);
+        }
+        const int qb = i0 + qfi * 16 + 4 * g;  // rows qb..qb+3 (multiple of 4, < S_pad)
+        const f32x4 l4 = *(const f32x4*)(lseb + qb);
+        const f32x4 d4 = *(const f32x4*)(dsb + qb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (qb + r) < S;
+          const float p = ok ? exp2f(sa[q2][r] * c2 + mk - l4[r]) : 0.f;
+          da[q2][r] = ok ? p * (da[q2][r] - d4[r]) : 0.f;
+          sa[q2][r] = p;
+        }
+      }
+      const bf16x8 pb = pack8(sa[0], sa[1]);
+      const bf16x8 dsbf = pack8(da[0], da[1]);
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        dv[d] = MFMA(read_colfrag(sdOt, d, t, g, li), pb, dv[d]);     // D[i=dv][j=key]
+        dk[d] = MFMA(read_colfrag(sQt, d, t, g, li), dsbf, dk[d]);
+      }
+    }
+    __syncthreads();
+  }
+  if (keyok) {
+    bf16_t* kp = a.dK + ((int64_t)b * S + mykey) * a.lddk + h * DH + 4 * g;
+    bf16_t* vp = a.dV + ((int64_t)b * S + mykey) * a.lddv + h * DH + 4 * g;
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      u32x2 u;
+      u[0] = pack2bf(dk[d][0] * a.scale, dk[d][1] * a.scale);
+      u[1] = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
+      *(u32x2*)(kp + d * 16) = u;
+      u[0] = pack2bf(dv[d][0], dv[d][1]);
+      u[1] = pack2bf(dv[d][2], dv[d][3]);
+      *(u32x2*)(vp + d * 16) = u;
+    }
+  }
+}
+
+int check_common(const qfx_attn_args* a) {
+  if (!a || a->B <= 0 || a->S <= 0 || a->H <= 0 || (a->S_pad % 64) || a->S_pad < a->S) return QFX_EINVAL;
+  if (a->dh != 64 && a->dh != 128) return QFX_EUNSUPPORTED;
+  return QFX_OK;
+}
+
+}  // namespace
+
+extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!a->Q || !a->K || !a->Vt || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldo % 4)) return QFX_EINVAL;
+  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  if (a->dh == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!a->O || !a->dO || !a->dsum || (a->ldo % 8) || (a->lddo % 8)) return QFX_EINVAL;
+  const int64_t n = (int64_t)a->B * a->S * a->H;
+  const int ipb = 256 / (a->dh / 8);
+  dim3 grid((unsigned)((n + ipb - 1) / ipb));
+  if (a->dh == 128) hipLaunchKernelGGL(attn_prep_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(attn_prep_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!a->Q || !a->K || !a->V || !a->Kt || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
+  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (!a->Q || !a->Qt || !a->K || !a->V || !a->dO || !a->dOt || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
+  dim3 grid((a->S + 63) / 64, a->H, a->B);
+  if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}

@@ -1,0 +1,618 @@
+// qfx_elem.hip -- the HBM-bound row kernels of the DiT block: LayerNorm+modulate (fwd/bwd),
+// RMSNorm, modulation GEMV, QK-RMSNorm+RoPE (fwd/bwd), head transposes, criterion, clip+AdamW.
+// All bf16 traffic is 16 bytes per lane; one wave owns one row so reductions are shuffle-only.
+// Rounding points replicate the reference's bf16 eager graph (every torch op rounds its output).
+#include "qfx_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int MAXP = 8;  // 8 passes x 64 lanes x 8 elems = rows up to 4096 wide
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+  const u32x4 u = *(const u32x4*)p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(u[i] << 16);
+    v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+  u32x4 u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  *(u32x4*)p = u;
+}
+
+// ---------------------------------------------------------------- LayerNorm + modulate, forward
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ shift,
+                                                         const bf16_t* __restrict__ scale, int64_t mod_bstride,
+                                                         bf16_t* __restrict__ y, int rows, int D, int rpb, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row / rpb;
+  const bf16_t* xr = x + (int64_t)row * D;
+  float v[MAXP][8];
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      ld8(xr + col, v[p]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[p][i];
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[p][i] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      float sc[8], sh[8], o[8];
+      ld8(scale + (int64_t)b * mod_bstride + col, sc);
+      ld8(shift + (int64_t)b * mod_bstride + col, sh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float ln = rbf((v[p][i] - mean) * rstd);
+        const float t1 = rbf(1.0f + sc[i]);
+        o[i] = rbf(ln * t1) + sh[i];
+      }
+      st8(y + (int64_t)row * D + col, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm + modulate, backward
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                         const bf16_t* __restrict__ scale, int64_t mod_bstride,
+                                                         const bf16_t* __restrict__ dres, const bf16_t* __restrict__ gate,
+                                                         int64_t gate_bstride, bf16_t* __restrict__ dx,
+                                                         bf16_t* __restrict__ dyg, int rows, int D, int rpb, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row / rpb;
+  const int64_t ro = (int64_t)row * D;
+  float v[MAXP][8];   // x, later xhat
+  float gq[MAXP][8];  // g = bf16(dy * bf16(1+scale))
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      ld8(x + ro + col, v[p]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[p][i];
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[p][i] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      float sc[8], d[8];
+      ld8(scale + (int64_t)b * mod_bstride + col, sc);
+      ld8(dy + ro + col, d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[p][i] = (v[p][i] - mean) * rstd;
+        gq[p][i] = rbf(d[i] * rbf(1.0f + sc[i]));
+        c1 += gq[p][i];
+        c2 += gq[p][i] * v[p][i];
+      }
+    }
+  }
+  c1 = wave_sum(c1) / (float)D;
+  c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      float o[8], r[8];
+      if (dres) ld8(dres + ro + col, r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dl = rbf((gq[p][i] - c1 - v[p][i] * c2) * rstd);
+        o[i] = dres ? rbf(r[i] + dl) : dl;
+      }
+      st8(dx + ro + col, o);
+      if (dyg) {
+        float gt[8], og[8];
+        ld8(gate + (int64_t)b * gate_bstride + col, gt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) og[i] = gt[i] * o[i];
+        st8(dyg + ro + col, og);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_mul_kernel(const bf16_t* __restrict__ dx, const bf16_t* __restrict__ gate,
+                                                       int64_t gate_bstride, bf16_t* __restrict__ dyg, int64_t total8,
+                                                       int D, int rpb) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 8;
+    const int row = (int)(e / D), col = (int)(e % D);
+    float a[8], g[8], o[8];
+    ld8(dx + e, a);
+    ld8(gate + (int64_t)(row / rpb) * gate_bstride + col, g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = a[k] * g[k];
+    st8(dyg + e, o);
+  }
+}
+
+// ---------------------------------------------------------------- RMSNorm with weight (txt_norm)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y, int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[MAXP][8];
+  float s = 0.f;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      ld8(x + (int64_t)row * D + col, v[p]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[p][i] * v[p][i];
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(s) / (float)D + eps);
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+      float ww[8], o[8];
+      ld8(w + col, ww);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = rbf(v[p][i] * rstd) * ww[i];
+      st8(y + (int64_t)row * D + col, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- modulation GEMV (pure weight streaming)
+// out[mat][b][n] = bf16(sum_k bf16(silu(temb[b][k])) W_mat[n][k] + bias_mat[n]); wave = 4 rows of W.
+__global__ __launch_bounds__(256) void mod_gemv_kernel(const bf16_t* __restrict__ temb, int B, int K,
+                                                       const bf16_t* const* __restrict__ Ws,
+                                                       const bf16_t* const* __restrict__ biases, int N,
+                                                       int apply_silu, bf16_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* sT = (bf16_t*)smem_raw;  // [B][K] bf16(silu(temb))
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < B * K; i += 256) {
+    const float t = bf2f(temb[i]);
+    sT[i] = apply_silu ? f2bf(t / (1.0f + __expf(-t))) : temb[i];
+  }
+  __syncthreads();
+  const int mat = blockIdx.y;
+  const bf16_t* W = Ws[mat];
+  const int n0 = (blockIdx.x * 4 + w) * 4;
+  if (n0 >= N) return;
+  float acc[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[r][b] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    float wv[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r < N ? n0 + r : N - 1;
+      ld8(W + (int64_t)n * K + k, wv[r]);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b < B) {
+        float tv[8];
+        ld8(sT + b * K + k, tv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[r][b] = fmaf(wv[r][i], tv[i], acc[r][b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b < B) acc[r][b] = wave_sum(acc[r][b]);
+  if (lane == 0) {
+    const bf16_t* bias = biases ? biases[mat] : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r;
+      if (n < N) {
+        const float bv = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (b < B) out[((int64_t)mat * B + b) * N + n] = f2bf(acc[r][b] + bv);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- QK RMSNorm + RoPE (in place on qkv)
+template <int DH, bool BWD>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ qkv, bf16_t* __restrict__ saved,
+                                                           const float* __restrict__ rope,
+                                                           const bf16_t* __restrict__ wq_txt, const bf16_t* __restrict__ wk_txt,
+                                                           const bf16_t* __restrict__ wq_img, const bf16_t* __restrict__ wk_img,
+                                                           int B, int S, int T, int H, float eps) {
+  constexpr int LPI = DH / 8;        // lanes per (token, q|k, head) item
+  constexpr int IPB = 256 / LPI;     // items per block
+  const int sub = threadIdx.x % LPI;
+  const int64_t item = (int64_t)blockIdx.x * IPB + threadIdx.x / LPI;
+  const int64_t nitems = (int64_t)B * S * 2 * H;
+  const bool valid = item < nitems;
+  const int64_t it = valid ? item : nitems - 1;
+  const int64_t token = it / (2 * H);
+  const int rem = (int)(it % (2 * H));
+  const int which = rem / H, h = rem % H;
+  const int s = (int)(token % S);
+  const int Dm = H * DH;
+  bf16_t* px = qkv + token * 3 * Dm + which * Dm + h * DH + sub * 8;
+  bf16_t* ps = saved ? saved + token * 2 * Dm + which * Dm + h * DH + sub * 8 : nullptr;
+  const bf16_t* wsel = (s < T) ? (which ? wk_txt : wq_txt) : (which ? wk_img : wq_img);
+  float w[8], cs[8];
+  ld8(wsel + sub * 8, w);
+  {
+    const f32x4 c0 = *(const f32x4*)(rope + ((int64_t)s * (DH / 2) + sub * 4) * 2);
+    const f32x4 c1 = *(const f32x4*)(rope + ((int64_t)s * (DH / 2) + sub * 4) * 2 + 4);
+    cs[0] = c0[0]; cs[1] = c0[1]; cs[2] = c0[2]; cs[3] = c0[3];
+    cs[4] = c1[0]; cs[5] = c1[1]; cs[6] = c1[2]; cs[7] = c1[3];
+  }
+  if constexpr (!BWD) {
+    float x[8];
+    ld8(px, x);
+    if (ps && valid) st8(ps, x);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+    for (int o = 1; o < LPI; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss / (float)DH + eps);
+    float o8[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t0 = rbf(rbf(x[2 * j] * rstd) * w[2 * j]);
+      const float t1 = rbf(rbf(x[2 * j + 1] * rstd) * w[2 * j + 1]);
+      const float c = cs[2 * j], sn = cs[2 * j + 1];
+      o8[2 * j] = t0 * c - t1 * sn;
+      o8[2 * j + 1] = t0 * sn + t1 * c;
+    }
+    if (valid) st8(px, o8);
+  } else {
+    float dy[8], x[8];
+    ld8(px, dy);
+    ld8(ps, x);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+#pragma unroll
+    for (int o = 1; o < LPI; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss / (float)DH + eps);
+    float dn[8], xh[8];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float c = cs[2 * j], sn = cs[2 * j + 1];
+      const float d0 = rbf(dy[2 * j] * c + dy[2 * j + 1] * sn);     // dy * conj(f)
+      const float d1 = rbf(-dy[2 * j] * sn + dy[2 * j + 1] * c);
+      dn[2 * j] = rbf(d0 * w[2 * j]);
+      dn[2 * j + 1] = rbf(d1 * w[2 * j + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xh[i] = x[i] * rstd; dot += dn[i] * xh[i]; }
+#pragma unroll
+    for (int o = 1; o < LPI; o <<= 1) dot += __shfl_xor(dot, o);
+    dot /= (float)DH;
+    float o8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o8[i] = (dn[i] - xh[i] * dot) * rstd;
+    if (valid) st8(px, o8);
+  }
+}
+
+// ---------------------------------------------------------------- [B,S,(H,dh)] -> [B,H,dh,S_pad]
+__global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16_t* __restrict__ in, int64_t ld_in,
+                                                              bf16_t* __restrict__ out, int S, int S_pad, int HD) {
+  __shared__ bf16_t tile[64][66];
+  const int s0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + it * 256;  // 512 chunks of 8
+    const int r = e >> 3, ch = e & 7;
+    const int s = s0 + r;
+    u32x4 u = {0u, 0u, 0u, 0u};
+    if (s < S) u = *(const u32x4*)(in + ((int64_t)b * S + s) * ld_in + c0 + ch * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tile[r][ch * 8 + 2 * i] = (bf16_t)(u[i] & 0xffffu);
+      tile[r][ch * 8 + 2 * i + 1] = (bf16_t)(u[i] >> 16);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + it * 256;
+    const int c = e >> 3, ch = e & 7;  // out row = column c, 8 tokens ch*8..
+    u32x4 u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      u[i] = (uint32_t)tile[ch * 8 + 2 * i][c] | ((uint32_t)tile[ch * 8 + 2 * i + 1][c] << 16);
+    *(u32x4*)(out + ((int64_t)b * HD + c0 + c) * S_pad + s0 + ch * 8) = u;
+  }
+}
+
+// ---------------------------------------------------------------- criterion (weighted-MSE with weight 1)
+__global__ __launch_bounds__(256) void mse_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ target,
+                                                  float* __restrict__ loss, bf16_t* __restrict__ dpred, int B, int S_all,
+                                                  int S_t, int C, float gscale) {
+  __shared__ float red[4];
+  const int64_t total = (int64_t)B * S_all * C;
+  const float inv = 1.0f / ((float)B * (float)S_t * (float)C);
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t t = i / C;
+    const int s = (int)(t % S_all), b = (int)(t / S_all);
+    float g = 0.f;
+    if (s < S_t) {
+      const float d = bf2f(pred[i]) - bf2f(target[((int64_t)b * S_t + s) * C + c]);
+      acc += d * d;
+      g = 2.0f * d * inv * gscale;
+    }
+    if (dpred) dpred[i] = f2bf(g);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += g[i] * g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, const float* __restrict__ gnorm_sq,
+                                                    float max_norm, float grad_scale) {
+  float clip = grad_scale;
+  if (gnorm_sq != nullptr && max_norm > 0.f) {
+    const float nrm = sqrtf(*gnorm_sq) * grad_scale;
+    const float c = max_norm / (nrm + 1e-6f);
+    clip *= c < 1.0f ? c : 1.0f;
+  }
+  const float step = lr / bc1;
+  const float rs2 = 1.0f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= step * mi / (sqrtf(vi) * rs2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+__global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __restrict__ t, int B, int dim, float scale,
+                                                             bf16_t* __restrict__ out) {
+  const int half = dim / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * half; i += gridDim.x * blockDim.x) {
+    const int b = i / half, j = i % half;
+    const float tv = rbf(t[b]);
+    const float f = expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
+    const float e = scale * (tv * f);
+    out[b * dim + j] = f2bf(cosf(e));
+    out[b * dim + half + j] = f2bf(sinf(e));
+  }
+}
+
+__global__ __launch_bounds__(256) void flowmatch_prepare_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ noise,
+                                                                const bf16_t* __restrict__ ctrl, const bf16_t* __restrict__ sigma,
+                                                                bf16_t* __restrict__ packed, bf16_t* __restrict__ target,
+                                                                int B, int S_t, int S_c, int C) {
+  const int64_t total = (int64_t)B * (S_t + S_c) * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int s = (int)(r % (S_t + S_c)), b = (int)(r / (S_t + S_c));
+    if (s < S_t) {
+      const int64_t j = ((int64_t)b * S_t + s) * C + c;
+      const float sg = bf2f(sigma[b]), a = bf2f(x0[j]), n = bf2f(noise[j]);
+      packed[i] = f2bf(rbf(rbf(1.0f - sg) * a) + rbf(sg * n));
+      target[j] = f2bf(n - a);
+    } else {
+      packed[i] = ctrl[((int64_t)b * S_c + (s - S_t)) * C + c];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, uint16_t* out, void* stream) {
+  if (!t || !out || B <= 0 || dim <= 0 || (dim % 2)) return QFX_EINVAL;
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, B, dim, scale, out);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_flowmatch_prepare(const uint16_t* x0, const uint16_t* noise, const uint16_t* ctrl, const uint16_t* sigma,
+                                     uint16_t* packed, uint16_t* target, int32_t B, int32_t S_t, int32_t S_c, int32_t C,
+                                     void* stream) {
+  if (!x0 || !noise || !sigma || !packed || !target || B <= 0 || S_t <= 0 || S_c < 0 || C <= 0 || (S_c > 0 && !ctrl)) return QFX_EINVAL;
+  const int64_t total = (int64_t)B * (S_t + S_c) * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(flowmatch_prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x0, noise, ctrl, sigma, packed,
+                     target, B, S_t, S_c, C);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_ln_modulate_fwd(const uint16_t* x, const uint16_t* shift, const uint16_t* scale, int64_t mod_bstride,
+                                   uint16_t* y, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, void* stream) {
+  if (!x || !shift || !scale || !y || rows <= 0 || D <= 0 || (D % 8) || D > MAXP * 512 || rows_per_batch <= 0 || (mod_bstride % 8))
+    return QFX_EINVAL;
+  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, shift, scale,
+                     mod_bstride, y, rows, D, rows_per_batch, eps);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* scale, int64_t mod_bstride,
+                                   const uint16_t* dres, const uint16_t* gate, int64_t gate_bstride, uint16_t* dx,
+                                   uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, void* stream) {
+  if (!dy || !x || !scale || !dx || rows <= 0 || D <= 0 || (D % 8) || D > MAXP * 512 || rows_per_batch <= 0 || (mod_bstride % 8))
+    return QFX_EINVAL;
+  if (dyg && (!gate || (gate_bstride % 8))) return QFX_EINVAL;
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, scale,
+                     mod_bstride, dres, gate, gate_bstride, dx, dyg, rows, D, rows_per_batch, eps);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg, int32_t rows,
+                            int32_t D, int32_t rows_per_batch, void* stream) {
+  if (!dx || !gate || !dyg || rows <= 0 || D <= 0 || (D % 8) || (gate_bstride % 8) || rows_per_batch <= 0) return QFX_EINVAL;
+  const int64_t total8 = (int64_t)rows * D / 8;
+  int blocks = (int)((total8 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(gate_mul_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dx, gate, gate_bstride, dyg, total8, D,
+                     rows_per_batch);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_rmsnorm_fwd(const uint16_t* x, const uint16_t* w, uint16_t* y, int32_t rows, int32_t D, float eps,
+                               void* stream) {
+  if (!x || !w || !y || rows <= 0 || D <= 0 || (D % 8) || D > MAXP * 512) return QFX_EINVAL;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, y, rows, D, eps);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const uint16_t* const* W, const uint16_t* const* bias,
+                            int32_t nmat, int32_t N, int32_t apply_silu, uint16_t* out, void* stream) {
+  if (!temb || !W || !out || B <= 0 || B > 8 || K <= 0 || (K % 8) || nmat <= 0 || N <= 0) return QFX_EINVAL;
+  const size_t lds = (size_t)B * K * 2;
+  if (lds > 64 * 1024) return QFX_EUNSUPPORTED;
+  hipLaunchKernelGGL(mod_gemv_kernel, dim3((N + 15) / 16, nmat), dim3(256), lds, (hipStream_t)stream, temb, B, K, W, bias, N,
+                     apply_silu, out);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope, const uint16_t* wq_txt,
+                     const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B, int32_t S,
+                     int32_t T, int32_t H, int32_t dh, float eps, void* stream) {
+  if (!qkv || !rope || !wq_txt || !wk_txt || !wq_img || !wk_img || B <= 0 || S <= 0 || T < 0 || T > S || H <= 0) return QFX_EINVAL;
+  if (bwd && !saved) return QFX_EINVAL;
+  const int64_t nitems = (int64_t)B * S * 2 * H;
+  hipStream_t s = (hipStream_t)stream;
+  if (dh == 128) {
+    const int ipb = 256 / 16;
+    dim3 grid((unsigned)((nitems + ipb - 1) / ipb));
+    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<128, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<128, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
+  } else if (dh == 64) {
+    const int ipb = 256 / 8;
+    dim3 grid((unsigned)((nitems + ipb - 1) / ipb));
+    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<64, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<64, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
+  } else {
+    return QFX_EUNSUPPORTED;
+  }
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope, const uint16_t* wq_txt,
+                                    const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
+                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream) {
+  return launch_qk(false, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, stream);
+}
+extern "C" int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope, const uint16_t* wq_txt,
+                                    const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
+                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream) {
+  return launch_qk(true, dqkv, (uint16_t*)saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, stream);
+}
+
+extern "C" int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_t B, int32_t S, int32_t S_pad,
+                                   int32_t H, int32_t dh, void* stream) {
+  if (!in || !out || B <= 0 || S <= 0 || S_pad < S || (S_pad % 64) || ((H * dh) % 64) || (ld_in % 8)) return QFX_EINVAL;
+  hipLaunchKernelGGL(transpose_heads_kernel, dim3(S_pad / 64, H * dh / 64, B), dim3(256), 0, (hipStream_t)stream, in, ld_in,
+                     out, S, S_pad, H * dh);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_mse_loss_fwd_bwd(const uint16_t* pred, const uint16_t* target, float* loss, uint16_t* dpred, int32_t B,
+                                    int32_t S_all, int32_t S_t, int32_t C, float gscale, void* stream) {
+  if (!pred || !target || !loss || B <= 0 || S_all <= 0 || S_t <= 0 || S_t > S_all || C <= 0) return QFX_EINVAL;
+  const int64_t total = (int64_t)B * S_all * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, loss, dpred, B, S_all, S_t, C,
+                     gscale);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_sumsq(const float* g, int64_t n, float* out, void* stream) {
+  if (!g || !out || n <= 0) return QFX_EINVAL;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* gnorm_sq,
+                              float max_norm, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0) return QFX_EINVAL;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bias_corr1, bias_corr2, gnorm_sq, max_norm, grad_scale);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_abi_version(void) { return QFX_ABI_VERSION; }
+extern "C" const char* qfx_build_arch(void) { return "gfx950"; }

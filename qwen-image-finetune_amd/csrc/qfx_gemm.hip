@@ -1,0 +1,220 @@
+// qfx_gemm.hip -- bf16 MFMA GEMM for gfx950 with fused LoRA K-extension and epilogues.
+//
+//   C[M,N] = A1[M,K1] B1[N,K1]^T (+ A2[M,K2] B2[N,K2]^T) + bias  -> epilogue
+//
+// Both operands are K-contiguous ("TN"): the forward uses the nn.Linear weight [N,K] as is, the dX
+// GEMMs use a transposed copy of the frozen weight kept resident in HBM (288 GB makes that free).
+// The LoRA side branch rides along as a second K segment: A2 = [u_hi|u_lo|u_hi] (rank-r down
+// projection split in two bf16), B2 = [sB_hi|sB_hi|sB_lo], i.e. an fp32-accurate rank-r update
+// for 3r extra K columns of MFMA work instead of a separate HBM-bound pass over y.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 fragments.
+// Global->LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), double buffered,
+// one barrier per K tile.  LDS image is lane-linear (DMA constraint) so the bank swizzle
+// chunk' = chunk ^ ((row>>1)&7) is applied on the SOURCE address and again on the ds_read_b128.
+// MFMA operands are swapped (D' = B A^T) so each lane ends up with 4 consecutive N for one M row:
+// 8-byte bf16x4 stores / bias / gate / residual accesses in the epilogue.
+// blockIdx -> tile mapping is XCD-aware (each XCD walks a contiguous chunk of the tile list).
+#include "qfx_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)g, (QFX_AS3 void*)lds, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][A|B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+
+  // ---- XCD-aware tile mapping (bijective for any grid size)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int m0 = (swz % tiles_m) * BM;
+  const int n0 = (swz / tiles_m) * BN;
+
+  // ---- staging addresses: wave w stages rows [w*32, w*32+32) of both tiles, 8 rows per DMA
+  const int srow = lane >> 3;  // 0..7 within the 8-row group
+  const int schunk = lane & 7;
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+  int64_t a_row[4], b_row[4];
+  int sc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lr = w * 32 + i * 8 + srow;
+    sc[i] = (schunk ^ ((lr >> 1) & 7)) * 8;  // source column (elements) inside the 64-wide K tile
+    int gm = m0 + lr; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + lr; gn = gn < p.N ? gn : p.N - 1;
+    a_row[i] = gm; b_row[i] = gn;
+    pa[i] = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1 + sc[i];
+    pb[i] = p.B1 + (int64_t)gn * p.ldb1 + sc[i];
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
+  const int g = lane >> 4, li = lane & 15;
+
+  auto stage = [&](int t) {
+    char* sA = smem + (t & 1) * 2 * TILE_BYTES;
+    char* sB = sA + TILE_BYTES;
+    const int koff = (t < nt1 ? t : t - nt1) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(pa[i] + koff, sA + (w * 32 + i * 8) * (BK * 2));
+      glds16(pb[i] + koff, sB + (w * 32 + i * 8) * (BK * 2));
+    }
+  };
+
+  stage(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) {
+      if (t + 1 == nt1) {  // switch to the LoRA K segment
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pa[i] = p.A2 + a_row[i] * p.lda2 + sc[i];
+          pb[i] = p.B2 + b_row[i] * p.ldb2 + sc[i];
+        }
+      }
+      stage(t + 1);
+    }
+    const char* sA = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* sB = sA + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[4], b[4];
+      const int chunk = kk * 4 + g;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int row = wr * 64 + mi * 16 + li;
+        a[mi] = *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int row = wc * 64 + ni * 16 + li;
+        b[ni] = *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+    }
+    if (nt2 > 0 && t == nt1 - 1) {
+      // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && n + 3 < p.N) {
+          const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = ..+li][n = ..+4g+r], r=0..3
+  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wr * 64 + mi * 16 + li;
+    if (m >= p.M) continue;
+    const int bidx = m / p.rows_per_batch;
+    const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+      if (n + 3 >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+      if (bias_pending) {
+        const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f((bf16_t)bb[r]);
+      }
+      bf16x4 o;
+      if constexpr (EPI == QFX_EPI_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(v[r]);
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+      } else if constexpr (EPI == QFX_EPI_GELU) {
+        bf16x4 o2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16_t h = f2bf(v[r]);
+          o[r] = (short)h;
+          o2[r] = (short)f2bf(gelu_tanh_f(bf2f(h)));
+        }
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+        *(bf16x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+      } else if constexpr (EPI == QFX_EPI_GATE_RES) {
+        const bf16x4 gt = *(const bf16x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
+        const bf16x4 rs = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = rbf(v[r]);
+          const float gy = rbf(bf2f((bf16_t)gt[r]) * y);
+          o[r] = (short)f2bf(bf2f((bf16_t)rs[r]) + gy);
+        }
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+      } else {  // QFX_EPI_DGELU
+        const bf16x4 hx = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = rbf(v[r]);
+          o[r] = (short)f2bf(y * gelu_tanh_grad_f(bf2f((bf16_t)hx[r])));
+        }
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int qfx_gemm_bf16(const qfx_gemm_args* a, void* stream) {
+  if (!a || !a->A1 || !a->B1 || !a->C) return QFX_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K1 <= 0 || (a->K1 % BK) != 0 || (a->K2 % BK) != 0 || a->K2 < 0) return QFX_EINVAL;
+  if ((a->N % 4) != 0 || (a->lda1 % 8) || (a->ldb1 % 8) || (a->ldc % 4)) return QFX_EINVAL;
+  if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return QFX_EINVAL;
+  if (a->rows_per_batch <= 0) return QFX_EINVAL;
+  if (a->epi == QFX_EPI_GELU && (!a->C2 || (a->ldc2 % 4))) return QFX_EINVAL;
+  if (a->epi == QFX_EPI_GATE_RES && (!a->gate || !a->aux || (a->ldaux % 4))) return QFX_EINVAL;
+  if (a->epi == QFX_EPI_DGELU && (!a->aux || (a->ldaux % 4))) return QFX_EINVAL;
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->epi) {
+    case QFX_EPI_NONE: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_NONE>, dim3(tiles), dim3(256), 0, s, *a); break;
+    case QFX_EPI_GELU: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_GELU>, dim3(tiles), dim3(256), 0, s, *a); break;
+    case QFX_EPI_GATE_RES: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_GATE_RES>, dim3(tiles), dim3(256), 0, s, *a); break;
+    case QFX_EPI_DGELU: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_DGELU>, dim3(tiles), dim3(256), 0, s, *a); break;
+    default: return QFX_EUNSUPPORTED;
+  }
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}

@@ -1,0 +1,131 @@
+"""ctypes binding of libqfx.so (include/qfx.h).  The product path has NO fallback: if the HIP
+library is missing or does not export a symbol this module raises at import time."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqfx.so")
+
+c_u16p = C.c_void_p
+c_f32p = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A1", C.c_void_p), ("B1", C.c_void_p), ("lda1", C.c_int64), ("ldb1", C.c_int64), ("K1", C.c_int32),
+        ("A2", C.c_void_p), ("B2", C.c_void_p), ("lda2", C.c_int64), ("ldb2", C.c_int64), ("K2", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32),
+        ("bias", C.c_void_p),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("C2", C.c_void_p), ("ldc2", C.c_int64),
+        ("aux", C.c_void_p), ("ldaux", C.c_int64),
+        ("gate", C.c_void_p), ("gate_bstride", C.c_int64),
+        ("rows_per_batch", C.c_int32),
+        ("a_batch_rows", C.c_int32), ("a_row_off", C.c_int32),
+        ("c_batch_rows", C.c_int32), ("c_row_off", C.c_int32),
+        ("epi", C.c_int32),
+    ]
+
+
+class LoraDownArgs(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
+        ("W_hi", C.c_void_p), ("W_lo", C.c_void_p), ("ldw", C.c_int64), ("R", C.c_int32),
+        ("U", C.c_void_p), ("ldu", C.c_int64),
+        ("ext", C.c_void_p), ("ld_ext", C.c_int64),
+        ("group_R", C.c_int32), ("group_stride", C.c_int32),
+        ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
+    ]
+
+
+class LoraGradArgs(C.Structure):
+    _fields_ = [
+        ("V", C.c_void_p), ("ldv", C.c_int64), ("R", C.c_int32), ("r_valid", C.c_int32),
+        ("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
+        ("G", C.c_void_p), ("g_sr", C.c_int64), ("g_sc", C.c_int64),
+        ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
+    ]
+
+
+class LoraPackArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("r", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("scale", C.c_float),
+        ("A_hi", C.c_void_p), ("A_lo", C.c_void_p), ("ld_a", C.c_int64),
+        ("Bt_hi", C.c_void_p), ("Bt_lo", C.c_void_p), ("ld_bt", C.c_int64),
+        ("We", C.c_void_p), ("ld_we", C.c_int64),
+        ("WeT", C.c_void_p), ("ld_wet", C.c_int64),
+        ("Rp", C.c_int32), ("Kext", C.c_int32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64),
+        ("Qt", C.c_void_p), ("Kt", C.c_void_p), ("Vt", C.c_void_p),
+        ("O", C.c_void_p), ("ldo", C.c_int64),
+        ("lse2", C.c_void_p), ("dsum", C.c_void_p),
+        ("dO", C.c_void_p), ("lddo", C.c_int64), ("dOt", C.c_void_p),
+        ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
+        ("key_mask", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("S_pad", C.c_int32), ("H", C.c_int32), ("dh", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
+
+# name -> (restype, argtypes); every symbol include/qfx.h declares
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "qfx_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "qfx_lora_down": (C.c_int, [C.POINTER(LoraDownArgs), _vp]),
+    "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),
+    "qfx_lora_pack": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "qfx_ln_modulate_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f, _vp]),
+    "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp]),
+    "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
+    "qfx_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
+    "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "qfx_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f, _vp, _vp]),
+    "qfx_qk_norm_rope_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
+    "qfx_qk_norm_rope_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
+    "qfx_transpose_heads": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "qfx_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "qfx_attn_bwd_prep": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "qfx_attn_bwd_dq": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "qfx_attn_bwd_dkv": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "qfx_mse_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
+    "qfx_flowmatch_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "qfx_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "qfx_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _vp]),
+    "qfx_abi_version": (C.c_int, []),
+    "qfx_build_arch": (C.c_char_p, []),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the gfx950 HIP library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "at the repo root (needs hipcc). qflux_amd has no CPU / eager fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.qfx_abi_version() != 1:
+        raise ImportError("libqfx.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+class QfxError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise QfxError(f"{what} failed with code {rc}" + (" (HIP error %d)" % (-rc - 1000) if rc <= -1000 else ""))

@@ -1,0 +1,203 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/qfx.h).
+These are what the per-kernel parity tests call; the model builds cached argument structs instead
+(models/transformer_qwenimage.py) so that a training step is a flat list of C calls."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+lib = L.lib
+BF = torch.bfloat16
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _bf(t, name):
+    assert t.dtype == BF and t.is_cuda, f"{name}: bf16 CUDA tensor required"
+    return t
+
+
+def gemm(a1, b1, *, bias=None, a2=None, b2=None, out=None, epi=L.EPI_NONE, out2=None, aux=None, gate=None,
+         rows_per_batch=None, a_map=(0, 0), c_map=(0, 0), M=None, c_rows=None):
+    """C = a1 @ b1.T (+ a2 @ b2.T) + bias -> epilogue.  a1 [*,K1] (row stride = a1.stride(0)), b1 [N,K1]."""
+    _bf(a1, "a1"); _bf(b1, "b1")
+    M = a1.shape[0] if M is None else M
+    N, K1 = b1.shape
+    if out is None:
+        out = torch.empty(M if c_rows is None else c_rows, N, dtype=BF, device=a1.device)
+    g = L.GemmArgs()
+    g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _p(a1), _p(b1), a1.stride(0), b1.stride(0), K1
+    if a2 is not None:
+        g.A2, g.B2, g.lda2, g.ldb2, g.K2 = _p(a2), _p(b2), a2.stride(0), b2.stride(0), b2.shape[1]
+    g.M, g.N = M, N
+    g.bias = _p(bias)
+    g.C, g.ldc = _p(out), out.stride(0)
+    if out2 is not None:
+        g.C2, g.ldc2 = _p(out2), out2.stride(0)
+    if aux is not None:
+        g.aux, g.ldaux = _p(aux), aux.stride(0)
+    if gate is not None:
+        g.gate, g.gate_bstride = _p(gate), gate.stride(0)
+    g.rows_per_batch = M if rows_per_batch is None else rows_per_batch
+    g.a_batch_rows, g.a_row_off = a_map
+    g.c_batch_rows, g.c_row_off = c_map
+    g.epi = epi
+    L.check(lib.qfx_gemm_bf16(C.byref(g), stream_ptr()), "qfx_gemm_bf16")
+    return out
+
+
+def lora_down(x, w_hi, w_lo, *, U=None, ext=None, group_R=None, group_stride=0, M=None, rows_per_batch=None, x_map=(0, 0)):
+    a = L.LoraDownArgs()
+    M = x.shape[0] if M is None else M
+    R, K = w_hi.shape
+    a.X, a.ldx, a.M, a.K = _p(x), x.stride(0), M, K
+    a.W_hi, a.W_lo, a.ldw, a.R = _p(w_hi), _p(w_lo), w_hi.stride(0), R
+    if U is not None:
+        a.U, a.ldu = _p(U), U.stride(0)
+    if ext is not None:
+        a.ext, a.ld_ext = _p(ext), ext.stride(0)
+    a.group_R = R if group_R is None else group_R
+    a.group_stride = group_stride
+    a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
+    a.x_batch_rows, a.x_row_off = x_map
+    L.check(lib.qfx_lora_down(C.byref(a), stream_ptr()), "qfx_lora_down")
+
+
+def lora_grad(V, X, G, g_sr, g_sc, *, r_valid=None, M=None, K=None, rows_per_batch=None, x_map=(0, 0)):
+    a = L.LoraGradArgs()
+    M = V.shape[0] if M is None else M
+    a.V, a.ldv, a.R = _p(V), V.stride(0), V.shape[1]
+    a.r_valid = V.shape[1] if r_valid is None else r_valid
+    a.X, a.ldx, a.M, a.K = _p(X), X.stride(0), M, (X.shape[1] if K is None else K)
+    a.G, a.g_sr, a.g_sc = _p(G), g_sr, g_sc
+    a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
+    a.x_batch_rows, a.x_row_off = x_map
+    L.check(lib.qfx_lora_grad(C.byref(a), stream_ptr()), "qfx_lora_grad")
+
+
+def pack_descs_tensor(descs, device):
+    """list[LoraPackArgs] -> uint8 device tensor holding the C array."""
+    arr = (L.LoraPackArgs * len(descs))(*descs)
+    raw = bytes(arr)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def lora_pack(desc_tensor, n, max_dim):
+    L.check(lib.qfx_lora_pack(desc_tensor.data_ptr(), n, max_dim, stream_ptr()), "qfx_lora_pack")
+
+
+def ln_modulate_fwd(x, shift, scale, rows_per_batch, eps=1e-6, out=None):
+    rows, D = x.shape
+    out = torch.empty_like(x) if out is None else out
+    assert shift.stride(0) == scale.stride(0)
+    L.check(lib.qfx_ln_modulate_fwd(_p(x), _p(shift), _p(scale), shift.stride(0), _p(out), rows, D, rows_per_batch, eps,
+                                    stream_ptr()), "qfx_ln_modulate_fwd")
+    return out
+
+
+def ln_modulate_bwd(dy, x, scale, rows_per_batch, dres=None, gate=None, eps=1e-6, want_dyg=False):
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    dyg = torch.empty_like(x) if want_dyg else None
+    L.check(lib.qfx_ln_modulate_bwd(_p(dy), _p(x), _p(scale), scale.stride(0), _p(dres), _p(gate),
+                                    gate.stride(0) if gate is not None else 0, _p(dx), _p(dyg), rows, D, rows_per_batch, eps,
+                                    stream_ptr()), "qfx_ln_modulate_bwd")
+    return dx, dyg
+
+
+def gate_mul(dx, gate, rows_per_batch):
+    rows, D = dx.shape
+    out = torch.empty_like(dx)
+    L.check(lib.qfx_gate_mul(_p(dx), _p(gate), gate.stride(0), _p(out), rows, D, rows_per_batch, stream_ptr()), "qfx_gate_mul")
+    return out
+
+
+def rmsnorm_fwd(x, w, eps=1e-6):
+    rows, D = x.shape
+    out = torch.empty_like(x)
+    L.check(lib.qfx_rmsnorm_fwd(_p(x), _p(w), _p(out), rows, D, eps, stream_ptr()), "qfx_rmsnorm_fwd")
+    return out
+
+
+def ptr_table(tensors, device):
+    return torch.tensor([t.data_ptr() if t is not None else 0 for t in tensors], dtype=torch.int64, device=device)
+
+
+def mod_gemv(temb, weights, biases, apply_silu=True):
+    B, K = temb.shape
+    N = weights[0].shape[0]
+    wt = ptr_table(weights, temb.device)
+    bt = ptr_table(biases, temb.device) if biases is not None else None
+    out = torch.empty(len(weights), B, N, dtype=BF, device=temb.device)
+    L.check(lib.qfx_mod_gemv(_p(temb), B, K, _p(wt), _p(bt), len(weights), N, int(apply_silu), _p(out), stream_ptr()), "qfx_mod_gemv")
+    return out
+
+
+def timestep_embed(t, dim=256, scale=1000.0):
+    out = torch.empty(t.shape[0], dim, dtype=BF, device=t.device)
+    L.check(lib.qfx_timestep_embed(_p(t.float().contiguous()), t.shape[0], dim, scale, _p(out), stream_ptr()), "qfx_timestep_embed")
+    return out
+
+
+def qk_norm_rope(qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps=1e-6, backward=False):
+    fn = lib.qfx_qk_norm_rope_bwd if backward else lib.qfx_qk_norm_rope_fwd
+    L.check(fn(_p(qkv), _p(saved), _p(rope), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img), B, S, T, H, dh, eps, stream_ptr()),
+            "qfx_qk_norm_rope")
+
+
+def transpose_heads(x, ld, B, S, S_pad, H, dh, out=None):
+    """x: pointer-carrying tensor whose element 0 is [b=0,s=0,h=0,d=0]; row stride ld."""
+    out = torch.empty(B, H, dh, S_pad, dtype=BF, device=x.device) if out is None else out
+    L.check(lib.qfx_transpose_heads(_p(x), ld, _p(out), B, S, S_pad, H, dh, stream_ptr()), "qfx_transpose_heads")
+    return out
+
+
+def attn_args(B, S, S_pad, H, dh, scale, **kw):
+    a = L.AttnArgs()
+    a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return a
+
+
+def attn_call(name, a):
+    L.check(getattr(lib, name)(C.byref(a), stream_ptr()), name)
+
+
+def mse_loss_fwd_bwd(pred, target, S_t, gscale=1.0, want_grad=True):
+    B, S_all, Cc = pred.shape
+    loss = torch.zeros((), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    L.check(lib.qfx_mse_loss_fwd_bwd(_p(pred), _p(target), _p(loss), _p(dpred), B, S_all, S_t, Cc, gscale, stream_ptr()),
+            "qfx_mse_loss_fwd_bwd")
+    return loss, dpred
+
+
+def flowmatch_prepare(x0, noise, ctrl, sigma):
+    B, S_t, Cc = x0.shape
+    S_c = ctrl.shape[1] if ctrl is not None else 0
+    packed = torch.empty(B, S_t + S_c, Cc, dtype=BF, device=x0.device)
+    target = torch.empty_like(x0)
+    L.check(lib.qfx_flowmatch_prepare(_p(x0), _p(noise), _p(ctrl), _p(sigma), _p(packed), _p(target), B, S_t, S_c, Cc, stream_ptr()),
+            "qfx_flowmatch_prepare")
+    return packed, target
+
+
+def sumsq(g, out):
+    L.check(lib.qfx_sumsq(_p(g), g.numel(), _p(out), stream_ptr()), "qfx_sumsq")
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    L.check(lib.qfx_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, _p(gnorm_sq), max_norm,
+                               grad_scale, stream_ptr()), "qfx_adamw_step")

@@ -1,0 +1,38 @@
+"""CPU: the C-ABI library loads and exports every symbol include/qfx.h declares (no compute calls)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _built():
+    return os.path.exists(os.path.join(ROOT, "qwen-image-finetune_amd", "qflux_amd", "libqfx.so"))
+
+
+def test_header_symbols_are_exported_and_bound():
+    if not _built():
+        import __graft_entry__ as g
+        g.build()
+    from qflux_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "qfx.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(qfx_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(_lib.lib, name)
+    assert _lib.lib.qfx_abi_version() == 1
+    assert _lib.lib.qfx_build_arch() == b"gfx950"
+
+
+def test_argument_validation_without_gpu():
+    """Rejected arguments return QFX_EINVAL before any launch (safe on a CPU-only host)."""
+    import ctypes as C
+    from qflux_amd import _lib
+    g = _lib.GemmArgs()
+    assert _lib.lib.qfx_gemm_bf16(C.byref(g), None) == -1
+    a = _lib.AttnArgs()
+    assert _lib.lib.qfx_attn_fwd(C.byref(a), None) == -1
+    with pytest.raises(_lib.QfxError):
+        _lib.check(-1, "x")

@@ -1,0 +1,470 @@
+"""GPU parity tests, one per C-ABI entry point: HIP kernel vs a plain fp32 torch restatement of the same op
+(with the reference's bf16 rounding points) on the same seeded inputs.  All calls go through the C ABI."""
+import json
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+DEV = "cuda:0"
+_STATS = {}
+
+
+def _ops():
+    from qflux_amd import ops
+    return ops
+
+
+def rel_err(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    d = (got - ref).abs()
+    denom = ref.abs().max().item() + 1e-12
+    return d.max().item() / denom, d
+
+
+def check(name, got, ref, tol):
+    assert torch.isfinite(got.float()).all(), f"{name}: non-finite output"
+    e, d = rel_err(got, ref)
+    bad = (d > tol * (ref.abs().max().item() + 1e-12)).float().mean().item()
+    _STATS[name] = dict(rel=e, tol=tol, bad_frac=bad)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "kernel_parity.json"), "w") as f:
+        json.dump(_STATS, f, indent=1)
+    if e > tol:
+        idx = torch.nonzero(d == d.max())[0].tolist()
+        raise AssertionError(f"{name}: rel err {e:.3e} > {tol:.1e}; worst at {idx}; bad fraction {bad:.3f}")
+
+
+def rb(x):  # round through bf16
+    return x.to(BF).float()
+
+
+def randn(*s, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*s, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 256, 128), (384, 768, 256), (130, 64, 64), (2432, 1024, 3072)])
+def test_gemm_plain(M, N, K):
+    ops = _ops()
+    a = randn(M, K, seed=1).to(BF)
+    b = randn(N, K, seed=2).to(BF)
+    bias = randn(N, seed=3).to(BF)
+    ref = rb(a.float() @ b.float().t() + bias.float())
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV))
+    check(f"gemm_plain_{M}x{N}x{K}", out, ref, 1e-2)
+
+
+def test_gemm_transpose_detect():
+    """A = I-like asymmetric check: catches swapped row/col in the MFMA C layout."""
+    ops = _ops()
+    M = N = K = 128
+    a = torch.eye(M, K).to(BF)
+    b = (torch.arange(N * K).reshape(N, K) % 61).float().to(BF)
+    out = ops.gemm(a.to(DEV), b.to(DEV))
+    check("gemm_identity", out, b.float().t()[:M, :N], 1e-3)
+
+
+def test_gemm_lora_segment_and_gelu():
+    ops = _ops()
+    M, N, K, K2 = 200, 256, 128, 64
+    a, b = randn(M, K, seed=1).to(BF), randn(N, K, seed=2, scale=0.2).to(BF)
+    a2, b2 = randn(M, K2, seed=3).to(BF), randn(N, K2, seed=4, scale=0.1).to(BF)
+    bias = randn(N, seed=5).to(BF)
+    base = rb(a.float() @ b.float().t() + bias.float())
+    h = rb(base + a2.float() @ b2.float().t())
+    g = rb(F.gelu(h, approximate="tanh"))
+    out2 = torch.empty(M, N, dtype=BF, device=DEV)
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), a2=a2.to(DEV), b2=b2.to(DEV), epi=1, out2=out2)
+    check("gemm_seg2_pre", out, h, 1e-2)
+    check("gemm_seg2_gelu", out2, g, 1e-2)
+
+
+def test_gemm_gate_res_and_remap():
+    ops = _ops()
+    Bn, rpb, T, N, K = 2, 100, 28, 128, 64
+    S = T + rpb
+    M = Bn * rpb
+    a_joint = randn(Bn * S, K, seed=1).to(BF)     # A rows live in a joint [B, S] buffer at offset T
+    b = randn(N, K, seed=2, scale=0.3).to(BF)
+    gate = randn(Bn, N, seed=3).to(BF)
+    res = randn(M, N, seed=4).to(BF)
+    a = a_joint.view(Bn, S, K)[:, T:].reshape(M, K)
+    y = rb(a.float() @ b.float().t())
+    ref = rb(res.float() + rb(gate.float().repeat_interleave(rpb, 0) * y))
+    out = ops.gemm(a_joint.to(DEV), b.to(DEV), epi=2, aux=res.to(DEV), gate=gate.to(DEV), rows_per_batch=rpb,
+                   a_map=(S, T), M=M)
+    check("gemm_gate_res_amap", out, ref, 1e-2)
+    # C remap: write into a joint buffer
+    cj = torch.zeros(Bn * S, N, dtype=BF, device=DEV)
+    ops.gemm(a.contiguous().to(DEV), b.to(DEV), out=cj, rows_per_batch=rpb, c_map=(S, T))
+    got = cj.view(Bn, S, N)[:, T:].reshape(M, N)
+    check("gemm_cmap", got, y, 1e-2)
+    assert cj.view(Bn, S, N)[:, :T].abs().max().item() == 0.0
+
+
+def test_gemm_dgelu():
+    ops = _ops()
+    M, N, K = 192, 256, 128
+    a, b = randn(M, K, seed=1).to(BF), randn(N, K, seed=2, scale=0.2).to(BF)
+    h = randn(M, N, seed=3).to(BF)
+    hh = h.float().requires_grad_(True)
+    F.gelu(hh, approximate="tanh").sum().backward()
+    ref = rb(rb(a.float() @ b.float().t()) * hh.grad)
+    out = ops.gemm(a.to(DEV), b.to(DEV), epi=3, aux=h.to(DEV))
+    check("gemm_dgelu", out, ref, 1.5e-2)
+
+
+# ------------------------------------------------------------------------------------------ LoRA pieces
+def _split(x):
+    hi = x.to(BF)
+    lo = (x - hi.float()).to(BF)
+    return hi, lo
+
+
+@pytest.mark.parametrize("R,M,K", [(16, 100, 256), (48, 2432, 3072), (32, 77, 512)])
+def test_lora_down(R, M, K):
+    ops = _ops()
+    x = randn(M, K, seed=1).to(BF)
+    w = randn(R, K, seed=2, scale=0.1)
+    hi, lo = _split(w)
+    ref = x.float() @ (hi.float() + lo.float()).t()
+    U = torch.empty(M, R, dtype=torch.float32, device=DEV)
+    Kext = ((3 * R + 63) // 64) * 64
+    ext = torch.zeros(M, Kext, dtype=BF, device=DEV)
+    ops.lora_down(x.to(DEV), hi.to(DEV), lo.to(DEV), U=U, ext=ext)
+    check(f"lora_down_U_{R}", U, ref, 2e-5)
+    check(f"lora_down_fp32acc_{R}", U, x.float() @ w.t(), 1e-4)
+    e = ext.float().cpu()
+    recon = e[:, :R] + e[:, R:2 * R]
+    check(f"lora_down_ext_{R}", recon, ref, 1e-4)
+    assert torch.equal(e[:, :R], e[:, 2 * R:3 * R])
+
+
+def test_lora_down_grouped_ext():
+    ops = _ops()
+    M, K, Rp, Kext = 64, 128, 16, 64
+    x = randn(M, K, seed=1).to(BF)
+    w = randn(3 * Rp, K, seed=2, scale=0.1)
+    hi, lo = _split(w)
+    ext = torch.zeros(M, 3 * Kext, dtype=BF, device=DEV)
+    U = torch.empty(M, 3 * Rp, dtype=torch.float32, device=DEV)
+    ops.lora_down(x.to(DEV), hi.to(DEV), lo.to(DEV), U=U, ext=ext, group_R=Rp, group_stride=Kext)
+    e = ext.float().cpu().view(M, 3, Kext)
+    u = U.cpu().view(M, 3, Rp)
+    check("lora_down_grouped", e[:, :, :Rp] + e[:, :, Rp:2 * Rp], u, 1e-4)
+    assert e[:, :, 3 * Rp:].abs().max() == 0
+
+
+def test_lora_grad():
+    ops = _ops()
+    M, K, R, r = 300, 1024, 16, 12
+    V = randn(M, R, seed=1)
+    X = randn(M, K, seed=2).to(BF)
+    G = torch.zeros(r, K, dtype=torch.float32, device=DEV)
+    ops.lora_grad(V.to(DEV), X.to(DEV), G, K, 1, r_valid=r)
+    check("lora_grad_A", G, (V.t() @ X.float())[:r], 1e-4)
+    Gt = torch.zeros(K, r, dtype=torch.float32, device=DEV)
+    ops.lora_grad(V.to(DEV), X.to(DEV), Gt, 1, r, r_valid=r)
+    check("lora_grad_Bt", Gt, (V.t() @ X.float())[:r].t(), 1e-4)
+
+
+def test_lora_pack():
+    from qflux_amd import _lib as L
+    ops = _ops()
+    r, K, N, Rp, Kext, s = 4, 128, 192, 16, 64, 2.0
+    A, Bm = randn(r, K, seed=1).to(DEV), randn(N, r, seed=2).to(DEV)
+    A_hi = torch.empty(Rp, K, dtype=BF, device=DEV); A_lo = torch.empty_like(A_hi)
+    Bt_hi = torch.empty(Rp, N, dtype=BF, device=DEV); Bt_lo = torch.empty_like(Bt_hi)
+    We = torch.full((N, Kext), 7.0, dtype=BF, device=DEV); WeT = torch.full((K, Kext), 7.0, dtype=BF, device=DEV)
+    d = L.LoraPackArgs()
+    d.A, d.B, d.r, d.K, d.N, d.scale = A.data_ptr(), Bm.data_ptr(), r, K, N, s
+    d.A_hi, d.A_lo, d.ld_a = A_hi.data_ptr(), A_lo.data_ptr(), K
+    d.Bt_hi, d.Bt_lo, d.ld_bt = Bt_hi.data_ptr(), Bt_lo.data_ptr(), N
+    d.We, d.ld_we, d.WeT, d.ld_wet, d.Rp, d.Kext = We.data_ptr(), Kext, WeT.data_ptr(), Kext, Rp, Kext
+    t = ops.pack_descs_tensor([d], DEV)
+    ops.lora_pack(t, 1, max(K, N))
+    torch.cuda.synchronize()
+    Ap = torch.zeros(Rp, K); Ap[:r] = A.cpu()
+    Bp = torch.zeros(Rp, N); Bp[:r] = s * Bm.cpu().t()
+    check("pack_A", A_hi.float() + A_lo.float(), Ap, 1e-4)
+    check("pack_Bt", Bt_hi.float() + Bt_lo.float(), Bp, 1e-4)
+    we = We.float().cpu()
+    check("pack_We", we[:, :Rp] + we[:, 2 * Rp:3 * Rp], Bp.t(), 1e-4)
+    assert torch.equal(we[:, :Rp], we[:, Rp:2 * Rp]) and we[:, 3 * Rp:].abs().max() == 0
+    wt = WeT.float().cpu()
+    check("pack_WeT", wt[:, :Rp] + wt[:, 2 * Rp:3 * Rp], Ap.t(), 1e-4)
+    assert torch.equal(wt[:, :Rp], wt[:, Rp:2 * Rp]) and wt[:, 3 * Rp:].abs().max() == 0
+
+
+def test_lora_linear_composition():
+    """skinny down + packed operands + GEMM K-extension == peft LoRA linear (oracle semantics)."""
+    from qflux_amd import _lib as L
+    ops = _ops()
+    M, K, N, r, Rp, Kext, s = 200, 256, 384, 8, 16, 64, 2.0
+    x = randn(M, K, seed=1).to(BF)
+    W, bias = randn(N, K, seed=2, scale=0.06).to(BF), randn(N, seed=3, scale=0.1).to(BF)
+    A, Bm = randn(r, K, seed=4, scale=0.2), randn(N, r, seed=5, scale=0.2)
+    base = rb(x.float() @ W.float().t() + bias.float())
+    ref = rb(base + (x.float() @ A.t()) @ Bm.t() * s)
+    A_hi = torch.empty(Rp, K, dtype=BF, device=DEV); A_lo = torch.empty_like(A_hi)
+    Bt_hi = torch.empty(Rp, N, dtype=BF, device=DEV); Bt_lo = torch.empty_like(Bt_hi)
+    We = torch.empty(N, Kext, dtype=BF, device=DEV); WeT = torch.empty(K, Kext, dtype=BF, device=DEV)
+    Ad, Bd = A.to(DEV), Bm.to(DEV)
+    d = L.LoraPackArgs()
+    d.A, d.B, d.r, d.K, d.N, d.scale = Ad.data_ptr(), Bd.data_ptr(), r, K, N, s
+    d.A_hi, d.A_lo, d.ld_a = A_hi.data_ptr(), A_lo.data_ptr(), K
+    d.Bt_hi, d.Bt_lo, d.ld_bt = Bt_hi.data_ptr(), Bt_lo.data_ptr(), N
+    d.We, d.ld_we, d.WeT, d.ld_wet, d.Rp, d.Kext = We.data_ptr(), Kext, WeT.data_ptr(), Kext, Rp, Kext
+    ops.lora_pack(ops.pack_descs_tensor([d], DEV), 1, max(K, N))
+    ext = torch.zeros(M, Kext, dtype=BF, device=DEV)
+    xd = x.to(DEV)
+    ops.lora_down(xd, A_hi, A_lo, ext=ext)
+    out = ops.gemm(xd, W.to(DEV), bias=bias.to(DEV), a2=ext, b2=We)
+    check("lora_linear_fwd", out, ref, 1e-2)
+    # the LoRA delta itself must be accurate (not hidden in bf16 rounding of the base)
+    out0 = ops.gemm(xd, W.to(DEV), bias=bias.to(DEV))
+    delta = out.float().cpu() - out0.float().cpu()
+    check("lora_linear_delta", delta, ref - base, 5e-2)
+
+
+# ------------------------------------------------------------------------------------------ row kernels
+def _ln_mod_ref(x, shift, scale, rpb):
+    ln = rb(F.layer_norm(x, (x.shape[-1],), eps=1e-6))
+    t1 = rb(1 + scale.repeat_interleave(rpb, 0))
+    return rb(rb(ln * t1) + shift.repeat_interleave(rpb, 0))
+
+
+@pytest.mark.parametrize("D", [256, 3072])
+def test_ln_modulate_fwd_bwd(D):
+    ops = _ops()
+    Bn, rpb = 2, 37
+    rows = Bn * rpb
+    x = randn(rows, D, seed=1, scale=2.0).to(BF)
+    mod = randn(Bn, 6 * D, seed=2, scale=0.5).to(BF)
+    shift, scale, gate = mod[:, :D], mod[:, D:2 * D], mod[:, 2 * D:3 * D]
+    ref = _ln_mod_ref(x.float(), shift.float(), scale.float(), rpb)
+    modd = mod.to(DEV)
+    out = ops.ln_modulate_fwd(x.to(DEV), modd[:, :D], modd[:, D:2 * D], rpb)
+    check(f"ln_mod_fwd_{D}", out, ref, 1e-2)
+    # backward vs autograd of the fp32 graph
+    dy = randn(rows, D, seed=3).to(BF)
+    dres = randn(rows, D, seed=4).to(BF)
+    xx = x.float().requires_grad_(True)
+    y = F.layer_norm(xx, (D,), eps=1e-6) * rb(1 + scale.float().repeat_interleave(rpb, 0)) + shift.float().repeat_interleave(rpb, 0)
+    y.backward(dy.float())
+    dx_ref = rb(dres.float() + rb(xx.grad))
+    dx, dyg = ops.ln_modulate_bwd(dy.to(DEV), x.to(DEV), modd[:, D:2 * D], rpb, dres=dres.to(DEV), gate=modd[:, 2 * D:3 * D], want_dyg=True)
+    check(f"ln_mod_bwd_dx_{D}", dx, dx_ref, 1.5e-2)
+    check(f"ln_mod_bwd_dyg_{D}", dyg, rb(gate.float().repeat_interleave(rpb, 0) * dx.float().cpu()), 1e-2)
+    g2 = ops.gate_mul(dx, modd[:, 2 * D:3 * D], rpb)
+    check(f"gate_mul_{D}", g2, rb(gate.float().repeat_interleave(rpb, 0) * dx.float().cpu()), 1e-2)
+
+
+def test_rmsnorm_fwd():
+    ops = _ops()
+    x = randn(50, 3584, seed=1, scale=3.0).to(BF)
+    w = (1 + 0.1 * randn(3584, seed=2)).to(BF)
+    xf = x.float()
+    ref = rb(rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)) * w.float())
+    check("rmsnorm", ops.rmsnorm_fwd(x.to(DEV), w.to(DEV)), ref, 1e-2)
+
+
+def test_mod_gemv_and_timestep():
+    ops = _ops()
+    Bn, K, N = 2, 512, 1536
+    temb = randn(Bn, K, seed=1).to(BF)
+    Ws = [randn(N, K, seed=10 + i, scale=0.05).to(BF) for i in range(3)]
+    bs = [randn(N, seed=20 + i, scale=0.1).to(BF) for i in range(3)]
+    s = rb(F.silu(temb.float()))
+    out = ops.mod_gemv(temb.to(DEV), [w.to(DEV) for w in Ws], [b.to(DEV) for b in bs])
+    for i in range(3):
+        check(f"mod_gemv_{i}", out[i], rb(s @ Ws[i].float().t() + bs[i].float()), 1e-2)
+    out = ops.mod_gemv(temb.to(DEV), [Ws[0].to(DEV)], [bs[0].to(DEV)], apply_silu=False)
+    check("gemv_nosilu", out[0], rb(temb.float() @ Ws[0].float().t() + bs[0].float()), 1e-2)
+    from oracle.qwen_dit import timestep_sinusoid
+    t = torch.tensor([0.7109, 0.1611, 0.999])
+    ref = rb(timestep_sinusoid(rb(t), 256, scale=1000.0))
+    check("timestep_embed", ops.timestep_embed(t.to(DEV)), ref, 2e-2)
+
+
+@pytest.mark.parametrize("dh", [64, 128])
+def test_qk_norm_rope_fwd_bwd(dh):
+    from oracle.qwen_dit import OracleRMSNorm, apply_rope_complex, qwen_rope_tables
+    ops = _ops()
+    Bn, H, T = 2, 3, 5
+    shapes = [(1, 4, 6), (1, 4, 6)]
+    S_i = 48
+    S = T + S_i
+    D = H * dh
+    axes = (16, 56, 56) if dh == 128 else (8, 28, 28)
+    vid, txt = qwen_rope_tables(shapes, T, axes)
+    freqs = torch.cat([txt, vid], 0)  # joint order [text, image]
+    rope = torch.view_as_real(freqs).contiguous().float()  # [S, dh/2, 2]
+    qkv = randn(Bn, S, 3 * D, seed=1, scale=1.5).to(BF)
+    ws = [(1 + 0.2 * randn(dh, seed=10 + i)).to(BF) for i in range(4)]  # q_txt, k_txt, q_img, k_img
+
+    def ref_fwd(qkv_f):
+        outs = []
+        for sec, (wt, wi) in enumerate([(ws[0], ws[2]), (ws[1], ws[3])]):
+            x = qkv_f[:, :, sec * D:(sec + 1) * D].reshape(Bn, S, H, dh)
+            parts = []
+            for (lo, hi, wsel) in [(0, T, wt), (T, S, wi)]:
+                n = OracleRMSNorm(dh)
+                n.weight.data = wsel.clone()
+                parts.append(apply_rope_complex(n(x[:, lo:hi].to(BF)), freqs[lo:hi]))
+            outs.append(torch.cat(parts, 1).reshape(Bn, S, D))
+        return outs
+
+    q_ref, k_ref = ref_fwd(qkv)
+    buf = qkv.clone().to(DEV)
+    saved = torch.empty(Bn, S, 2 * D, dtype=BF, device=DEV)
+    wd = [w.to(DEV) for w in ws]
+    ops.qk_norm_rope(buf, saved, rope.to(DEV), wd[0], wd[1], wd[2], wd[3], Bn, S, T, H, dh)
+    check(f"qk_fwd_q_{dh}", buf[:, :, :D], q_ref.float(), 1.5e-2)
+    check(f"qk_fwd_k_{dh}", buf[:, :, D:2 * D], k_ref.float(), 1.5e-2)
+    assert torch.equal(buf[:, :, 2 * D:].cpu(), qkv[:, :, 2 * D:])
+    assert torch.equal(saved.cpu(), qkv[:, :, :2 * D])
+    # backward vs fp32 autograd
+    dq = randn(Bn, S, 3 * D, seed=5).to(BF)
+    xx = qkv.float().requires_grad_(True)
+    outs = []
+    for sec, (wt, wi) in enumerate([(ws[0], ws[2]), (ws[1], ws[3])]):
+        x = xx[:, :, sec * D:(sec + 1) * D].reshape(Bn, S, H, dh)
+        parts = []
+        for (lo, hi, wsel) in [(0, T, wt), (T, S, wi)]:
+            xs = x[:, lo:hi]
+            n = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6) * wsel.float()
+            xc = torch.view_as_complex(n.reshape(*n.shape[:-1], -1, 2))
+            parts.append(torch.view_as_real(xc * freqs[lo:hi].unsqueeze(1)).flatten(3))
+        outs.append(torch.cat(parts, 1).reshape(Bn, S, D))
+    (outs[0] * dq[:, :, :D].float()).sum().backward(retain_graph=True)
+    (outs[1] * dq[:, :, D:2 * D].float()).sum().backward()
+    dbuf = dq.clone().to(DEV)
+    ops.qk_norm_rope(dbuf, saved, rope.to(DEV), wd[0], wd[1], wd[2], wd[3], Bn, S, T, H, dh, backward=True)
+    check(f"qk_bwd_{dh}", dbuf[:, :, :2 * D], xx.grad[:, :, :2 * D], 2e-2)
+    assert torch.equal(dbuf[:, :, 2 * D:].cpu(), dq[:, :, 2 * D:])
+
+
+def test_transpose_heads():
+    ops = _ops()
+    Bn, S, H, dh, S_pad = 2, 100, 2, 64, 128
+    x = randn(Bn, S, 3 * H * dh, seed=1).to(BF).to(DEV)
+    v = x[:, :, 2 * H * dh:]
+    out = ops.transpose_heads(v, 3 * H * dh, Bn, S, S_pad, H, dh)
+    ref = torch.zeros(Bn, H, dh, S_pad)
+    ref[..., :S] = v.float().cpu().reshape(Bn, S, H, dh).permute(0, 2, 3, 1)
+    assert torch.equal(out.float().cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_case(dh, S, Bn=2, H=2, mask=False, seed=0):
+    D = H * dh
+    S_pad = ((S + 63) // 64) * 64
+    qkv = randn(Bn, S, 3 * D, seed=seed + 1).to(BF)
+    do = randn(Bn, S, D, seed=seed + 2).to(BF)
+    km = None
+    if mask:
+        km = torch.zeros(Bn, S)
+        km[1, S - 7:] = float("-inf")
+    return qkv, do, km, S_pad
+
+
+@pytest.mark.parametrize("dh,S,mask", [(64, 200, False), (128, 200, False), (128, 333, True), (64, 64, False), (128, 2432, False)])
+def test_attention_fwd_bwd(dh, S, mask):
+    ops = _ops()
+    Bn, H = (2, 2) if S < 1000 else (1, 2)
+    D = H * dh
+    qkv, do, km, S_pad = _attn_case(dh, S, Bn, H, mask)
+    scale = 1.0 / math.sqrt(dh)
+    # fp32 reference with autograd
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, :, i * D:(i + 1) * D].reshape(Bn, S, H, dh).transpose(1, 2) for i in range(3))
+    am = km[:, None, None, :] if km is not None else None
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=am).transpose(1, 2).reshape(Bn, S, D)
+    o.backward(do.float())
+    qd = qkv.to(DEV)
+    ld = 3 * D
+    Q, K, V = qd[:, :, :D], qd[:, :, D:2 * D], qd[:, :, 2 * D:]
+    Vt = ops.transpose_heads(V, ld, Bn, S, S_pad, H, dh)
+    O = torch.empty(Bn, S, D, dtype=BF, device=DEV)
+    lse2 = torch.zeros(Bn, H, S_pad, dtype=torch.float32, device=DEV)
+    kmd = km.to(DEV) if km is not None else None
+    a = ops.attn_args(Bn, S, S_pad, H, dh, scale, Q=Q, K=K, V=V, ldq=ld, ldk=ld, ldv=ld, Vt=Vt, O=O, ldo=D, lse2=lse2,
+                      key_mask=kmd.data_ptr() if kmd is not None else None)
+    ops.attn_call("qfx_attn_fwd", a)
+    check(f"attn_fwd_{dh}_{S}", O, o, 1e-2)
+    # lse check
+    sc = (q @ k.transpose(-1, -2)) * scale
+    if am is not None:
+        sc = sc + am
+    lse_ref = torch.logsumexp(sc, -1) / math.log(2.0)
+    check(f"attn_lse_{dh}_{S}", lse2[:, :, :S], lse_ref, 1e-3)
+    # backward
+    dOd = do.to(DEV)
+    Qt = ops.transpose_heads(Q, ld, Bn, S, S_pad, H, dh)
+    Kt = ops.transpose_heads(K, ld, Bn, S, S_pad, H, dh)
+    dOt = ops.transpose_heads(dOd, D, Bn, S, S_pad, H, dh)
+    dsum = torch.zeros(Bn, H, S_pad, dtype=torch.float32, device=DEV)
+    dqkv = torch.zeros(Bn, S, 3 * D, dtype=BF, device=DEV)
+    a.Qt, a.Kt, a.dO, a.lddo, a.dOt, a.dsum = Qt.data_ptr(), Kt.data_ptr(), dOd.data_ptr(), D, dOt.data_ptr(), dsum.data_ptr()
+    a.dQ, a.dK, a.dV = dqkv[:, :, :D].data_ptr(), dqkv[:, :, D:2 * D].data_ptr(), dqkv[:, :, 2 * D:].data_ptr()
+    a.lddq = a.lddk = a.lddv = ld
+    ops.attn_call("qfx_attn_bwd_prep", a)
+    check(f"attn_dsum_{dh}_{S}", dsum[:, :, :S], (do.float() * O.float().cpu()).reshape(Bn, S, H, dh).sum(-1).transpose(1, 2), 2e-2)
+    ops.attn_call("qfx_attn_bwd_dq", a)
+    ops.attn_call("qfx_attn_bwd_dkv", a)
+    g = x.grad
+    check(f"attn_dq_{dh}_{S}", dqkv[:, :, :D], g[:, :, :D], 2e-2)
+    check(f"attn_dk_{dh}_{S}", dqkv[:, :, D:2 * D], g[:, :, D:2 * D], 2e-2)
+    check(f"attn_dv_{dh}_{S}", dqkv[:, :, 2 * D:], g[:, :, 2 * D:], 2e-2)
+
+
+# ------------------------------------------------------------------------------------------ criterion / optimizer
+def test_flowmatch_and_mse():
+    ops = _ops()
+    Bn, S_t, S_c, Cc = 2, 24, 24, 64
+    x0, noise, ctrl = (randn(Bn, S_t, Cc, seed=i).to(BF) for i in (1, 2, 3))
+    sigma = torch.tensor([0.711, 0.161]).to(BF)
+    sg = sigma.float().view(Bn, 1, 1)
+    xt = rb(rb(rb(1 - sg) * x0.float()) + rb(sg * noise.float()))
+    packed, target = ops.flowmatch_prepare(x0.to(DEV), noise.to(DEV), ctrl.to(DEV), sigma.to(DEV))
+    assert torch.equal(packed[:, :S_t].float().cpu(), xt) and torch.equal(packed[:, S_t:].cpu(), ctrl)
+    assert torch.equal(target.float().cpu(), rb(noise.float() - x0.float()))
+    pred = randn(Bn, S_t + S_c, Cc, seed=5).to(BF)
+    pp = pred.float().requires_grad_(True)
+    el = (pp[:, :S_t] - target.float().cpu()) ** 2
+    loss_ref = el.reshape(Bn, -1).mean(1).mean()
+    loss_ref.backward()
+    loss, dpred = ops.mse_loss_fwd_bwd(pred.to(DEV), target, S_t)
+    check("mse_loss", loss.reshape(1), loss_ref.detach().reshape(1), 1e-5)
+    check("mse_dpred", dpred, rb(pp.grad), 1e-2)
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    n = 10000
+    p0, g0 = randn(n, seed=1), randn(n, seed=2) * 3
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    nsq = torch.zeros((), device=DEV)
+    for step in range(1, 4):
+        g = g0 * step
+        p_ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        nsq.zero_()
+        gd = g.to(DEV)
+        ops.sumsq(gd, nsq)
+        ops.adamw_step(p, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, gnorm_sq=nsq, max_norm=1.0)
+    check("adamw", p, p_ref.detach(), 1e-5)
