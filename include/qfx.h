@@ -92,6 +92,7 @@ typedef struct qfx_lora_grad_args {
   const uint16_t* X; int64_t ldx; int32_t M; int32_t K;
   float* G; int64_t g_sr; int64_t g_sc;
   int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off;
+  float out_scale;                       /* G += out_scale * (V^T X)  (lora_alpha/r for dB) */
 } qfx_lora_grad_args;
 
 int qfx_lora_grad(const qfx_lora_grad_args* args, void* stream);

@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const qfx_lora_grad_args
   for (int j = 0; j < 16; ++j) {
     if (jb + j < p.r_valid) {
       float* gp = p.G + (int64_t)(jb + j) * p.g_sr + (int64_t)k * p.g_sc;
-      unsafeAtomicAdd(gp, a0[j]);
-      unsafeAtomicAdd(gp + p.g_sc, a1[j]);
+      unsafeAtomicAdd(gp, a0[j] * p.out_scale);
+      unsafeAtomicAdd(gp + p.g_sc, a1[j] * p.out_scale);
     }
   }
 }

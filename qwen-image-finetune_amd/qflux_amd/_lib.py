@@ -46,6 +46,7 @@ class LoraGradArgs(C.Structure):
         ("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
         ("G", C.c_void_p), ("g_sr", C.c_int64), ("g_sc", C.c_int64),
         ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
+        ("out_scale", C.c_float),
     ]
 
 

@@ -72,7 +72,7 @@ def lora_down(x, w_hi, w_lo, *, U=None, ext=None, group_R=None, group_stride=0, 
     L.check(lib.qfx_lora_down(C.byref(a), stream_ptr()), "qfx_lora_down")
 
 
-def lora_grad(V, X, G, g_sr, g_sc, *, r_valid=None, M=None, K=None, rows_per_batch=None, x_map=(0, 0)):
+def lora_grad(V, X, G, g_sr, g_sc, *, r_valid=None, M=None, K=None, rows_per_batch=None, x_map=(0, 0), out_scale=1.0):
     a = L.LoraGradArgs()
     M = V.shape[0] if M is None else M
     a.V, a.ldv, a.R = _p(V), V.stride(0), V.shape[1]
@@ -81,6 +81,7 @@ def lora_grad(V, X, G, g_sr, g_sc, *, r_valid=None, M=None, K=None, rows_per_bat
     a.G, a.g_sr, a.g_sc = _p(G), g_sr, g_sc
     a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
     a.x_batch_rows, a.x_row_off = x_map
+    a.out_scale = out_scale
     L.check(lib.qfx_lora_grad(C.byref(a), stream_ptr()), "qfx_lora_grad")
 
 
