@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- training images/s of the Qwen-Image-Edit LoRA step (BASELINE.json configs[1]) on MI355X.
+
+A "step" = one full optimisation step of the hot path on one batch of synthetic cached embeddings
+per GPU: flow-match prepare -> 60-block DiT forward -> criterion -> DiT backward (dX + LoRA dA/dB) ->
+all-reduce of the LoRA gradients (N>1) -> global-norm clip + AdamW.  Inputs are resident in HBM when the
+timed region starts.  Random-init weights of the real architecture (no network for checkpoints).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see README/DESIGN for the field meanings).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
+
+BF = torch.bfloat16
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_flops(L, D, S_i, T, Jd, Cin, Cout, r, n_tgt):
+    """MACs x 2, B = 1, frozen base (dX only), no recompute."""
+    S = S_i + T
+    f_lin = 2 * (L * ((S_i + T) * 12 * D * D + 2 * 6 * D * D) + S_i * Cin * D + T * Jd * D + 256 * D + 3 * D * D + S_i * D * Cout)
+    f_attn = 2 * L * 2 * S * S * D
+    lora = 2 * L * n_tgt * S_i * 2 * D * r
+    fwd = f_lin + f_attn + lora
+    bwd = f_lin + 2.5 * f_attn + 2 * lora
+    return fwd, bwd
+
+
+def gemm_flops_of(prog):
+    """Algorithmic flops of every qfx_gemm_bf16 launch of a launch program (from its argument structs)."""
+    from qflux_amd import _lib as L
+    tot = 0
+    n = 0
+    for g in prog.keep:
+        if isinstance(g, L.GemmArgs):
+            tot += 2 * g.M * g.N * (g.K1 + g.K2)
+            n += 1
+    return tot, n
+
+
+def run_profiled(prog, fn_target):
+    """Replay a program with a HIP event pair around every launch of `fn_target`; returns summed ms and count."""
+    st_obj = torch.cuda.current_stream()
+    st = st_obj.cuda_stream
+    evs = []
+    for fn, args in prog.calls:
+        if fn is None:
+            args()
+            continue
+        if fn is fn_target:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st_obj)
+            rc = fn(*args, st)
+            e1.record(st_obj)
+            evs.append((e0, e1))
+        else:
+            rc = fn(*args, st)
+        if rc != 0:
+            raise RuntimeError(f"{fn.__name__} -> {rc}")
+    return evs
+
+
+def cpu_baseline(cfg_dims, blocks=2, steps=2):
+    """The oracle (a CPU restatement of the reference's module graph, fp32 eager PyTorch) timed on this host's
+    cores: K=2 blocks + head/tail, forward+backward+AdamW on the LoRA params; extrapolated x(60/K)."""
+    sys.path.insert(0, ROOT)
+    from oracle import qwen_dit as O
+    D_h, H, Jd, S_t, T = cfg_dims
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    m = O.OracleQwenDiT(num_layers=blocks, attention_head_dim=D_h, num_attention_heads=H, joint_attention_dim=Jd)
+    O.add_lora(m, r=16, lora_alpha=16, adapter_name="default", seed=0)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    emb = dict(image_latents=torch.randn(1, S_t, 64), control_latents=torch.randn(1, S_t, 64),
+               prompt_embeds=torch.randn(1, T, Jd) * 4, prompt_embeds_mask=torch.ones(1, T, dtype=torch.int64),
+               img_shapes=[[(1, 32, 32), (1, 32, 32)]])
+    times = []
+    for i in range(steps + 1):
+        t0 = time.time()
+        loss = O.qwen_compute_loss(m, emb, torch.randn(1, S_t, 64), torch.rand(1), torch.float32)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        if i > 0:
+            times.append(time.time() - t0)
+    per_step = sum(times) / len(times)
+    full = per_step * (60.0 / blocks)
+    return {"value": 1.0 / full, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{blocks} of 60 DiT blocks + head/tail, fp32 eager, B=1, 512^2 (S_i=2048,T={T}), fwd+bwd+AdamW, "
+                      f"{steps} timed steps of {per_step:.2f} s, extrapolated x{60 // blocks}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=60)
+    ap.add_argument("--batch", type=int, default=1, help="per-GPU micro batch")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--rank", type=int, default=16, help="LoRA rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from qflux_amd.models import QwenImageTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd import _lib as L
+    from qflux_amd.trainer import QwenLoraTrainStep
+    from qflux_amd.trainer.qwen_step import init_distributed_from_env
+    import torch.distributed as dist
+
+    rank, local, world = init_distributed_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234 + rank)
+
+    with torch.device(dev):
+        dit = QwenImageTransformer2DModel(num_layers=args.layers)
+    with torch.no_grad():
+        for n, p in dit.named_parameters():
+            if p.ndim == 2:
+                p.normal_(0.0, 0.02)
+            elif "norm" in n:
+                p.fill_(1.0)
+            elif ".img_mod." in n or ".txt_mod." in n or "norm_out" in n:
+                p.normal_(0.0, 0.02)
+            else:
+                p.zero_()
+    gen = torch.Generator().manual_seed(1234)  # identical LoRA init on every rank (the reference relies on equal seeds)
+    dit.add_adapter(LoraConfig(r=args.rank, lora_alpha=args.rank, init_lora_weights="gaussian"), "default", generator=gen)
+    step = QwenLoraTrainStep(dit, lr=1e-4, max_grad_norm=1.0)
+
+    B = args.batch
+    side = args.res // 16
+    S_t = side * side
+    T = 384
+    Jd = dit.config.joint_attention_dim
+    emb = dict(image_latents=torch.randn(B, S_t, 64).half().to(dev), control_latents=torch.randn(B, S_t, 64).half().to(dev),
+               prompt_embeds=(torch.randn(B, T, Jd) * 4).half().to(dev), prompt_embeds_mask=None,
+               img_shapes=[[(1, side, side), (1, side, side)]] * B)
+
+    for _ in range(args.warmup):
+        step.train_step(emb)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = step.train_step(emb)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # ---- dominant kernel (gemm_kernel): per-launch HIP-event timing on the launch stream, one extra replayed step
+    plan = list(dit._plans.values())[0]
+    dit.refresh_lora_operands()
+    ev = run_profiled(plan.fwd, L.lib.qfx_gemm_bf16)
+    loss2, dpred = None, None
+    from qflux_amd import ops
+    ev += run_profiled(plan.bwd, L.lib.qfx_gemm_bf16)
+    torch.cuda.synchronize()
+    gemm_ms = sum(a.elapsed_time(b) for a, b in ev)
+    gf_f, n_f = gemm_flops_of(plan.fwd)
+    gf_b, n_b = gemm_flops_of(plan.bwd)
+    n_launch = n_f + n_b
+    achieved = (gf_f + gf_b) / (gemm_ms * 1e-3) / 1e12
+    step.zero_grad()
+
+    cfgd = dit.config
+    fwd_fl, bwd_fl = algorithmic_flops(cfgd.num_layers, dit.inner_dim, 2 * S_t, T, Jd, cfgd.in_channels, dit.proj_out.out_features,
+                                       args.rank, 4)
+    out = {
+        "metric": "train images/sec, Qwen-Image-Edit LoRA r=16 bf16 512^2, cached-embed",
+        "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init weights of the real architecture, synthetic cached embeddings)",
+        "config": {"workload": f"Qwen-Image-Edit DiT LoRA step: {cfgd.num_layers} blocks, D={dit.inner_dim}, 24x128 heads, "
+                               f"{args.res}x{args.res} target + 1 control (S_i={2 * S_t}), T={T}, LoRA r={args.rank} on "
+                               f"to_q/to_k/to_v/to_out.0, AdamW + clip, no recompute",
+                   "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                   "step_tflop_algorithmic": round((fwd_fl + bwd_fl) * B / 1e12, 2),
+                   "whole_step_tflops_per_gpu": round((fwd_fl + bwd_fl) * B / (ms_per_step * 1e-3) / 1e12, 1),
+                   "loss": float(loss.item())},
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel (qfx_gemm_bf16, all epilogue variants)",
+                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                     "gemm_share_of_step": round(gemm_ms / ms_per_step, 3)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline((cfgd.attention_head_dim, cfgd.num_attention_heads, Jd, S_t, T))
+        except Exception as e:  # the baseline is a reported side number; never let it kill the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,760 @@
+"""MI355X-native drop-in for the reference's QwenImageTransformer2DModel
+(src/qflux/models/transformer_qwenimage.py:497-672) on the LoRA-training hot path.
+
+Same constructor arguments, state-dict keys, forward signature and return value; `add_adapter`
+reproduces peft's naming (X.base_layer / X.lora_A.<name> / X.lora_B.<name>).  The forward and the
+backward of the whole DiT are ONE autograd node: for a given shape signature a *launch program*
+(flat list of libqfx C-ABI calls with pre-built argument structs over a persistent HBM arena) is
+built once and replayed every step -- no per-op autograd graph, no gradient checkpointing (288 GB),
+frozen base weights never get a dW, LoRA dA/dB accumulate straight into the flat gradient buffer.
+
+Numerics follow the reference's bf16 eager graph at every rounding point (see csrc/*.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..modules import (LoraConfig, LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm, init_lora_, match_target)
+from ..rope import normalize_img_shapes, qwen_joint_rope
+
+lib = L.lib
+BF = torch.bfloat16
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------------------------
+# holder modules (names == reference state-dict keys)
+# ----------------------------------------------------------------------------------------------
+class _GELUProj(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = QfxLinear(dim_in, dim_out)
+
+
+class QfxFeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([_GELUProj(dim, dim * mult), nn.Identity(), QfxLinear(dim * mult, dim)])
+
+
+class QfxAttention(nn.Module):
+    def __init__(self, dim, heads, dim_head, eps=1e-6):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj"):
+            setattr(self, n, QfxLinear(dim, inner))
+        self.to_out = nn.ModuleList([QfxLinear(inner, dim), nn.Identity()])
+        self.to_add_out = QfxLinear(inner, dim)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            setattr(self, n, QfxRMSNorm(dim_head, eps))
+
+
+class QwenImageTransformerBlock(nn.Module):
+    def __init__(self, dim, num_attention_heads, attention_head_dim, eps=1e-6):
+        super().__init__()
+        self.img_mod = nn.Sequential(nn.Identity(), QfxLinear(dim, 6 * dim))   # index 1 == the Linear (index 0 is SiLU)
+        self.attn = QfxAttention(dim, num_attention_heads, attention_head_dim, eps)
+        self.img_mlp = QfxFeedForward(dim)
+        self.txt_mod = nn.Sequential(nn.Identity(), QfxLinear(dim, 6 * dim))
+        self.txt_mlp = QfxFeedForward(dim)
+
+
+class _TimestepEmbedder(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.linear_1 = QfxLinear(256, dim)
+        self.linear_2 = QfxLinear(dim, dim)
+
+
+class _TimeTextEmbed(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.timestep_embedder = _TimestepEmbedder(dim)
+
+
+class _AdaLNOut(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.linear = QfxLinear(dim, 2 * dim)
+
+
+class _Cfg:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# prepared device-side weights
+# ----------------------------------------------------------------------------------------------
+class _LoraW:
+    __slots__ = ("mod", "r", "Rp", "Kext", "scale", "A_hi", "A_lo", "Bt_hi", "Bt_lo", "We", "WeT", "gA", "gB")
+
+
+class _LinW:
+    __slots__ = ("W", "b", "WT", "lora", "N", "K")
+
+    def __init__(self, mod, need_T: bool):
+        base = mod.base_layer if isinstance(mod, QfxLoraLinear) else mod
+        self.W = base.weight.data
+        assert self.W.is_contiguous() and self.W.dtype == BF
+        self.b = base.bias.data if base.bias is not None else None
+        self.N, self.K = self.W.shape
+        self.WT = self.W.t().contiguous() if need_T else None
+        self.lora = None
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class _Prog:
+    """A flat launch program: list of (callable, args); C calls get the stream appended."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []
+
+    def c(self, fn, *args):
+        self.calls.append((fn, args))
+
+    def py(self, fn):
+        self.calls.append((None, fn))
+
+    def run(self):
+        st = torch.cuda.current_stream().cuda_stream
+        for fn, args in self.calls:
+            if fn is None:
+                args()
+            else:
+                rc = fn(*args, st)
+                if rc != 0:
+                    raise L.QfxError(f"{fn.__name__} failed with code {rc}")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return t.data_ptr() if isinstance(t, torch.Tensor) else t
+
+
+# ----------------------------------------------------------------------------------------------
+class QwenImageTransformer2DModel(nn.Module):
+    """See module docstring.  Reference: transformer_qwenimage.py:497-672."""
+
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, patch_size: int = 2, in_channels: int = 64, out_channels: int | None = 16, num_layers: int = 60,
+                 attention_head_dim: int = 128, num_attention_heads: int = 24, joint_attention_dim: int = 3584,
+                 guidance_embeds: bool = False, axes_dims_rope=(16, 56, 56)):
+        super().__init__()
+        if attention_head_dim not in (64, 128):
+            raise ValueError("qflux_amd attention kernels support head dims 64 and 128")
+        self.config = _Cfg(patch_size=patch_size, in_channels=in_channels, out_channels=out_channels, num_layers=num_layers,
+                           attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
+                           joint_attention_dim=joint_attention_dim, guidance_embeds=guidance_embeds,
+                           axes_dims_rope=tuple(axes_dims_rope))
+        self.out_channels = out_channels or in_channels
+        self.inner_dim = num_attention_heads * attention_head_dim
+        D = self.inner_dim
+        self.time_text_embed = _TimeTextEmbed(D)
+        self.txt_norm = QfxRMSNorm(joint_attention_dim, eps=1e-6)
+        self.img_in = QfxLinear(in_channels, D)
+        self.txt_in = QfxLinear(joint_attention_dim, D)
+        self.transformer_blocks = nn.ModuleList(
+            [QwenImageTransformerBlock(D, num_attention_heads, attention_head_dim) for _ in range(num_layers)])
+        self.norm_out = _AdaLNOut(D)
+        self.proj_out = QfxLinear(D, patch_size * patch_size * self.out_channels)
+        self.gradient_checkpointing = False
+        self._lora = LoraStore(self)
+        self._adapter_name = None
+        self._prepared = None      # prepared weights
+        self._lora_prep = None     # packed-operand buffers + descriptors
+        self._plans = {}
+        self._version = 0
+
+    # ------------------------------------------------------------------ reference-surface methods
+    @property
+    def device(self):
+        return self.proj_out.weight.device
+
+    @property
+    def dtype(self):
+        return self.proj_out.weight.dtype
+
+    def enable_gradient_checkpointing(self):
+        """Accepted for API parity (base_trainer.py:324-325); a no-op: activations stay resident in HBM."""
+        self.gradient_checkpointing = True
+
+    def _invalidate(self):
+        self._prepared = None
+        self._lora_prep = None
+        self._plans = {}
+        self._version += 1
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._invalidate()
+        return r
+
+    def add_adapter(self, adapter_config, adapter_name: str = "default", generator: torch.Generator | None = None):
+        """peft add_adapter look-alike (base_trainer.py:939): wrap matching Linears, freeze all but 'lora' params."""
+        cfg = adapter_config
+        names = [n for n, m in self.named_modules() if isinstance(m, QfxLinear) and ".base_layer" not in n
+                 and not n.endswith("base_layer") and match_target(n, cfg.target_modules)]
+        supported = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj", "attn.add_k_proj",
+                     "attn.add_v_proj", "attn.to_add_out")
+        for n in names:
+            if not (n.startswith("transformer_blocks.") and n.endswith(supported)):
+                raise NotImplementedError(
+                    f"LoRA target '{n}': round-1 fused path covers the attention projections of both streams "
+                    f"({', '.join(s.split('.', 1)[1] for s in supported)}); MLP / modulation / embedder targets are next (DESIGN.md)")
+        for n in names:
+            parent_name, _, child = n.rpartition(".")
+            parent = self.get_submodule(parent_name)
+            base = parent[int(child)] if child.isdigit() else getattr(parent, child)
+            wrapped = QfxLoraLinear(base, cfg.r, cfg.lora_alpha, adapter_name)
+            init_lora_(wrapped, cfg.init_lora_weights, generator)
+            if child.isdigit():
+                parent[int(child)] = wrapped
+            else:
+                setattr(parent, child, wrapped)
+        self._adapter_name = adapter_name
+        for pn, p in self.named_parameters():
+            p.requires_grad_("lora" in pn)
+        self._invalidate()
+        return names
+
+    def set_adapter(self, adapter_name):
+        self._adapter_name = adapter_name
+
+    def lora_parameters(self):
+        return [p for n, p in self.named_parameters() if "lora_" in n]
+
+    @property
+    def lora_store(self) -> LoraStore:
+        self._ensure_lora_store()
+        return self._lora
+
+    # ------------------------------------------------------------------ preparation
+    def _ensure_lora_store(self):
+        if not self._lora.is_consistent(self.device):
+            self._lora.rebuild(self.device)
+            self._lora_prep = None
+            self._plans = {}
+        self._lora.ensure_grads()
+
+    def _prepare(self):
+        """Contiguous bf16 weights + resident transposed copies for the dX GEMMs (2x weight memory, by design)."""
+        if self._prepared is not None:
+            return self._prepared
+        assert self.device.type == "cuda", "qflux_amd runs on the GPU only (no CPU fallback)"
+        P = {"blocks": []}
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            w = {}
+            for s, names in (("img", ("to_q", "to_k", "to_v")), ("txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
+                qkv = [_LinW(getattr(a, n), False) for n in names]
+                w[s + ".qkv"] = qkv
+                w[s + ".qkvT"] = torch.cat([l.W for l in qkv], dim=0).t().contiguous()       # [D, 3D]
+            w["img.o"] = _LinW(a.to_out[0], True)
+            w["txt.o"] = _LinW(a.to_add_out, True)
+            for s, mlp in (("img", blk.img_mlp), ("txt", blk.txt_mlp)):
+                w[s + ".fc1"] = _LinW(mlp.net[0].proj, True)
+                w[s + ".fc2"] = _LinW(mlp.net[2], True)
+            w["img.mod"] = _LinW(blk.img_mod[1], False)
+            w["txt.mod"] = _LinW(blk.txt_mod[1], False)
+            w["norms"] = (a.norm_added_q.weight.data, a.norm_added_k.weight.data, a.norm_q.weight.data, a.norm_k.weight.data)
+            P["blocks"].append(w)
+        P["img_in"] = _LinW(self.img_in, False)
+        P["txt_in"] = _LinW(self.txt_in, False)
+        P["t1"] = _LinW(self.time_text_embed.timestep_embedder.linear_1, False)
+        P["t2"] = _LinW(self.time_text_embed.timestep_embedder.linear_2, False)
+        P["norm_out"] = _LinW(self.norm_out.linear, False)
+        P["proj_out"] = _LinW(self.proj_out, True)
+        dev = self.device
+        mods = [w[s + ".mod"] for w in P["blocks"] for s in ("img", "txt")]
+        P["mod_W"] = torch.tensor([m.W.data_ptr() for m in mods], dtype=torch.int64, device=dev)
+        P["mod_b"] = torch.tensor([m.b.data_ptr() for m in mods], dtype=torch.int64, device=dev)
+        for key in ("t1", "t2", "norm_out"):
+            P[key + "_Wp"] = torch.tensor([P[key].W.data_ptr()], dtype=torch.int64, device=dev)
+            P[key + "_bp"] = torch.tensor([P[key].b.data_ptr()], dtype=torch.int64, device=dev)
+        self._prepared = P
+        return P
+
+    def _prepare_lora(self):
+        """Packed bf16 operand buffers for every adapter (+ the device descriptor array for qfx_lora_pack)."""
+        if self._lora_prep is not None:
+            return self._lora_prep
+        P = self._prepare()
+        self._ensure_lora_store()
+        dev = self.device
+        D = self.inner_dim
+        descs = []
+        keep = []
+        max_dim = 1
+        for w, blk in zip(P["blocks"], self.transformer_blocks):
+            a = blk.attn
+            for s, names in (("img", ("to_q", "to_k", "to_v")), ("txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
+                mods = [getattr(a, n) for n in names]
+                lmods = [m for m in mods if isinstance(m, QfxLoraLinear)]
+                w[s + ".qkv_lora"] = None
+                if not lmods:
+                    continue
+                r = lmods[0].r[lmods[0].active_adapter]
+                Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
+                A_hi = torch.zeros(3 * Rp, D, dtype=BF, device=dev)
+                A_lo = torch.zeros_like(A_hi)
+                WeT = torch.zeros(D, 3 * Kext, dtype=BF, device=dev)
+                grp = dict(Rp=Rp, Kext=Kext, A_hi=A_hi, A_lo=A_lo, WeT=WeT, present=[isinstance(m, QfxLoraLinear) for m in mods])
+                w[s + ".qkv_lora"] = grp
+                for sec, (m, lw) in enumerate(zip(mods, w[s + ".qkv"])):
+                    if not isinstance(m, QfxLoraLinear):
+                        continue
+                    lo = self._make_lora(m, Rp, Kext, A_hi[sec * Rp:(sec + 1) * Rp], A_lo[sec * Rp:(sec + 1) * Rp],
+                                         WeT[:, sec * Kext:(sec + 1) * Kext], dev)
+                    lw.lora = lo
+                    descs.append(self._pack_desc(lo))
+                    max_dim = max(max_dim, lw.N, lw.K)
+            for key, m in (("img.o", a.to_out[0]), ("txt.o", a.to_add_out)):
+                if isinstance(m, QfxLoraLinear):
+                    r = m.r[m.active_adapter]
+                    Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
+                    lw = w[key]
+                    lo = self._make_lora(m, Rp, Kext, torch.zeros(Rp, lw.K, dtype=BF, device=dev),
+                                         torch.zeros(Rp, lw.K, dtype=BF, device=dev),
+                                         torch.zeros(lw.K, Kext, dtype=BF, device=dev), dev)
+                    lw.lora = lo
+                    descs.append(self._pack_desc(lo))
+                    max_dim = max(max_dim, lw.N, lw.K)
+        prep = dict(n=len(descs), max_dim=max_dim, descs=None)
+        if descs:
+            arr = (L.LoraPackArgs * len(descs))(*descs)
+            prep["descs"] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self._lora_prep = prep
+        return prep
+
+    def _make_lora(self, m: QfxLoraLinear, Rp, Kext, A_hi, A_lo, WeT, dev):
+        lo = _LoraW()
+        name = m.active_adapter
+        lo.mod, lo.r, lo.Rp, lo.Kext, lo.scale = m, m.r[name], Rp, Kext, m.scaling[name]
+        N, K = m.out_features, m.in_features
+        lo.A_hi, lo.A_lo, lo.WeT = A_hi, A_lo, WeT
+        lo.Bt_hi = torch.zeros(Rp, N, dtype=BF, device=dev)
+        lo.Bt_lo = torch.zeros(Rp, N, dtype=BF, device=dev)
+        lo.We = torch.zeros(N, Kext, dtype=BF, device=dev)
+        st = self._lora
+        oa, ob = st.offset_of(m.A), st.offset_of(m.B)
+        lo.gA = st.gflat[oa:oa + m.A.numel()]
+        lo.gB = st.gflat[ob:ob + m.B.numel()]
+        return lo
+
+    @staticmethod
+    def _pack_desc(lo: _LoraW):
+        d = L.LoraPackArgs()
+        m = lo.mod
+        d.A, d.B, d.r, d.K, d.N, d.scale = m.A.data_ptr(), m.B.data_ptr(), lo.r, m.in_features, m.out_features, lo.scale
+        d.A_hi, d.A_lo, d.ld_a = lo.A_hi.data_ptr(), lo.A_lo.data_ptr(), lo.A_hi.stride(0)
+        d.Bt_hi, d.Bt_lo, d.ld_bt = lo.Bt_hi.data_ptr(), lo.Bt_lo.data_ptr(), lo.Bt_hi.stride(0)
+        d.We, d.ld_we = lo.We.data_ptr(), lo.We.stride(0)
+        d.WeT, d.ld_wet = lo.WeT.data_ptr(), lo.WeT.stride(0)
+        d.Rp, d.Kext = lo.Rp, lo.Kext
+        return d
+
+    def refresh_lora_operands(self):
+        """Re-split the fp32 adapter weights into the bf16 hi/lo MFMA operands (one launch for all adapters)."""
+        prep = self._prepare_lora()
+        if prep["n"]:
+            rc = lib.qfx_lora_pack(prep["descs"].data_ptr(), prep["n"], prep["max_dim"], torch.cuda.current_stream().cuda_stream)
+            L.check(rc, "qfx_lora_pack")
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, hidden_states, encoder_hidden_states=None, encoder_hidden_states_mask=None, timestep=None,
+                img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None, return_dict=True):
+        if encoder_hidden_states is None:
+            raise ValueError("QwenImageTransformer2DModel requires encoder_hidden_states (text stream)")
+        if guidance is not None:
+            raise NotImplementedError("guidance embeddings are not part of the Qwen-Image-Edit training path")
+        plan = self.get_plan(hidden_states.shape[0], hidden_states.shape[1], encoder_hidden_states.shape[1], img_shapes, txt_seq_lens)
+        out = _QwenDiTFn.apply(self, plan, hidden_states, encoder_hidden_states, timestep, *self.lora_parameters())
+        if not return_dict:
+            return (out,)
+        return _Cfg(sample=out)
+
+    def get_plan(self, B, S_i, T, img_shapes, txt_seq_lens):
+        shapes = normalize_img_shapes(img_shapes)
+        if sum(f * h * w for f, h, w in shapes) != S_i:
+            raise ValueError(f"img_shapes {shapes} do not cover the {S_i} image tokens")
+        if txt_seq_lens is not None and max(txt_seq_lens) != T:
+            raise ValueError("max(txt_seq_lens) must equal the text sequence length (reference RoPE broadcast)")
+        self._prepare()
+        self._prepare_lora()
+        key = (B, S_i, T, shapes, self._version)
+        if key not in self._plans:
+            self._plans[key] = _QwenPlan(self, B, S_i, T, shapes)
+        return self._plans[key]
+
+
+# ----------------------------------------------------------------------------------------------
+class _QwenPlan:
+    """Launch programs (forward, backward) + persistent arena for one shape signature."""
+
+    def __init__(self, model: QwenImageTransformer2DModel, B: int, S_i: int, T: int, shapes):
+        self.model = model
+        cfg = model.config
+        dev = model.device
+        self.B, self.S_i, self.T = B, S_i, T
+        H, dh = cfg.num_attention_heads, cfg.attention_head_dim
+        D = H * dh
+        S = T + S_i
+        S_pad = _ceil(S, 64)
+        Lyr = cfg.num_layers
+        Cin, Cout, Jd = cfg.in_channels, model.proj_out.out_features, cfg.joint_attention_dim
+        P = model._prepared
+        self.D, self.S, self.H, self.dh = D, S, H, dh
+        if B > 8:
+            raise NotImplementedError("per-GPU batch > 8 (modulation GEMV holds <= 8 rows in LDS)")
+
+        def buf(*shape, dtype=BF, zero=False):
+            return (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=dev)
+
+        rows = {"img": B * S_i, "txt": B * T}
+        rpb = {"img": S_i, "txt": T}
+        off = {"img": T, "txt": 0}
+        self.rope = qwen_joint_rope(shapes, T, cfg.axes_dims_rope).to(dev)
+        assert self.rope.shape == (S, dh // 2, 2)
+
+        # ---- arena
+        A = {}
+        A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, Jd); A["t"] = buf(B, dtype=F32)
+        A["tproj"] = buf(B, 256); A["t1"] = buf(1, B, D); A["temb"] = buf(1, B, D)
+        A["txt_n"] = buf(B * T, Jd)
+        A["X"] = {s: [buf(rows[s], D) for _ in range(Lyr + 1)] for s in ("img", "txt")}
+        A["mods"] = buf(2 * Lyr, B, 6 * D); A["mod_out"] = buf(1, B, 2 * D)
+        A["xm"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+        A["g"] = {s: buf(rows[s], 4 * D) for s in ("img", "txt")}
+        A["Vt"] = buf(B, H, dh, S_pad)
+        A["xn_out"] = buf(B * S_i, D); A["out"] = buf(B * S_i, Cout)
+        A["blk"] = []
+        for i in range(Lyr):
+            w = P["blocks"][i]
+            b = dict(qkv=buf(B, S, 3 * D), sqk=buf(B, S, 2 * D), ao=buf(B, S, D), lse=buf(B, H, S_pad, dtype=F32, zero=True),
+                     x1={s: buf(rows[s], D) for s in ("img", "txt")}, h={s: buf(rows[s], 4 * D) for s in ("img", "txt")})
+            for s in ("img", "txt"):
+                grp = w[s + ".qkv_lora"]
+                if grp is not None:
+                    b["xm1." + s] = buf(rows[s], D)
+                    b["Uqkv." + s] = buf(rows[s], 3 * grp["Rp"], dtype=F32)
+                if w[s + ".o"].lora is not None:
+                    b["Uo." + s] = buf(rows[s], w[s + ".o"].lora.Rp, dtype=F32)
+            A["blk"].append(b)
+        # LoRA scratch (pad columns stay zero forever)
+        kext_max = 0
+        rp_max = 0
+        for w in P["blocks"]:
+            for s in ("img", "txt"):
+                if w[s + ".qkv_lora"] is not None:
+                    kext_max = max(kext_max, w[s + ".qkv_lora"]["Kext"]); rp_max = max(rp_max, w[s + ".qkv_lora"]["Rp"])
+                if w[s + ".o"].lora is not None:
+                    kext_max = max(kext_max, w[s + ".o"].lora.Kext); rp_max = max(rp_max, w[s + ".o"].lora.Rp)
+        self.has_lora = kext_max > 0
+        if self.has_lora:
+            A["ext3"] = {s: buf(rows[s], 3 * kext_max, zero=True) for s in ("img", "txt")}
+            A["ext1"] = {s: buf(rows[s], kext_max, zero=True) for s in ("img", "txt")}
+            A["Vscr"] = {s: buf(rows[s], 3 * rp_max, dtype=F32) for s in ("img", "txt")}
+        # backward scratch
+        A["dpred"] = buf(B * S_i, Cout)
+        A["dxn"] = buf(B * S_i, D)
+        A["dX"] = {s: [buf(rows[s], D), buf(rows[s], D)] for s in ("img", "txt")}
+        A["dyg2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+        A["dyg1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+        A["dx1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+        A["dh"] = {s: buf(rows[s], 4 * D) for s in ("img", "txt")}
+        A["dxm"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+        A["dao"] = buf(B, S, D, zero=True)
+        A["dOt"] = buf(B, H, dh, S_pad); A["Qt"] = buf(B, H, dh, S_pad); A["Kt"] = buf(B, H, dh, S_pad)
+        A["dsum"] = buf(B, H, S_pad, dtype=F32, zero=True)
+        A["dqkv"] = buf(B, S, 3 * D)
+        self.A = A
+        self.rows, self.rpb, self.off = rows, rpb, off
+        self.S_pad = S_pad
+        self.fwd = _Prog()
+        self.bwd = _Prog()
+        self._build_forward(P)
+        self._build_backward(P)
+
+    # ------------------------------------------------------------------ emit helpers
+    def _gemm(self, prog, *, A1, lda1, B1, K1, M, N, C_, ldc, ldb1=None, bias=None, A2=None, lda2=0, B2=None, ldb2=0, K2=0,
+              epi=L.EPI_NONE, C2=None, ldc2=0, aux=None, ldaux=0, gate=None, gate_bs=0, rpb=None, a_map=(0, 0), c_map=(0, 0)):
+        g = L.GemmArgs()
+        g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _ptr(A1), _ptr(B1), lda1, (K1 if ldb1 is None else ldb1), K1
+        if K2:
+            g.A2, g.B2, g.lda2, g.ldb2, g.K2 = _ptr(A2), _ptr(B2), lda2, ldb2, K2
+        g.M, g.N = M, N
+        g.bias = _ptr(bias)
+        g.C, g.ldc = _ptr(C_), ldc
+        g.C2, g.ldc2 = _ptr(C2), ldc2
+        g.aux, g.ldaux = _ptr(aux), ldaux
+        g.gate, g.gate_bstride = _ptr(gate), gate_bs
+        g.rows_per_batch = M if rpb is None else rpb
+        g.a_batch_rows, g.a_row_off = a_map
+        g.c_batch_rows, g.c_row_off = c_map
+        g.epi = epi
+        prog.keep.append(g)
+        prog.c(lib.qfx_gemm_bf16, C.byref(g))
+
+    def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, group_R=None, group_stride=0,
+              rpb=None, x_map=(0, 0)):
+        a = L.LoraDownArgs()
+        a.X, a.ldx, a.M, a.K = _ptr(X), ldx, M, K
+        a.W_hi, a.W_lo, a.ldw, a.R = _ptr(W_hi), _ptr(W_lo), ldw, R
+        a.U, a.ldu = _ptr(U), ldu
+        a.ext, a.ld_ext = _ptr(ext), ld_ext
+        a.group_R = R if group_R is None else group_R
+        a.group_stride = group_stride
+        a.rows_per_batch = M if rpb is None else rpb
+        a.x_batch_rows, a.x_row_off = x_map
+        prog.keep.append(a)
+        prog.c(lib.qfx_lora_down, C.byref(a))
+
+    def _grad(self, prog, *, V, ldv, R, r_valid, X, ldx, M, K, G, g_sr, g_sc, rpb=None, x_map=(0, 0), out_scale=1.0):
+        a = L.LoraGradArgs()
+        a.V, a.ldv, a.R, a.r_valid = _ptr(V), ldv, R, r_valid
+        a.X, a.ldx, a.M, a.K = _ptr(X), ldx, M, K
+        a.G, a.g_sr, a.g_sc = _ptr(G), g_sr, g_sc
+        a.rows_per_batch = M if rpb is None else rpb
+        a.x_batch_rows, a.x_row_off = x_map
+        a.out_scale = out_scale
+        prog.keep.append(a)
+        prog.c(lib.qfx_lora_grad, C.byref(a))
+
+    # ------------------------------------------------------------------ forward program
+    def _build_forward(self, P):
+        A, B, D, S, H, dh, T, S_i = self.A, self.B, self.D, self.S, self.H, self.dh, self.T, self.S_i
+        S_pad = self.S_pad
+        p = self.fwd
+        model = self.model
+        cfg = model.config
+        Lyr = cfg.num_layers
+        Jd = cfg.joint_attention_dim
+        rows, rpb, off = self.rows, self.rpb, self.off
+        eps = 1e-6
+        # head: timestep embedding -> temb ; img_in ; txt_norm + txt_in ; all modulation vectors in one GEMV launch
+        p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1000.0, _ptr(A["tproj"]))
+        p.c(lib.qfx_mod_gemv, _ptr(A["tproj"]), B, 256, _ptr(P["t1_Wp"]), _ptr(P["t1_bp"]), 1, D, 0, _ptr(A["t1"]))
+        p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
+        p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
+        p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["norm_out_Wp"]), _ptr(P["norm_out_bp"]), 1, 2 * D, 1, _ptr(A["mod_out"]))
+        self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["img_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
+                   C_=A["X"]["img"][0], ldc=D, bias=P["img_in"].b)
+        p.c(lib.qfx_rmsnorm_fwd, _ptr(A["in_txt"]), _ptr(model.txt_norm.weight.data), _ptr(A["txt_n"]), rows["txt"], Jd, eps)
+        self._gemm(p, A1=A["txt_n"], lda1=Jd, B1=P["txt_in"].W, K1=Jd, M=rows["txt"], N=D, C_=A["X"]["txt"][0], ldc=D,
+                   bias=P["txt_in"].b)
+        scale = 1.0 / math.sqrt(dh)
+        self.attn_args = []
+        for i in range(Lyr):
+            w, bb = P["blocks"][i], A["blk"][i]
+            last = i == Lyr - 1
+            qkv = bb["qkv"]
+            for sidx, s in enumerate(("img", "txt")):
+                mod = A["mods"][2 * i + sidx]                       # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
+                x = A["X"][s][i]
+                grp = w[s + ".qkv_lora"]
+                xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
+                p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 6 * D, _ptr(xm1), rows[s], D, rpb[s], eps)
+                if grp is not None:
+                    self._down(p, X=xm1, ldx=D, M=rows[s], K=D, W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
+                               U=bb["Uqkv." + s], ldu=3 * grp["Rp"], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
+                               group_R=grp["Rp"], group_stride=grp["Kext"])
+                for sec in range(3):
+                    lw = w[s + ".qkv"][sec]
+                    kw = {}
+                    if lw.lora is not None:
+                        kw = dict(A2=A["ext3"][s][:, sec * grp["Kext"]:], lda2=A["ext3"][s].stride(0), B2=lw.lora.We,
+                                  ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
+                    self._gemm(p, A1=xm1, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=qkv.view(B * S, 3 * D)[:, sec * D:], ldc=3 * D,
+                               bias=lw.b, rpb=rpb[s], c_map=(S, off[s]), **kw)
+            nq_t, nk_t, nq_i, nk_i = w["norms"]
+            p.c(lib.qfx_qk_norm_rope_fwd, _ptr(qkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i),
+                B, S, T, H, dh, eps)
+            q2 = qkv.view(B * S, 3 * D)
+            p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["Vt"]), B, S, S_pad, H, dh)
+            a = L.AttnArgs()
+            a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
+            a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
+            a.ldq = a.ldk = a.ldv = 3 * D
+            a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["Vt"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
+            # backward fields (same struct reused by the backward program)
+            a.Qt, a.Kt, a.dOt, a.dsum = _ptr(A["Qt"]), _ptr(A["Kt"]), _ptr(A["dOt"]), _ptr(A["dsum"])
+            a.dO, a.lddo = _ptr(A["dao"]), D
+            dq2 = A["dqkv"].view(B * S, 3 * D)
+            a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
+            a.lddq = a.lddk = a.lddv = 3 * D
+            self.attn_args.append(a)
+            p.c(lib.qfx_attn_fwd, C.byref(a))
+            ao2 = bb["ao"].view(B * S, D)
+            for sidx, s in enumerate(("img", "txt")):
+                if last and s == "txt":
+                    continue  # dead compute: the text stream of the last block never reaches the output (:661-663)
+                mod = A["mods"][2 * i + sidx]
+                x = A["X"][s][i]
+                lw = w[s + ".o"]
+                kw = {}
+                if lw.lora is not None:
+                    self._down(p, X=ao2, ldx=D, M=rows[s], K=D, W_hi=lw.lora.A_hi, W_lo=lw.lora.A_lo, ldw=D, R=lw.lora.Rp,
+                               U=bb["Uo." + s], ldu=lw.lora.Rp, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0),
+                               rpb=rpb[s], x_map=(S, off[s]))
+                    kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
+                self._gemm(p, A1=ao2, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=bb["x1"][s], ldc=D, bias=lw.b, epi=L.EPI_GATE_RES,
+                           aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D], gate_bs=6 * D, rpb=rpb[s], a_map=(S, off[s]), **kw)
+                xm2 = A["xm"][s]
+                p.c(lib.qfx_ln_modulate_fwd, _ptr(bb["x1"][s]), _ptr(mod[:, 3 * D:4 * D]), _ptr(mod[:, 4 * D:5 * D]), 6 * D, _ptr(xm2),
+                    rows[s], D, rpb[s], eps)
+                f1, f2 = w[s + ".fc1"], w[s + ".fc2"]
+                self._gemm(p, A1=xm2, lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D, bias=f1.b, epi=L.EPI_GELU,
+                           C2=A["g"][s], ldc2=4 * D)
+                self._gemm(p, A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=A["X"][s][i + 1], ldc=D, bias=f2.b,
+                           epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mod[:, 5 * D:6 * D], gate_bs=6 * D, rpb=rpb[s])
+        mo = A["mod_out"][0]  # [B, 2D]: scale | shift  (AdaLayerNormContinuous chunk order)
+        p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
+            rows["img"], D, rpb["img"], eps)
+        po = P["proj_out"]
+        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b)
+
+    # ------------------------------------------------------------------ backward program
+    def _build_backward(self, P):
+        A, B, D, S, H, dh, T, S_i = self.A, self.B, self.D, self.S, self.H, self.dh, self.T, self.S_i
+        S_pad = self.S_pad
+        p = self.bwd
+        cfg = self.model.config
+        Lyr = cfg.num_layers
+        rows, rpb, off = self.rows, self.rpb, self.off
+        eps = 1e-6
+        po = P["proj_out"]
+        # tail: proj_out dX, norm_out LN backward (+ gate2 of the last block folded in)
+        self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D)
+        mo = A["mod_out"][0]
+        modL = A["mods"][2 * (Lyr - 1)]
+        cur = 0
+        p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"]), _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, 0:D]), 2 * D, None,
+            _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][cur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps)
+        dao2 = A["dao"].view(B * S, D)
+        dq2 = A["dqkv"].view(B * S, 3 * D)
+        for i in range(Lyr - 1, -1, -1):
+            w, bb = P["blocks"][i], A["blk"][i]
+            last = i == Lyr - 1
+            nxt = cur ^ 1
+            ao2 = bb["ao"].view(B * S, D)
+            for sidx, s in enumerate(("img", "txt")):
+                mod = A["mods"][2 * i + sidx]
+                if last and s == "txt":
+                    # no gradient reaches the last block's text tail: d(attn out) for text rows is zero
+                    tv = A["dao"][:, :T]
+                    p.py(tv.zero_)
+                    continue
+                dx2 = A["dX"][s][cur]
+                f1, f2 = w[s + ".fc1"], w[s + ".fc2"]
+                # MLP: dh = (gate2*dx2) W2 * gelu'(h) ; dxm2 = dh W1
+                self._gemm(p, A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s], ldc=4 * D, epi=L.EPI_DGELU,
+                           aux=bb["h"][s], ldaux=4 * D)
+                self._gemm(p, A1=A["dh"][s], lda1=4 * D, B1=f1.WT, K1=4 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D)
+                p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(bb["x1"][s]), _ptr(mod[:, 4 * D:5 * D]), 6 * D, _ptr(dx2),
+                    _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps)
+                # attention out-projection backward (+ LoRA)
+                lw = w[s + ".o"]
+                kw = {}
+                if lw.lora is not None:
+                    lo = lw.lora
+                    Vs = A["Vscr"][s]
+                    self._down(p, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0),
+                               R=lo.Rp, U=Vs, ldu=Vs.stride(0), ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0))
+                    self._grad(p, V=bb["Uo." + s], ldv=lo.Rp, R=lo.Rp, r_valid=lo.r, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N,
+                               G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale)
+                    self._grad(p, V=Vs, ldv=Vs.stride(0), R=lo.Rp, r_valid=lo.r, X=ao2, ldx=D, M=rows[s], K=lw.K, G=lo.gA,
+                               g_sr=lw.K, g_sc=1, rpb=rpb[s], x_map=(S, off[s]))
+                    kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
+                self._gemm(p, A1=A["dyg1"][s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
+                           c_map=(S, off[s]), **kw)
+            # attention backward
+            a = self.attn_args[i]
+            q2 = bb["qkv"].view(B * S, 3 * D)
+            p.c(lib.qfx_transpose_heads, _ptr(dao2), D, _ptr(A["dOt"]), B, S, S_pad, H, dh)
+            p.c(lib.qfx_transpose_heads, _ptr(q2[:, 0:]), 3 * D, _ptr(A["Qt"]), B, S, S_pad, H, dh)
+            p.c(lib.qfx_transpose_heads, _ptr(q2[:, D:]), 3 * D, _ptr(A["Kt"]), B, S, S_pad, H, dh)
+            p.c(lib.qfx_attn_bwd_prep, C.byref(a))
+            p.c(lib.qfx_attn_bwd_dq, C.byref(a))
+            p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
+            nq_t, nk_t, nq_i, nk_i = w["norms"]
+            p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
+                _ptr(nk_i), B, S, T, H, dh, eps)
+            for sidx, s in enumerate(("img", "txt")):
+                mod = A["mods"][2 * i + sidx]
+                grp = w[s + ".qkv_lora"]
+                kw = {}
+                if grp is not None:
+                    Rp, Kext = grp["Rp"], grp["Kext"]
+                    Vs = A["Vscr"][s]
+                    e3 = A["ext3"][s]
+                    for sec in range(3):
+                        lw = w[s + ".qkv"][sec]
+                        if lw.lora is None:
+                            continue
+                        lo = lw.lora
+                        self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=rows[s], K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo,
+                                   ldw=lo.Bt_hi.stride(0), R=Rp, U=Vs[:, sec * Rp:], ldu=Vs.stride(0), ext=e3[:, sec * Kext:],
+                                   ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]))
+                        self._grad(p, V=bb["Uqkv." + s][:, sec * Rp:], ldv=3 * Rp, R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D,
+                                   M=rows[s], K=D, G=lo.gB, g_sr=1, g_sc=lo.r, rpb=rpb[s], x_map=(S, off[s]), out_scale=lo.scale)
+                        self._grad(p, V=Vs[:, sec * Rp:], ldv=Vs.stride(0), R=Rp, r_valid=lo.r, X=bb["xm1." + s], ldx=D, M=rows[s],
+                                   K=D, G=lo.gA, g_sr=D, g_sc=1)
+                    kw = dict(A2=e3, lda2=e3.stride(0), B2=grp["WeT"], ldb2=grp["WeT"].stride(0), K2=3 * Kext)
+                if i == 0:
+                    continue  # nothing upstream of block 0 needs a gradient (frozen embedders, inputs without grad)
+                self._gemm(p, A1=dq2, lda1=3 * D, B1=w[s + ".qkvT"], K1=3 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D, rpb=rpb[s],
+                           a_map=(S, off[s]), **kw)
+                modp = A["mods"][2 * (i - 1) + sidx]
+                dres = None if (last and s == "txt") else A["dx1"][s]
+                p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(A["X"][s][i]), _ptr(mod[:, D:2 * D]), 6 * D, _ptr(dres),
+                    _ptr(modp[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"][s][nxt]), _ptr(A["dyg2"][s]), rows[s], D, rpb[s], eps)
+            cur = nxt
+
+    # ------------------------------------------------------------------ execution
+    def run_forward(self, hidden_states, encoder_hidden_states, timestep):
+        A = self.A
+        A["in_img"].view(self.B, self.S_i, -1).copy_(hidden_states)
+        A["in_txt"].view(self.B, self.T, -1).copy_(encoder_hidden_states)
+        A["t"].copy_(timestep.reshape(self.B).to(F32))
+        self.model.refresh_lora_operands()
+        self.fwd.run()
+        return A["out"].view(self.B, self.S_i, -1)
+
+    def run_backward(self, dpred):
+        self.A["dpred"].view(self.B, self.S_i, -1).copy_(dpred)
+        self.model._lora.ensure_grads()
+        self.bwd.run()
+
+
+class _QwenDiTFn(torch.autograd.Function):
+    """Whole-DiT autograd node.  LoRA parameters are inputs only so that autograd schedules the node;
+    their gradients are accumulated by the kernels directly into the flat .grad buffer (returns None)."""
+
+    @staticmethod
+    def forward(ctx, model, plan, hidden_states, encoder_hidden_states, timestep, *lora_params):
+        ctx.plan = plan
+        out = plan.run_forward(hidden_states, encoder_hidden_states, timestep)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.plan.run_backward(grad_out.contiguous())
+        return (None,) * len(ctx.needs_input_grad)

@@ -1,0 +1,148 @@
+"""The cached-embedding LoRA training step for Qwen-Image-Edit on MI355X.
+
+Mirrors the reference's step (names and argument meaning):
+  QwenImageEditTrainer._compute_loss      src/qflux/trainer/qwen_image_edit_trainer.py:777-849
+  BaseTrainer.train_epoch (one iteration) src/qflux/trainer/base_trainer.py:508-561
+  BaseTrainer.clip_gradients              :449-455   (global-norm clip, here over the trainable params only)
+  DDP of the LoRA container               :384-393   (here: ONE explicit RCCL all-reduce of the flat LoRA gradient)
+
+Two ways to drive it:
+  * drop-in: `loss = step.compute_loss(embeddings)` returns an autograd scalar built on `self.dit(...)`;
+    `loss.backward()`, any torch optimizer over the LoRA parameters.
+  * fused (bench / production): `step.train_step(embeddings)` = prepare -> DiT forward program -> criterion
+    kernel (loss + dpred) -> DiT backward program -> all-reduce -> fused clip+AdamW; no autograd graph, no
+    host synchronisation anywhere in the step.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+
+BF = torch.bfloat16
+
+
+def flowmatch_tables(num_train_timesteps: int = 1000, shift: float = 1.0):
+    """FlowMatchEulerDiscreteScheduler.timesteps / .sigmas as built at construction (third-party lookup
+    tables, qwen_image_edit_trainer.py:807-810,851-861; dynamic shifting => identity shift at init)."""
+    ts = torch.linspace(1, num_train_timesteps, num_train_timesteps).flip(0)
+    sig = ts / num_train_timesteps
+    sig = shift * sig / (1 + (shift - 1) * sig)
+    return sig * num_train_timesteps, sig
+
+
+class QwenLoraTrainStep:
+    def __init__(self, dit, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
+                 weight_dtype=BF, process_group=None):
+        self.dit = dit
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.weight_dtype = weight_dtype
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.timesteps_tbl, self.sigmas_tbl = flowmatch_tables()
+        self.global_step = 0
+        self._m = self._v = None
+        self._gnorm = None
+
+    # ------------------------------------------------------------------ sampling (CPU RNG like the reference)
+    def sample_timesteps(self, batch_size, u=None):
+        if u is None:
+            u = torch.rand(size=(batch_size,), device="cpu")  # compute_density_for_timestep_sampling("none")
+        idx = (u * 1000).long()
+        return self.timesteps_tbl[idx], self.sigmas_tbl[idx]
+
+    def _prepare(self, embeddings, noise=None, u=None):
+        dev = self.dit.device
+        x0 = embeddings["image_latents"].to(self.weight_dtype).to(dev, non_blocking=True)
+        ctrl = embeddings["control_latents"].to(self.weight_dtype).to(dev, non_blocking=True)
+        pe = embeddings["prompt_embeds"].to(self.weight_dtype).to(dev, non_blocking=True)
+        B = x0.shape[0]
+        if noise is None:
+            noise = torch.randn_like(x0, device=dev, dtype=self.weight_dtype)
+        else:
+            noise = noise.to(self.weight_dtype).to(dev)
+        timesteps, sigmas = self.sample_timesteps(B, u)
+        sig = sigmas.to(self.weight_dtype).to(dev, non_blocking=True)
+        packed, target = ops.flowmatch_prepare(x0.contiguous(), noise.contiguous(), ctrl.contiguous(), sig)
+        t_in = (timesteps / 1000).to(dev, non_blocking=True)
+        return packed, target, pe, t_in, x0.shape[1]
+
+    # ------------------------------------------------------------------ drop-in (autograd) path
+    def compute_loss(self, embeddings, noise=None, u=None):
+        packed, target, pe, t_in, S_t = self._prepare(embeddings, noise, u)
+        mask = embeddings["prompt_embeds_mask"]
+        txt_seq_lens = [pe.shape[1]] * pe.shape[0] if mask is None else mask.sum(dim=1).tolist()
+        pred = self.dit(hidden_states=packed, timestep=t_in, guidance=None, encoder_hidden_states_mask=mask,
+                        encoder_hidden_states=pe, img_shapes=embeddings["img_shapes"], txt_seq_lens=txt_seq_lens,
+                        return_dict=False)[0]
+        pred = pred[:, :S_t]
+        el = (pred.float() - target.float()) ** 2            # MseLoss with weighting = 1 (mse_loss.py:71-81)
+        return torch.mean(el.reshape(target.shape[0], -1), dim=1).mean()
+
+    # ------------------------------------------------------------------ fused path
+    def forward_backward(self, embeddings, noise=None, u=None, grad_scale=1.0):
+        """loss (device fp32 scalar); LoRA grads accumulated into the flat gradient buffer."""
+        packed, target, pe, t_in, S_t = self._prepare(embeddings, noise, u)
+        dit = self.dit
+        plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
+        dit.lora_store  # make sure the flat buffers / grads are attached
+        pred = plan.run_forward(packed, pe, t_in)
+        loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
+        plan.run_backward(dpred)
+        return loss
+
+    def allreduce_grads(self):
+        if self.world > 1:
+            g = self.dit.lora_store.gflat
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            return 1.0 / self.world
+        return 1.0
+
+    def optimizer_step(self, grad_scale=1.0):
+        st = self.dit.lora_store
+        if self._m is None or self._m.numel() != st.pflat.numel() or self._m.device != st.pflat.device:
+            self._m = torch.zeros_like(st.pflat)
+            self._v = torch.zeros_like(st.pflat)
+            self._gnorm = torch.zeros((), dtype=torch.float32, device=st.pflat.device)
+        self.global_step += 1
+        self._gnorm.zero_()
+        ops.sumsq(st.gflat, self._gnorm)
+        ops.adamw_step(st.pflat, st.gflat, self._m, self._v, self.lr, self.betas[0], self.betas[1], self.eps,
+                       self.weight_decay, self.global_step, gnorm_sq=self._gnorm, max_norm=self.max_grad_norm,
+                       grad_scale=grad_scale)
+
+    def zero_grad(self):
+        self.dit.lora_store.gflat.zero_()
+
+    def train_step(self, embeddings, noise=None, u=None):
+        """One full optimisation step; returns the (device) loss."""
+        loss = self.forward_backward(embeddings, noise, u)
+        scale = self.allreduce_grads()
+        self.optimizer_step(grad_scale=scale)
+        self.zero_grad()
+        return loss
+
+    def gather_loss(self, loss):
+        """accelerator.gather(loss).mean() (base_trainer.py:539)."""
+        if self.world > 1:
+            out = [torch.zeros_like(loss) for _ in range(self.world)]
+            dist.all_gather(out, loss, group=self.group)
+            return torch.stack(out).mean()
+        return loss
+
+
+def init_distributed_from_env():
+    """One process per GPU; backend "nccl" is RCCL on ROCm.  Returns (rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world

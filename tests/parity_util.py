@@ -1,0 +1,98 @@
+"""Shared parity drivers (used by tests/ and __graft_entry__.smoke()): HIP path vs the CPU oracle."""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "qwen-image-finetune_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+BF = torch.bfloat16
+
+
+def relmax(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def build_pair(cfg, r=4, lora_alpha=8, adapter="lora_edit", seed=2, device="cuda:0", targets=("to_k", "to_q", "to_v", "to_out.0")):
+    """Oracle (bf16 base weights, fp32 adapters: the reference's training dtype layout) and the HIP model
+    loaded from the oracle's state dict (exercises the state-dict name compatibility)."""
+    from common import fill_weights
+    from oracle import qwen_dit as O
+    from qflux_amd.models import QwenImageTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+
+    oracle = O.OracleQwenDiT(**cfg)
+    O.add_lora(oracle, r=r, lora_alpha=lora_alpha, adapter_name=adapter, target_modules=targets)
+    fill_weights(oracle, seed=seed)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    with torch.device(device):
+        hip = QwenImageTransformer2DModel(**cfg)
+    hip.add_adapter(LoraConfig(r=r, lora_alpha=lora_alpha, target_modules=list(targets)), adapter)
+    missing, unexpected = hip.load_state_dict(oracle.state_dict(), strict=True)
+    assert not missing and not unexpected
+    return oracle, hip
+
+
+def tiny_embeddings(B=2, shapes=((1, 4, 6), (1, 4, 6)), T=5, Jd=512, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    S_t = shapes[0][0] * shapes[0][1] * shapes[0][2]
+    S_c = sum(f * h * w for f, h, w in shapes[1:])
+    emb = dict(image_latents=torch.randn(B, S_t, 64, generator=g).half().float(),
+               control_latents=torch.randn(B, S_c, 64, generator=g).half().float(),
+               prompt_embeds=(torch.randn(B, T, Jd, generator=g) * 4).half().float(),
+               prompt_embeds_mask=torch.ones(B, T, dtype=torch.int64),
+               img_shapes=[[tuple(s) for s in shapes]] * B)
+    noise = torch.randn(B, S_t, 64, generator=g)
+    u = torch.tensor([0.7109, 0.1611, 0.5, 0.93][:B])
+    return emb, noise, u
+
+
+def run_tiny_step_parity(device="cuda:0", verbose=False, cfg=None, shapes=((1, 4, 6), (1, 4, 6)), T=5, B=2, r=4,
+                         targets=("to_k", "to_q", "to_v", "to_out.0"), fused=True):
+    from common import TINY
+    from oracle import qwen_dit as O
+    from qflux_amd.trainer import QwenLoraTrainStep
+
+    cfg = dict(TINY if cfg is None else cfg)
+    oracle, hip = build_pair(cfg, r=r, device=device, targets=targets)
+    emb, noise, u = tiny_embeddings(B=B, shapes=shapes, T=T, Jd=cfg["joint_attention_dim"])
+    loss_o, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+    loss_o.backward()
+    step = QwenLoraTrainStep(hip)
+    res = {}
+    if fused:
+        loss_h = step.forward_backward(emb, noise=noise, u=u)
+        plan = list(hip._plans.values())[0]
+        pred_h = plan.A["out"].view(B, -1, plan.A["out"].shape[-1])[:, : pred_o.shape[1]]
+    else:
+        loss_h = step.compute_loss(emb, noise=noise, u=u)
+        loss_h.backward()
+        pred_h = None
+    torch.cuda.synchronize()
+    res["loss_oracle"], res["loss_hip"] = loss_o.item(), loss_h.item()
+    res["loss_rel"] = abs(loss_h.item() - loss_o.item()) / abs(loss_o.item())
+    if pred_h is not None:
+        res["pred_rel"] = relmax(pred_h, pred_o)
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    worst = 0.0
+    worst_name = None
+    nz = 0
+    for n, p in hip.named_parameters():
+        if "lora" in n:
+            e = relmax(p.grad, og[n])
+            nz += int(p.grad.abs().max().item() > 0)
+            if e > worst:
+                worst, worst_name = e, n
+    res["grad_rel_worst"], res["grad_worst_name"], res["grads_nonzero"] = worst, worst_name, nz
+    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 4e-2 and worst < 8e-2 and nz == len(og))
+    if verbose:
+        print(res)
+    return res
