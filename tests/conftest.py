@@ -16,3 +16,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionstart(session):
+    """Refuse to test a stale libqfx.so (sources newer than the built library)."""
+    import __graft_entry__ as g
+    if os.path.exists(g.LIB) and g._stale():
+        g.build()
