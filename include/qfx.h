@@ -64,6 +64,12 @@ typedef struct qfx_gemm_args {
 
 int qfx_gemm_bf16(const qfx_gemm_args* args, void* stream);
 
+/* Grouped launch: n <= QFX_MAX_GROUPS independent problems with the same epilogue kind in ONE grid
+ * (image + text stream, q/k/v projections): the small text-stream GEMMs share the machine with the
+ * image-stream ones instead of running latency-bound on a few dozen tiles. `groups` is a HOST array. */
+#define QFX_MAX_GROUPS 6
+int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream);
+
 /* ---- LoRA rank-r down projection ("skinny" GEMM, HBM-bound) ----------------------------------
  * U[M,R] (fp32) = X[M,K] (bf16) * (W_hi + W_lo)[R,K]^T   (W = fp32 LoRA weight split in two bf16)
  * and its packed bf16 image EXT[M, 3R] = [U_hi | U_lo | U_hi] written at ext + m*ld_ext
@@ -75,6 +81,8 @@ typedef struct qfx_lora_down_args {
   const uint16_t* W_hi; const uint16_t* W_lo; int64_t ldw; int32_t R;
   float* U; int64_t ldu;                 /* may be NULL */
   uint16_t* ext; int64_t ld_ext;         /* may be NULL */
+  uint16_t* Ut_hi; uint16_t* Ut_lo; int64_t ld_ut; /* may be NULL: transposed split image Ut[R][ld_ut] (column = row index m),
+                                            the V operand of qfx_lora_grad; columns >= M must be pre-zeroed by the caller */
   int32_t group_R; int32_t group_stride; /* ext column of U column j: (j/group_R)*group_stride + j%group_R + {0,group_R,2*group_R}
                                             (several LoRA targets sharing X are fused in one call; group_R = R for one) */
   int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off; /* X row remap as in gemm */
@@ -82,17 +90,19 @@ typedef struct qfx_lora_down_args {
 
 int qfx_lora_down(const qfx_lora_down_args* args, void* stream);
 
-/* ---- LoRA weight gradients (outer-product accumulation over tokens) -------------------------
- * G[j,k] += sum_m V[m,j] * X[m,k]   j<R, k<K ; V fp32 [M,R], X bf16 [M,K]; G fp32, atomically
- * accumulated at G[j*g_sr + k*g_sc] (so dA [r,K] uses (K,1) and dB [N,r] uses (1,r)).
- * Replaces autograd's dW for lora_A / lora_B (frozen base weights never get a dW at all).
+/* ---- LoRA weight gradients (contraction over tokens, MFMA + LDS transpose reads) -------------
+ * G[j,k] += out_scale * sum_m (Vt_hi+Vt_lo)[j,m] * X[m,k]   j<R, k<K ; Vt = transposed bf16 split of the fp32
+ * rank-r activations written by qfx_lora_down (rows zero-padded to a multiple of 32 tokens), X bf16 [M,K];
+ * G fp32, atomically accumulated at G[j*g_sr + k*g_sc] (dA [r,K] uses (K,1), dB [N,r] uses (1,r)).
+ * Up to three fused targets: rank j belongs to group j/group_R and goes to G, G1 or G2 (rank j%group_R,
+ * written only if < r_valid).  Replaces autograd's dW for lora_A / lora_B (frozen base weights never get a dW).
  */
 typedef struct qfx_lora_grad_args {
-  const float* V; int64_t ldv; int32_t R; int32_t r_valid;  /* only j < r_valid are written */
+  const uint16_t* Vt_hi; const uint16_t* Vt_lo; int64_t ldvt; int32_t R; int32_t r_valid; int32_t group_R;
   const uint16_t* X; int64_t ldx; int32_t M; int32_t K;
-  float* G; int64_t g_sr; int64_t g_sc;
+  float* G; float* G1; float* G2; int64_t g_sr; int64_t g_sc;
   int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off;
-  float out_scale;                       /* G += out_scale * (V^T X)  (lora_alpha/r for dB) */
+  float out_scale;                       /* lora_alpha/r for dB, 1 for dA */
 } qfx_lora_grad_args;
 
 int qfx_lora_grad(const qfx_lora_grad_args* args, void* stream);
@@ -206,6 +216,9 @@ int qfx_sumsq(const float* g, int64_t n, float* out /* zeroed by caller */, void
 int qfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float bias_corr1, float bias_corr2,
                    const float* gnorm_sq /* may be NULL */, float max_norm, float grad_scale, void* stream);
+
+/* ---- debug: lane mapping of ds_read_b64_tr_b16 (64 lanes x 4 bf16 in, same out) ---- */
+int qfx_debug_tr_read(const uint16_t* in, uint16_t* out, void* stream);
 
 /* ---- misc ---- */
 int qfx_abi_version(void);

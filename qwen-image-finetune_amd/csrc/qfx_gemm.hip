@@ -195,10 +195,203 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
   }
 }
 
-}  // namespace
 
-extern "C" int qfx_gemm_bf16(const qfx_gemm_args* a, void* stream) {
-  if (!a || !a->A1 || !a->B1 || !a->C) return QFX_EINVAL;
+// =============================================================================================
+// v2: 256x128x64 tile, 8 waves (4x2, each 64x64), ONE block per CU, 3-stage LDS-DMA ring with a
+// counted vmcnt (two K tiles in flight across the single barrier per K tile), grouped launch:
+// up to QFX_MAX_GROUPS independent problems (image/text streams, q/k/v) share one grid so the
+// small text-stream GEMMs ride along instead of running latency-bound on 72 tiles.
+constexpr int BM2 = 256;
+constexpr int STAGE_BYTES = (BM2 + BN) * BK * 2;  // 48 KiB
+constexpr int NSTAGE = 3;
+
+struct GroupedArgs {
+  qfx_gemm_args g[QFX_MAX_GROUPS];
+  int tile_start[QFX_MAX_GROUPS + 1];
+  int n;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < QFX_MAX_GROUPS; ++i)
+    if (i < ga.n && swz >= ga.tile_start[i]) gi = i;
+  const qfx_gemm_args& p = ga.g[gi];
+  const int lt = swz - ga.tile_start[gi];
+  const int tiles_m = (p.M + BM2 - 1) / BM2;
+  const int m0 = (lt % tiles_m) * BM2;
+  const int n0 = (lt / tiles_m) * BN;
+
+  const int srow = lane >> 3;
+  const int schunk = lane & 7;
+  const bf16_t* pa[4];
+  const bf16_t* pb[2];
+  int a_row[4], b_row[2], sca[4], scb[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lr = w * 32 + i * 8 + srow;
+    sca[i] = (schunk ^ ((lr >> 1) & 7)) * 8;
+    int gm = m0 + lr; gm = gm < p.M ? gm : p.M - 1;
+    a_row[i] = gm;
+    pa[i] = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1 + sca[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = w * 16 + i * 8 + srow;
+    scb[i] = (schunk ^ ((lr >> 1) & 7)) * 8;
+    int gn = n0 + lr; gn = gn < p.N ? gn : p.N - 1;
+    b_row[i] = gn;
+    pb[i] = p.B1 + (int64_t)gn * p.ldb1 + scb[i];
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
+  const int g = lane >> 4, li = lane & 15;
+
+  auto stage = [&](int t, int buf) {
+    if (t == nt1) {  // switch to the LoRA K segment (A2 rows are never remapped)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pa[i] = p.A2 + (int64_t)a_row[i] * p.lda2 + sca[i];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) pb[i] = p.B2 + (int64_t)b_row[i] * p.ldb2 + scb[i];
+    }
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sB = sA + BM2 * BK * 2;
+    const int koff = (t < nt1 ? t : t - nt1) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(pa[i] + koff, sA + (w * 32 + i * 8) * (BK * 2));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(pb[i] + koff, sB + (w * 16 + i * 8) * (BK * 2));
+  };
+
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  int buf = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) {
+      int nb = buf + 2; nb = nb >= NSTAGE ? nb - NSTAGE : nb;
+      stage(t + 2, nb);
+    }
+    const char* sA = smem + buf * STAGE_BYTES;
+    const char* sB = sA + BM2 * BK * 2;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[4], b[4];
+      const int chunk = kk * 4 + g;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int row = wr * 64 + mi * 16 + li;
+        a[mi] = *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int row = wc * 64 + ni * 16 + li;
+        b[ni] = *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+    }
+    if (nt2 > 0 && t == nt1 - 1) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && n + 3 < p.N) {
+          const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
+      }
+    }
+    buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+  }
+
+  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wr * 64 + mi * 16 + li;
+    if (m >= p.M) continue;
+    const int bidx = m / p.rows_per_batch;
+    const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+      if (n + 3 >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+      if (bias_pending) {
+        const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f((bf16_t)bb[r]);
+      }
+      bf16x4 o;
+      if constexpr (EPI == QFX_EPI_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(v[r]);
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+      } else if constexpr (EPI == QFX_EPI_GELU) {
+        bf16x4 o2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16_t h = f2bf(v[r]);
+          o[r] = (short)h;
+          o2[r] = (short)f2bf(gelu_tanh_f(bf2f(h)));
+        }
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+        *(bf16x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+      } else if constexpr (EPI == QFX_EPI_GATE_RES) {
+        const bf16x4 gt = *(const bf16x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
+        const bf16x4 rs = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = rbf(v[r]);
+          const float gy = rbf(bf2f((bf16_t)gt[r]) * y);
+          o[r] = (short)f2bf(bf2f((bf16_t)rs[r]) + gy);
+        }
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+      } else {
+        const bf16x4 hx = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = rbf(v[r]);
+          o[r] = (short)f2bf(y * gelu_tanh_grad_f(bf2f((bf16_t)hx[r])));
+        }
+        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+int validate(const qfx_gemm_args* a) {
+  if (!a->A1 || !a->B1 || !a->C) return QFX_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K1 <= 0 || (a->K1 % BK) != 0 || (a->K2 % BK) != 0 || a->K2 < 0) return QFX_EINVAL;
   if ((a->N % 4) != 0 || (a->lda1 % 8) || (a->ldb1 % 8) || (a->ldc % 4)) return QFX_EINVAL;
   if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return QFX_EINVAL;
@@ -206,14 +399,51 @@ extern "C" int qfx_gemm_bf16(const qfx_gemm_args* a, void* stream) {
   if (a->epi == QFX_EPI_GELU && (!a->C2 || (a->ldc2 % 4))) return QFX_EINVAL;
   if (a->epi == QFX_EPI_GATE_RES && (!a->gate || !a->aux || (a->ldaux % 4))) return QFX_EINVAL;
   if (a->epi == QFX_EPI_DGELU && (!a->aux || (a->ldaux % 4))) return QFX_EINVAL;
+  if (a->epi < 0 || a->epi > 3) return QFX_EUNSUPPORTED;
+  return QFX_OK;
+}
+
+}  // namespace
+
+extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream) {
+  if (!groups || n <= 0 || n > QFX_MAX_GROUPS) return QFX_EINVAL;
+  GroupedArgs ga;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate(&groups[i]);
+    if (rc) return rc;
+    if (groups[i].epi != groups[0].epi) return QFX_EINVAL;
+    ga.g[i] = groups[i];
+    ga.tile_start[i] = tiles;
+    tiles += ((groups[i].M + BM2 - 1) / BM2) * ((groups[i].N + BN - 1) / BN);
+  }
+  for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
+  ga.n = n;
+  hipStream_t s = (hipStream_t)stream;
+  switch (groups[0].epi) {
+    case QFX_EPI_NONE: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_NONE>, dim3(tiles), dim3(512), 0, s, ga); break;
+    case QFX_EPI_GELU: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GELU>, dim3(tiles), dim3(512), 0, s, ga); break;
+    case QFX_EPI_GATE_RES: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GATE_RES>, dim3(tiles), dim3(512), 0, s, ga); break;
+    default: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_DGELU>, dim3(tiles), dim3(512), 0, s, ga); break;
+  }
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_gemm_bf16(const qfx_gemm_args* a, void* stream) {
+  if (!a) return QFX_EINVAL;
+  const int rc = validate(a);
+  if (rc) return rc;
+  // large problems: 256x128 tiles / 3-stage ring; small ones keep the 128x128 kernel (more tiles, 2 blocks per CU)
+  const int tiles256 = ((a->M + BM2 - 1) / BM2) * ((a->N + BN - 1) / BN);
+  if (tiles256 >= 160) return qfx_gemm_grouped(a, 1, stream);
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   hipStream_t s = (hipStream_t)stream;
   switch (a->epi) {
     case QFX_EPI_NONE: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_NONE>, dim3(tiles), dim3(256), 0, s, *a); break;
     case QFX_EPI_GELU: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_GELU>, dim3(tiles), dim3(256), 0, s, *a); break;
     case QFX_EPI_GATE_RES: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_GATE_RES>, dim3(tiles), dim3(256), 0, s, *a); break;
-    case QFX_EPI_DGELU: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_DGELU>, dim3(tiles), dim3(256), 0, s, *a); break;
-    default: return QFX_EUNSUPPORTED;
+    default: hipLaunchKernelGGL(gemm_kernel<QFX_EPI_DGELU>, dim3(tiles), dim3(256), 0, s, *a); break;
   }
   QFX_CHECK_LAUNCH();
   return QFX_OK;

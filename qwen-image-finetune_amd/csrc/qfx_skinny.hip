@@ -6,24 +6,22 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// U[M,R] = X[M,K] (W_hi+W_lo)[R,K]^T, fp32 accumulate.  Block = 32 rows of X, 4 waves interleave
-// the K/32 MFMA steps (adjacent waves read adjacent 64 B of each row), LDS reduce at the end.
+// U[M,R] = X[M,K] (W_hi+W_lo)[R,K]^T, fp32 accumulate.  Block = 16 rows of X x 8 waves; the waves
+// interleave the K/32 MFMA steps (adjacent waves read adjacent 64 B of each row), two steps in flight
+// per wave, LDS reduce at the end.  Outputs: U fp32, the packed bf16 K-extension image for the GEMM,
+// and the transposed hi/lo image Ut[R][M] that the weight-gradient kernel contracts over tokens.
 template <int NF>
-__global__ __launch_bounds__(256) void lora_down_kernel(const qfx_lora_down_args p) {
-  constexpr int MF = 2;
-  __shared__ float red[4][MF * NF * 256];
+__global__ __launch_bounds__(512) void lora_down_kernel(const qfx_lora_down_args p) {
+  constexpr int NW = 8;
+  __shared__ float red[NW][NF * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int m0 = blockIdx.x * (16 * MF);
+  const int m0 = blockIdx.x * 16;
 
-  const bf16_t* xrow[MF];
-#pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    int m = m0 + mf * 16 + li;
-    m = m < p.M ? m : p.M - 1;
-    xrow[mf] = p.X + remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + 8 * g;
-  }
+  int mr = m0 + li;
+  mr = mr < p.M ? mr : p.M - 1;
+  const bf16_t* xrow = p.X + remap_row(mr, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + 8 * g;
   const bf16_t* wh[NF];
   const bf16_t* wl[NF];
 #pragma unroll
@@ -31,97 +29,167 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const qfx_lora_down_args
     wh[nf] = p.W_hi + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
     wl[nf] = p.W_lo + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
   }
-  f32x4 acc[MF][NF];
+  f32x4 acc[NF];
 #pragma unroll
-  for (int i = 0; i < MF; ++i)
-#pragma unroll
-    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nks = p.K / 32;
-  for (int ks = w; ks < nks; ks += 4) {
-    const int k = ks * 32;
-    bf16x8 x[MF];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) x[mf] = *(const bf16x8*)(xrow[mf] + k);
+  int ks = w;
+  for (; ks + NW < nks; ks += 2 * NW) {
+    const int k0 = ks * 32, k1 = (ks + NW) * 32;
+    const bf16x8 x0 = *(const bf16x8*)(xrow + k0);
+    const bf16x8 x1 = *(const bf16x8*)(xrow + k1);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
-      const bf16x8 h = *(const bf16x8*)(wh[nf] + k);
-      const bf16x8 l = *(const bf16x8*)(wl[nf] + k);
+      const bf16x8 h0 = *(const bf16x8*)(wh[nf] + k0), l0 = *(const bf16x8*)(wl[nf] + k0);
+      const bf16x8 h1 = *(const bf16x8*)(wh[nf] + k1), l1 = *(const bf16x8*)(wl[nf] + k1);
+      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, h0, acc[nf], 0, 0, 0);
+      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, l0, acc[nf], 0, 0, 0);
+      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, h1, acc[nf], 0, 0, 0);
+      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, l1, acc[nf], 0, 0, 0);
+    }
+  }
+  for (; ks < nks; ks += NW) {
+    const int k0 = ks * 32;
+    const bf16x8 x0 = *(const bf16x8*)(xrow + k0);
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mf], h, acc[mf][nf], 0, 0, 0);
-        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mf], l, acc[mf][nf], 0, 0, 0);
-      }
+    for (int nf = 0; nf < NF; ++nf) {
+      const bf16x8 h0 = *(const bf16x8*)(wh[nf] + k0), l0 = *(const bf16x8*)(wl[nf] + k0);
+      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, h0, acc[nf], 0, 0, 0);
+      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, l0, acc[nf], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
+  for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][((mf * NF + nf) * 64 + lane) * 4 + r] = acc[mf][nf][r];
+    for (int r = 0; r < 4; ++r) red[w][(nf * 64 + lane) * 4 + r] = acc[nf][r];
   __syncthreads();
-  for (int e = tid; e < MF * NF * 256; e += 256) {
-    const float v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
-    const int r = e & 3, ln = (e >> 2) & 63, fn = e >> 8;
-    const int nf = fn % NF, mf = fn / NF;
-    const int m = m0 + mf * 16 + 4 * (ln >> 4) + r;   // D[i = 4g+r][j = lane&15]
+  for (int e = tid; e < NF * 256; e += 512) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += red[ww][e];
+    const int r = e & 3, ln = (e >> 2) & 63, nf = e >> 8;
+    const int m = m0 + 4 * (ln >> 4) + r;   // D[i = 4g+r][j = lane&15]
     const int j = nf * 16 + (ln & 15);
     if (m >= p.M) continue;
     if (p.U) p.U[(int64_t)m * p.ldu + j] = v;
+    const bf16_t hi = f2bf(v);
+    const bf16_t lo = f2bf(v - bf2f(hi));
     if (p.ext) {
-      const bf16_t hi = f2bf(v);
-      const bf16_t lo = f2bf(v - bf2f(hi));
       bf16_t* e0 = p.ext + (int64_t)m * p.ld_ext + (j / p.group_R) * p.group_stride + (j % p.group_R);
       e0[0] = hi;
       e0[p.group_R] = lo;
       e0[2 * p.group_R] = hi;
     }
+    if (p.Ut_hi) {
+      p.Ut_hi[(int64_t)j * p.ld_ut + m] = hi;
+      p.Ut_lo[(int64_t)j * p.ld_ut + m] = lo;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// G[j,k] += sum_m V[m,j] X[m,k].  grid = (K/512, M/64, R/16); thread = 2 columns x 16 ranks.
+// G[j,k] += scale * sum_m (Vt_hi+Vt_lo)[j,m] X[m,k]  -- LoRA dA / dB.  Contraction over TOKENS: the
+// token-major X tile goes through LDS and comes back as MFMA B fragments with ds_read_b64_tr_b16
+// (gfx950 hardware transpose read): within a 16-lane group, lane s supplies 8 bytes
+// {row 8g+4h+(s>>2), cols 4(s&3)..+3} and receives {rows 8g+4h+0..3, col s}.
+// grid = (K/128, token chunks of 128); block = 4 waves x 32 columns; fp32 atomics into G.
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
+constexpr int GX_ROWB = 288;  // padded LDS row stride (bytes) of the [32 tokens][128 cols] tile
+
+template <int NF>
 __global__ __launch_bounds__(256) void lora_grad_kernel(const qfx_lora_grad_args p) {
-  constexpr int MC = 64;
-  __shared__ __attribute__((aligned(16))) float sV[MC][16];
-  const int tid = threadIdx.x;
-  const int jb = blockIdx.z * 16;
-  const int mb = blockIdx.y * MC;
-  const int k = blockIdx.x * 512 + tid * 2;
-  for (int e = tid; e < MC * 16; e += 256) {
-    const int r = e >> 4, c = e & 15;
-    const int m = mb + r;
-    sV[r][c] = (m < p.M && jb + c < p.R) ? p.V[(int64_t)m * p.ldv + jb + c] : 0.f;
-  }
+  constexpr int CH = 128;  // tokens per block
+  __shared__ __attribute__((aligned(16))) char sX[2][32 * GX_ROWB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int k0 = blockIdx.x * 128;
+  const int mb = blockIdx.y * CH;
+  const int nsteps = ((p.M - mb < CH ? p.M - mb : CH) + 31) / 32;
+
+  // staging: thread -> (token row tid/16 + 16*it, 16-byte chunk tid%16)
+  const int srow = tid >> 4, sch = tid & 15;
+  int kc = k0 + sch * 8;
+  const bool kok = kc < p.K;
+  kc = kok ? kc : 0;
+  u32x4 st[2];
+  auto gload = [&](int step) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int m = mb + step * 32 + it * 16 + srow;
+      m = m < p.M ? m : p.M - 1;
+      const bf16_t* src = p.X + remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + kc;
+      st[it] = *(const u32x4*)src;
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) *(u32x4*)(&sX[buf][(it * 16 + srow) * GX_ROWB + sch * 16]) = st[it];
+  };
+
+  f32x4 acc[NF][2];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+
+  gload(0);
+  swrite(0);
   __syncthreads();
-  if (k >= p.K) return;
-  float a0[16], a1[16];
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) gload(s + 1);
+    const char* tile = sX[s & 1];
+    const int mtok = mb + s * 32 + 8 * g;   // tokens mtok..mtok+7 are this lane group's k-slots
+    bf16x8 b[2];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { a0[j] = 0.f; a1[j] = 0.f; }
-  const int mend = (p.M - mb) < MC ? (p.M - mb) : MC;
-  for (int r = 0; r < mend; ++r) {
-    const int64_t row = remap_row(mb + r, p.rows_per_batch, p.x_batch_rows, p.x_row_off);
-    const uint32_t xx = *(const uint32_t*)(p.X + row * p.ldx + k);
-    const float x0 = __uint_as_float(xx << 16), x1 = __uint_as_float(xx & 0xffff0000u);
+    for (int cf = 0; cf < 2; ++cf) {
+      const int colb = (w * 32 + cf * 16 + 4 * (li & 3)) * 2;
+      const char* a0 = tile + (8 * g + (li >> 2)) * GX_ROWB + colb;
+      const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0));
+      const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0 + 4 * GX_ROWB));
+      const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+      b[cf][0] = l4[0]; b[cf][1] = l4[1]; b[cf][2] = l4[2]; b[cf][3] = l4[3];
+      b[cf][4] = h4[0]; b[cf][5] = h4[1]; b[cf][6] = h4[2]; b[cf][7] = h4[3];
+    }
 #pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-      const f32x4 v = *(const f32x4*)(&sV[r][j4 * 4]);
+    for (int nf = 0; nf < NF; ++nf) {
+      const int64_t ro = (int64_t)(nf * 16 + li) * p.ldvt + mtok;
+      const bf16x8 ah = *(const bf16x8*)(p.Vt_hi + ro);
+      const bf16x8 al = *(const bf16x8*)(p.Vt_lo + ro);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a0[j4 * 4 + q] = fmaf(v[q], x0, a0[j4 * 4 + q]);
-        a1[j4 * 4 + q] = fmaf(v[q], x1, a1[j4 * 4 + q]);
+      for (int cf = 0; cf < 2; ++cf) {
+        acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[cf], acc[nf][cf], 0, 0, 0);
+        acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[cf], acc[nf][cf], 0, 0, 0);
       }
     }
+    if (s + 1 < nsteps) swrite((s + 1) & 1);
+    __syncthreads();
   }
+  // D[i = rank 4g+r][j = col li]
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    if (jb + j < p.r_valid) {
-      float* gp = p.G + (int64_t)(jb + j) * p.g_sr + (int64_t)k * p.g_sc;
-      unsafeAtomicAdd(gp, a0[j] * p.out_scale);
-      unsafeAtomicAdd(gp + p.g_sc, a1[j] * p.out_scale);
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = nf * 16 + 4 * g + r;
+      const int grp = j / p.group_R, jj = j % p.group_R;
+      if (jj >= p.r_valid) continue;
+      float* G = grp == 0 ? p.G : (grp == 1 ? p.G1 : p.G2);
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) {
+        const int k = k0 + w * 32 + cf * 16 + li;
+        if (k < p.K) unsafeAtomicAdd(G + (int64_t)jj * p.g_sr + (int64_t)k * p.g_sc, acc[nf][cf][r] * p.out_scale);
+      }
     }
-  }
+}
+
+// debug: dump the lane mapping of ds_read_b64_tr_b16 (lane l supplies elements 4l..4l+3 of `in`)
+__global__ void tr_probe_kernel(const bf16_t* in, bf16_t* out) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[256];
+  const int l = threadIdx.x;
+  for (int i = 0; i < 4; ++i) lds[l * 4 + i] = in[l * 4 + i];
+  __syncthreads();
+  const bf16x4v v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(lds + l * 4));
+  const bf16x4 r = __builtin_bit_cast(bf16x4, v);
+  for (int i = 0; i < 4; ++i) out[l * 4 + i] = (bf16_t)r[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,9 +234,10 @@ extern "C" int qfx_lora_down(const qfx_lora_down_args* a, void* stream) {
   if (!a || !a->X || !a->W_hi || !a->W_lo) return QFX_EINVAL;
   if (a->M <= 0 || a->K <= 0 || (a->K % 32) || (a->ldx % 8) || (a->ldw % 8) || (a->R % 16) || a->R <= 0) return QFX_EINVAL;
   if (a->ext && (a->group_R <= 0 || (a->R % a->group_R))) return QFX_EINVAL;
+  if (a->Ut_hi && (!a->Ut_lo || a->ld_ut < a->M)) return QFX_EINVAL;
   if (a->rows_per_batch <= 0) return QFX_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((a->M + 31) / 32), block(256);
+  dim3 grid((a->M + 15) / 16), block(512);
   switch (a->R / 16) {
     case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, block, 0, s, *a); break;
     case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, block, 0, s, *a); break;
@@ -182,10 +251,22 @@ extern "C" int qfx_lora_down(const qfx_lora_down_args* a, void* stream) {
 }
 
 extern "C" int qfx_lora_grad(const qfx_lora_grad_args* a, void* stream) {
-  if (!a || !a->V || !a->X || !a->G) return QFX_EINVAL;
-  if (a->M <= 0 || a->K <= 0 || (a->K % 2) || (a->ldx % 2) || a->R <= 0 || a->rows_per_batch <= 0) return QFX_EINVAL;
-  dim3 grid((a->K + 511) / 512, (a->M + 63) / 64, (a->R + 15) / 16);
-  hipLaunchKernelGGL(lora_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  if (!a || !a->Vt_hi || !a->Vt_lo || !a->X || !a->G) return QFX_EINVAL;
+  if (a->M <= 0 || a->K <= 0 || (a->K % 8) || (a->ldx % 8) || a->R <= 0 || (a->R % 16) || a->rows_per_batch <= 0) return QFX_EINVAL;
+  if ((a->ldvt % 8) || a->ldvt < ((a->M + 31) / 32) * 32) return QFX_EINVAL;  /* rows must be zero-padded to a multiple of 32 tokens */
+  if (a->group_R <= 0 || (a->group_R % 16) || (a->R % a->group_R) || a->R / a->group_R > 3) return QFX_EINVAL;
+  if (a->R / a->group_R > 1 && !a->G1) return QFX_EINVAL;
+  if (a->R / a->group_R > 2 && !a->G2) return QFX_EINVAL;
+  dim3 grid((a->K + 127) / 128, (a->M + 127) / 128);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->R / 16) {
+    case 1: hipLaunchKernelGGL(lora_grad_kernel<1>, grid, dim3(256), 0, s, *a); break;
+    case 2: hipLaunchKernelGGL(lora_grad_kernel<2>, grid, dim3(256), 0, s, *a); break;
+    case 3: hipLaunchKernelGGL(lora_grad_kernel<3>, grid, dim3(256), 0, s, *a); break;
+    case 4: hipLaunchKernelGGL(lora_grad_kernel<4>, grid, dim3(256), 0, s, *a); break;
+    case 6: hipLaunchKernelGGL(lora_grad_kernel<6>, grid, dim3(256), 0, s, *a); break;
+    default: return QFX_EUNSUPPORTED;
+  }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
@@ -195,6 +276,13 @@ extern "C" int qfx_lora_pack(const qfx_lora_pack_args* descs, int32_t n, int32_t
   int bx = (max_dim * 16 + 255) / 256;
   if (bx > 64) bx = 64;
   hipLaunchKernelGGL(lora_pack_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, descs);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_debug_tr_read(const uint16_t* in, uint16_t* out, void* stream) {
+  if (!in || !out) return QFX_EINVAL;
+  hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -35,6 +35,7 @@ class LoraDownArgs(C.Structure):
         ("W_hi", C.c_void_p), ("W_lo", C.c_void_p), ("ldw", C.c_int64), ("R", C.c_int32),
         ("U", C.c_void_p), ("ldu", C.c_int64),
         ("ext", C.c_void_p), ("ld_ext", C.c_int64),
+        ("Ut_hi", C.c_void_p), ("Ut_lo", C.c_void_p), ("ld_ut", C.c_int64),
         ("group_R", C.c_int32), ("group_stride", C.c_int32),
         ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
     ]
@@ -42,9 +43,9 @@ class LoraDownArgs(C.Structure):
 
 class LoraGradArgs(C.Structure):
     _fields_ = [
-        ("V", C.c_void_p), ("ldv", C.c_int64), ("R", C.c_int32), ("r_valid", C.c_int32),
+        ("Vt_hi", C.c_void_p), ("Vt_lo", C.c_void_p), ("ldvt", C.c_int64), ("R", C.c_int32), ("r_valid", C.c_int32), ("group_R", C.c_int32),
         ("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
-        ("G", C.c_void_p), ("g_sr", C.c_int64), ("g_sc", C.c_int64),
+        ("G", C.c_void_p), ("G1", C.c_void_p), ("G2", C.c_void_p), ("g_sr", C.c_int64), ("g_sc", C.c_int64),
         ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
         ("out_scale", C.c_float),
     ]
@@ -80,6 +81,7 @@ EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "qfx_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "qfx_gemm_grouped": (C.c_int, [C.POINTER(GemmArgs), _i32, _vp]),
     "qfx_lora_down": (C.c_int, [C.POINTER(LoraDownArgs), _vp]),
     "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),
     "qfx_lora_pack": (C.c_int, [_vp, _i32, _i32, _vp]),
@@ -100,6 +102,7 @@ SYMBOLS = {
     "qfx_flowmatch_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "qfx_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
     "qfx_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _vp]),
+    "qfx_debug_tr_read": (C.c_int, [_vp, _vp, _vp]),
     "qfx_abi_version": (C.c_int, []),
     "qfx_build_arch": (C.c_char_p, []),
 }

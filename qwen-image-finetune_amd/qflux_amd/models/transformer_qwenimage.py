@@ -443,7 +443,7 @@ class _QwenPlan:
         A["mods"] = buf(2 * Lyr, B, 6 * D); A["mod_out"] = buf(1, B, 2 * D)
         A["xm"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["g"] = {s: buf(rows[s], 4 * D) for s in ("img", "txt")}
-        A["Vt"] = buf(B, H, dh, S_pad)
+        A["VtA"] = buf(B, H, dh, S_pad)
         A["xn_out"] = buf(B * S_i, D); A["out"] = buf(B * S_i, Cout)
         A["blk"] = []
         for i in range(Lyr):
@@ -452,11 +452,13 @@ class _QwenPlan:
                      x1={s: buf(rows[s], D) for s in ("img", "txt")}, h={s: buf(rows[s], 4 * D) for s in ("img", "txt")})
             for s in ("img", "txt"):
                 grp = w[s + ".qkv_lora"]
+                mp = _ceil(rows[s], 128)
                 if grp is not None:
                     b["xm1." + s] = buf(rows[s], D)
-                    b["Uqkv." + s] = buf(rows[s], 3 * grp["Rp"], dtype=F32)
+                    b["Uqkv." + s] = (buf(3 * grp["Rp"], mp, zero=True), buf(3 * grp["Rp"], mp, zero=True))   # u^T hi/lo
                 if w[s + ".o"].lora is not None:
-                    b["Uo." + s] = buf(rows[s], w[s + ".o"].lora.Rp, dtype=F32)
+                    rp_o = w[s + ".o"].lora.Rp
+                    b["Uo." + s] = (buf(rp_o, mp, zero=True), buf(rp_o, mp, zero=True))
             A["blk"].append(b)
         # LoRA scratch (pad columns stay zero forever)
         kext_max = 0
@@ -471,7 +473,8 @@ class _QwenPlan:
         if self.has_lora:
             A["ext3"] = {s: buf(rows[s], 3 * kext_max, zero=True) for s in ("img", "txt")}
             A["ext1"] = {s: buf(rows[s], kext_max, zero=True) for s in ("img", "txt")}
-            A["Vscr"] = {s: buf(rows[s], 3 * rp_max, dtype=F32) for s in ("img", "txt")}
+            A["Vt"] = {s: (buf(3 * rp_max, _ceil(rows[s], 128), zero=True), buf(3 * rp_max, _ceil(rows[s], 128), zero=True))
+                       for s in ("img", "txt")}   # v^T hi/lo scratch (pad columns stay zero)
         # backward scratch
         A["dpred"] = buf(B * S_i, Cout)
         A["dxn"] = buf(B * S_i, D)
@@ -494,8 +497,9 @@ class _QwenPlan:
         self._build_backward(P)
 
     # ------------------------------------------------------------------ emit helpers
-    def _gemm(self, prog, *, A1, lda1, B1, K1, M, N, C_, ldc, ldb1=None, bias=None, A2=None, lda2=0, B2=None, ldb2=0, K2=0,
-              epi=L.EPI_NONE, C2=None, ldc2=0, aux=None, ldaux=0, gate=None, gate_bs=0, rpb=None, a_map=(0, 0), c_map=(0, 0)):
+    @staticmethod
+    def _gargs(*, A1, lda1, B1, K1, M, N, C_, ldc, ldb1=None, bias=None, A2=None, lda2=0, B2=None, ldb2=0, K2=0,
+               epi=L.EPI_NONE, C2=None, ldc2=0, aux=None, ldaux=0, gate=None, gate_bs=0, rpb=None, a_map=(0, 0), c_map=(0, 0)):
         g = L.GemmArgs()
         g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _ptr(A1), _ptr(B1), lda1, (K1 if ldb1 is None else ldb1), K1
         if K2:
@@ -510,16 +514,32 @@ class _QwenPlan:
         g.a_batch_rows, g.a_row_off = a_map
         g.c_batch_rows, g.c_row_off = c_map
         g.epi = epi
+        return g
+
+    def _gemm(self, prog, **kw):
+        g = self._gargs(**kw)
         prog.keep.append(g)
         prog.c(lib.qfx_gemm_bf16, C.byref(g))
 
-    def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, group_R=None, group_stride=0,
-              rpb=None, x_map=(0, 0)):
+    def _gemm_group(self, prog, groups):
+        """One grid for several independent GEMMs with the same epilogue (image+text streams, q/k/v)."""
+        if len(groups) == 1:
+            prog.keep.append(groups[0])
+            prog.c(lib.qfx_gemm_bf16, C.byref(groups[0]))
+            return
+        arr = (L.GemmArgs * len(groups))(*groups)
+        prog.keep.append(arr)
+        prog.c(lib.qfx_gemm_grouped, arr, len(groups))
+
+    def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
+              group_stride=0, rpb=None, x_map=(0, 0)):
         a = L.LoraDownArgs()
         a.X, a.ldx, a.M, a.K = _ptr(X), ldx, M, K
         a.W_hi, a.W_lo, a.ldw, a.R = _ptr(W_hi), _ptr(W_lo), ldw, R
         a.U, a.ldu = _ptr(U), ldu
         a.ext, a.ld_ext = _ptr(ext), ld_ext
+        if Ut is not None:
+            a.Ut_hi, a.Ut_lo, a.ld_ut = _ptr(Ut[0]), _ptr(Ut[1]), Ut[0].stride(0)
         a.group_R = R if group_R is None else group_R
         a.group_stride = group_stride
         a.rows_per_batch = M if rpb is None else rpb
@@ -527,11 +547,16 @@ class _QwenPlan:
         prog.keep.append(a)
         prog.c(lib.qfx_lora_down, C.byref(a))
 
-    def _grad(self, prog, *, V, ldv, R, r_valid, X, ldx, M, K, G, g_sr, g_sc, rpb=None, x_map=(0, 0), out_scale=1.0):
+    def _grad(self, prog, *, Vt, R, r_valid, X, ldx, M, K, G, g_sr, g_sc, group_R=None, rpb=None, x_map=(0, 0), out_scale=1.0):
         a = L.LoraGradArgs()
-        a.V, a.ldv, a.R, a.r_valid = _ptr(V), ldv, R, r_valid
+        Gs = G if isinstance(G, (tuple, list)) else (G,)
+        a.Vt_hi, a.Vt_lo, a.ldvt, a.R, a.r_valid = _ptr(Vt[0]), _ptr(Vt[1]), Vt[0].stride(0), R, r_valid
+        a.group_R = R // len(Gs) if group_R is None else group_R
         a.X, a.ldx, a.M, a.K = _ptr(X), ldx, M, K
-        a.G, a.g_sr, a.g_sc = _ptr(G), g_sr, g_sc
+        a.G = _ptr(Gs[0])
+        a.G1 = _ptr(Gs[1]) if len(Gs) > 1 else None
+        a.G2 = _ptr(Gs[2]) if len(Gs) > 2 else None
+        a.g_sr, a.g_sc = g_sr, g_sc
         a.rows_per_batch = M if rpb is None else rpb
         a.x_batch_rows, a.x_row_off = x_map
         a.out_scale = out_scale
@@ -562,19 +587,25 @@ class _QwenPlan:
                    bias=P["txt_in"].b)
         scale = 1.0 / math.sqrt(dh)
         self.attn_args = []
+        STREAMS = (("img", 0), ("txt", 1))
         for i in range(Lyr):
             w, bb = P["blocks"][i], A["blk"][i]
             last = i == Lyr - 1
             qkv = bb["qkv"]
-            for sidx, s in enumerate(("img", "txt")):
-                mod = A["mods"][2 * i + sidx]                       # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
+            q2 = qkv.view(B * S, 3 * D)
+            ao2 = bb["ao"].view(B * S, D)
+            mods = {s: A["mods"][2 * i + sidx] for s, sidx in STREAMS}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
+            # ---- LN1 + modulate, LoRA down-projections, then ONE grouped launch for the 6 q/k/v projections
+            groups = []
+            for s, sidx in STREAMS:
+                mod = mods[s]
                 x = A["X"][s][i]
                 grp = w[s + ".qkv_lora"]
                 xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
                 p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 6 * D, _ptr(xm1), rows[s], D, rpb[s], eps)
                 if grp is not None:
                     self._down(p, X=xm1, ldx=D, M=rows[s], K=D, W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
-                               U=bb["Uqkv." + s], ldu=3 * grp["Rp"], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
+                               Ut=bb["Uqkv." + s], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
                                group_R=grp["Rp"], group_stride=grp["Kext"])
                 for sec in range(3):
                     lw = w[s + ".qkv"][sec]
@@ -582,18 +613,18 @@ class _QwenPlan:
                     if lw.lora is not None:
                         kw = dict(A2=A["ext3"][s][:, sec * grp["Kext"]:], lda2=A["ext3"][s].stride(0), B2=lw.lora.We,
                                   ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
-                    self._gemm(p, A1=xm1, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=qkv.view(B * S, 3 * D)[:, sec * D:], ldc=3 * D,
-                               bias=lw.b, rpb=rpb[s], c_map=(S, off[s]), **kw)
+                    groups.append(self._gargs(A1=xm1, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=q2[:, sec * D:], ldc=3 * D,
+                                              bias=lw.b, rpb=rpb[s], c_map=(S, off[s]), **kw))
+            self._gemm_group(p, groups)
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_fwd, _ptr(qkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i),
                 B, S, T, H, dh, eps)
-            q2 = qkv.view(B * S, 3 * D)
-            p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["Vt"]), B, S, S_pad, H, dh)
+            p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["VtA"]), B, S, S_pad, H, dh)
             a = L.AttnArgs()
             a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
             a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
             a.ldq = a.ldk = a.ldv = 3 * D
-            a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["Vt"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
+            a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["VtA"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
             # backward fields (same struct reused by the backward program)
             a.Qt, a.Kt, a.dOt, a.dsum = _ptr(A["Qt"]), _ptr(A["Kt"]), _ptr(A["dOt"]), _ptr(A["dsum"])
             a.dO, a.lddo = _ptr(A["dao"]), D
@@ -602,29 +633,37 @@ class _QwenPlan:
             a.lddq = a.lddk = a.lddv = 3 * D
             self.attn_args.append(a)
             p.c(lib.qfx_attn_fwd, C.byref(a))
-            ao2 = bb["ao"].view(B * S, D)
-            for sidx, s in enumerate(("img", "txt")):
-                if last and s == "txt":
-                    continue  # dead compute: the text stream of the last block never reaches the output (:661-663)
-                mod = A["mods"][2 * i + sidx]
-                x = A["X"][s][i]
+            # the text stream of the last block never reaches the output (:661-663): dead compute, skipped
+            live = [(s, sidx) for s, sidx in STREAMS if not (last and s == "txt")]
+            groups = []
+            for s, sidx in live:
                 lw = w[s + ".o"]
                 kw = {}
                 if lw.lora is not None:
                     self._down(p, X=ao2, ldx=D, M=rows[s], K=D, W_hi=lw.lora.A_hi, W_lo=lw.lora.A_lo, ldw=D, R=lw.lora.Rp,
-                               U=bb["Uo." + s], ldu=lw.lora.Rp, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0),
+                               Ut=bb["Uo." + s], ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0),
                                rpb=rpb[s], x_map=(S, off[s]))
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
-                self._gemm(p, A1=ao2, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=bb["x1"][s], ldc=D, bias=lw.b, epi=L.EPI_GATE_RES,
-                           aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D], gate_bs=6 * D, rpb=rpb[s], a_map=(S, off[s]), **kw)
-                xm2 = A["xm"][s]
-                p.c(lib.qfx_ln_modulate_fwd, _ptr(bb["x1"][s]), _ptr(mod[:, 3 * D:4 * D]), _ptr(mod[:, 4 * D:5 * D]), 6 * D, _ptr(xm2),
-                    rows[s], D, rpb[s], eps)
-                f1, f2 = w[s + ".fc1"], w[s + ".fc2"]
-                self._gemm(p, A1=xm2, lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D, bias=f1.b, epi=L.EPI_GELU,
-                           C2=A["g"][s], ldc2=4 * D)
-                self._gemm(p, A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=A["X"][s][i + 1], ldc=D, bias=f2.b,
-                           epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mod[:, 5 * D:6 * D], gate_bs=6 * D, rpb=rpb[s])
+                groups.append(self._gargs(A1=ao2, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=bb["x1"][s], ldc=D, bias=lw.b,
+                                          epi=L.EPI_GATE_RES, aux=A["X"][s][i], ldaux=D, gate=mods[s][:, 2 * D:3 * D], gate_bs=6 * D,
+                                          rpb=rpb[s], a_map=(S, off[s]), **kw))
+            self._gemm_group(p, groups)
+            groups = []
+            for s, sidx in live:
+                mod = mods[s]
+                p.c(lib.qfx_ln_modulate_fwd, _ptr(bb["x1"][s]), _ptr(mod[:, 3 * D:4 * D]), _ptr(mod[:, 4 * D:5 * D]), 6 * D,
+                    _ptr(A["xm"][s]), rows[s], D, rpb[s], eps)
+                f1 = w[s + ".fc1"]
+                groups.append(self._gargs(A1=A["xm"][s], lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D,
+                                          bias=f1.b, epi=L.EPI_GELU, C2=A["g"][s], ldc2=4 * D))
+            self._gemm_group(p, groups)
+            groups = []
+            for s, sidx in live:
+                f2 = w[s + ".fc2"]
+                groups.append(self._gargs(A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=A["X"][s][i + 1], ldc=D,
+                                          bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
+                                          gate_bs=6 * D, rpb=rpb[s]))
+            self._gemm_group(p, groups)
         mo = A["mod_out"][0]  # [B, 2D]: scale | shift  (AdaLayerNormContinuous chunk order)
         p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
             rows["img"], D, rpb["img"], eps)
@@ -650,42 +689,44 @@ class _QwenPlan:
             _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][cur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps)
         dao2 = A["dao"].view(B * S, D)
         dq2 = A["dqkv"].view(B * S, 3 * D)
+        STREAMS = (("img", 0), ("txt", 1))
         for i in range(Lyr - 1, -1, -1):
             w, bb = P["blocks"][i], A["blk"][i]
             last = i == Lyr - 1
             nxt = cur ^ 1
             ao2 = bb["ao"].view(B * S, D)
-            for sidx, s in enumerate(("img", "txt")):
-                mod = A["mods"][2 * i + sidx]
-                if last and s == "txt":
-                    # no gradient reaches the last block's text tail: d(attn out) for text rows is zero
-                    tv = A["dao"][:, :T]
-                    p.py(tv.zero_)
-                    continue
-                dx2 = A["dX"][s][cur]
-                f1, f2 = w[s + ".fc1"], w[s + ".fc2"]
-                # MLP: dh = (gate2*dx2) W2 * gelu'(h) ; dxm2 = dh W1
-                self._gemm(p, A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s], ldc=4 * D, epi=L.EPI_DGELU,
-                           aux=bb["h"][s], ldaux=4 * D)
-                self._gemm(p, A1=A["dh"][s], lda1=4 * D, B1=f1.WT, K1=4 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D)
-                p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(bb["x1"][s]), _ptr(mod[:, 4 * D:5 * D]), 6 * D, _ptr(dx2),
-                    _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps)
+            mods = {s: A["mods"][2 * i + sidx] for s, sidx in STREAMS}
+            live = [(s, sidx) for s, sidx in STREAMS if not (last and s == "txt")]
+            if last:
+                # no gradient reaches the last block's text tail: d(attn out) of the text rows is zero
+                p.py(A["dao"][:, :T].zero_)
+            # ---- MLP backward: dh = (gate2*dx2) W2 * gelu'(h) ; dxm2 = dh W1   (both streams per launch)
+            self._gemm_group(p, [self._gargs(A1=A["dyg2"][s], lda1=D, B1=w[s + ".fc2"].WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s],
+                                             ldc=4 * D, epi=L.EPI_DGELU, aux=bb["h"][s], ldaux=4 * D) for s, _ in live])
+            self._gemm_group(p, [self._gargs(A1=A["dh"][s], lda1=4 * D, B1=w[s + ".fc1"].WT, K1=4 * D, M=rows[s], N=D,
+                                             C_=A["dxm"][s], ldc=D) for s, _ in live])
+            groups = []
+            for s, sidx in live:
+                mod = mods[s]
+                p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(bb["x1"][s]), _ptr(mod[:, 4 * D:5 * D]), 6 * D,
+                    _ptr(A["dX"][s][cur]), _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps)
                 # attention out-projection backward (+ LoRA)
                 lw = w[s + ".o"]
                 kw = {}
                 if lw.lora is not None:
                     lo = lw.lora
-                    Vs = A["Vscr"][s]
+                    Vt = (A["Vt"][s][0][:lo.Rp], A["Vt"][s][1][:lo.Rp])
                     self._down(p, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0),
-                               R=lo.Rp, U=Vs, ldu=Vs.stride(0), ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0))
-                    self._grad(p, V=bb["Uo." + s], ldv=lo.Rp, R=lo.Rp, r_valid=lo.r, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N,
+                               R=lo.Rp, Ut=Vt, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0))
+                    self._grad(p, Vt=bb["Uo." + s], R=lo.Rp, r_valid=lo.r, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N,
                                G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale)
-                    self._grad(p, V=Vs, ldv=Vs.stride(0), R=lo.Rp, r_valid=lo.r, X=ao2, ldx=D, M=rows[s], K=lw.K, G=lo.gA,
+                    self._grad(p, Vt=Vt, R=lo.Rp, r_valid=lo.r, X=ao2, ldx=D, M=rows[s], K=lw.K, G=lo.gA,
                                g_sr=lw.K, g_sc=1, rpb=rpb[s], x_map=(S, off[s]))
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
-                self._gemm(p, A1=A["dyg1"][s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
-                           c_map=(S, off[s]), **kw)
-            # attention backward
+                groups.append(self._gargs(A1=A["dyg1"][s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
+                                          c_map=(S, off[s]), **kw))
+            self._gemm_group(p, groups)
+            # ---- attention backward
             a = self.attn_args[i]
             q2 = bb["qkv"].view(B * S, 3 * D)
             p.c(lib.qfx_transpose_heads, _ptr(dao2), D, _ptr(A["dOt"]), B, S, S_pad, H, dh)
@@ -697,35 +738,48 @@ class _QwenPlan:
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
                 _ptr(nk_i), B, S, T, H, dh, eps)
-            for sidx, s in enumerate(("img", "txt")):
-                mod = A["mods"][2 * i + sidx]
+            # ---- q/k/v projection backward (+ LoRA), both streams in one launch
+            groups = []
+            for s, sidx in STREAMS:
                 grp = w[s + ".qkv_lora"]
                 kw = {}
                 if grp is not None:
                     Rp, Kext = grp["Rp"], grp["Kext"]
-                    Vs = A["Vscr"][s]
+                    Vth, Vtl = A["Vt"][s]
+                    Uth, Utl = bb["Uqkv." + s]
                     e3 = A["ext3"][s]
                     for sec in range(3):
                         lw = w[s + ".qkv"][sec]
                         if lw.lora is None:
                             continue
                         lo = lw.lora
+                        sl = slice(sec * Rp, (sec + 1) * Rp)
                         self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=rows[s], K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo,
-                                   ldw=lo.Bt_hi.stride(0), R=Rp, U=Vs[:, sec * Rp:], ldu=Vs.stride(0), ext=e3[:, sec * Kext:],
+                                   ldw=lo.Bt_hi.stride(0), R=Rp, Ut=(Vth[sl], Vtl[sl]), ext=e3[:, sec * Kext:],
                                    ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]))
-                        self._grad(p, V=bb["Uqkv." + s][:, sec * Rp:], ldv=3 * Rp, R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D,
+                        self._grad(p, Vt=(Uth[sl], Utl[sl]), R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D,
                                    M=rows[s], K=D, G=lo.gB, g_sr=1, g_sc=lo.r, rpb=rpb[s], x_map=(S, off[s]), out_scale=lo.scale)
-                        self._grad(p, V=Vs[:, sec * Rp:], ldv=Vs.stride(0), R=Rp, r_valid=lo.r, X=bb["xm1." + s], ldx=D, M=rows[s],
-                                   K=D, G=lo.gA, g_sr=D, g_sc=1)
+                    los = [w[s + ".qkv"][sec].lora for sec in range(3)]
+                    if all(l is not None for l in los):   # one pass over xm1 for dA of q, k and v
+                        self._grad(p, Vt=(Vth[:3 * Rp], Vtl[:3 * Rp]), R=3 * Rp, r_valid=los[0].r, group_R=Rp, X=bb["xm1." + s],
+                                   ldx=D, M=rows[s], K=D, G=[l.gA for l in los], g_sr=D, g_sc=1)
+                    else:
+                        for sec, lo in enumerate(los):
+                            if lo is not None:
+                                sl = slice(sec * Rp, (sec + 1) * Rp)
+                                self._grad(p, Vt=(Vth[sl], Vtl[sl]), R=Rp, r_valid=lo.r, X=bb["xm1." + s], ldx=D, M=rows[s],
+                                           K=D, G=lo.gA, g_sr=D, g_sc=1)
                     kw = dict(A2=e3, lda2=e3.stride(0), B2=grp["WeT"], ldb2=grp["WeT"].stride(0), K2=3 * Kext)
-                if i == 0:
-                    continue  # nothing upstream of block 0 needs a gradient (frozen embedders, inputs without grad)
-                self._gemm(p, A1=dq2, lda1=3 * D, B1=w[s + ".qkvT"], K1=3 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D, rpb=rpb[s],
-                           a_map=(S, off[s]), **kw)
-                modp = A["mods"][2 * (i - 1) + sidx]
-                dres = None if (last and s == "txt") else A["dx1"][s]
-                p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(A["X"][s][i]), _ptr(mod[:, D:2 * D]), 6 * D, _ptr(dres),
-                    _ptr(modp[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"][s][nxt]), _ptr(A["dyg2"][s]), rows[s], D, rpb[s], eps)
+                if i > 0:   # nothing upstream of block 0 needs a gradient (frozen embedders, inputs without grad)
+                    groups.append(self._gargs(A1=dq2, lda1=3 * D, B1=w[s + ".qkvT"], K1=3 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D,
+                                              rpb=rpb[s], a_map=(S, off[s]), **kw))
+            if i > 0:
+                self._gemm_group(p, groups)
+                for s, sidx in STREAMS:
+                    modp = A["mods"][2 * (i - 1) + sidx]
+                    dres = None if (last and s == "txt") else A["dx1"][s]
+                    p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(A["X"][s][i]), _ptr(mods[s][:, D:2 * D]), 6 * D, _ptr(dres),
+                        _ptr(modp[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"][s][nxt]), _ptr(A["dyg2"][s]), rows[s], D, rpb[s], eps)
             cur = nxt
 
     # ------------------------------------------------------------------ execution

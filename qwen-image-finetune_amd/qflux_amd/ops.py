@@ -55,7 +55,24 @@ def gemm(a1, b1, *, bias=None, a2=None, b2=None, out=None, epi=L.EPI_NONE, out2=
     return out
 
 
-def lora_down(x, w_hi, w_lo, *, U=None, ext=None, group_R=None, group_stride=0, M=None, rows_per_batch=None, x_map=(0, 0)):
+def gemm_grouped(arg_list):
+    """arg_list: list of (a1, b1, out, kwargs) -> one grouped launch (kwargs as for gemm's struct fields)."""
+    gs = []
+    for (a1, b1, out, kw) in arg_list:
+        g = L.GemmArgs()
+        g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _p(a1), _p(b1), a1.stride(0), b1.stride(0), b1.shape[1]
+        g.M, g.N = kw.get("M", a1.shape[0]), b1.shape[0]
+        g.bias = _p(kw.get("bias"))
+        g.C, g.ldc = _p(out), out.stride(0)
+        g.rows_per_batch = g.M
+        g.epi = kw.get("epi", L.EPI_NONE)
+        gs.append(g)
+    arr = (L.GemmArgs * len(gs))(*gs)
+    L.check(lib.qfx_gemm_grouped(arr, len(gs), stream_ptr()), "qfx_gemm_grouped")
+
+
+def lora_down(x, w_hi, w_lo, *, U=None, ext=None, Ut=None, group_R=None, group_stride=0, M=None, rows_per_batch=None, x_map=(0, 0)):
+    """Ut = (Ut_hi, Ut_lo) bf16 [R, ld] zero-initialised transposed split outputs (optional)."""
     a = L.LoraDownArgs()
     M = x.shape[0] if M is None else M
     R, K = w_hi.shape
@@ -65,6 +82,8 @@ def lora_down(x, w_hi, w_lo, *, U=None, ext=None, group_R=None, group_stride=0, 
         a.U, a.ldu = _p(U), U.stride(0)
     if ext is not None:
         a.ext, a.ld_ext = _p(ext), ext.stride(0)
+    if Ut is not None:
+        a.Ut_hi, a.Ut_lo, a.ld_ut = _p(Ut[0]), _p(Ut[1]), Ut[0].stride(0)
     a.group_R = R if group_R is None else group_R
     a.group_stride = group_stride
     a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
@@ -72,13 +91,17 @@ def lora_down(x, w_hi, w_lo, *, U=None, ext=None, group_R=None, group_stride=0, 
     L.check(lib.qfx_lora_down(C.byref(a), stream_ptr()), "qfx_lora_down")
 
 
-def lora_grad(V, X, G, g_sr, g_sc, *, r_valid=None, M=None, K=None, rows_per_batch=None, x_map=(0, 0), out_scale=1.0):
+def lora_grad(Vt, X, G, g_sr, g_sc, *, M, r_valid=None, group_R=None, K=None, rows_per_batch=None, x_map=(0, 0), out_scale=1.0):
+    """Vt = (Vt_hi, Vt_lo) bf16 [R, ld>=roundup(M,32)] ; G a tensor or a tuple of up to 3 tensors (fused targets)."""
     a = L.LoraGradArgs()
-    M = V.shape[0] if M is None else M
-    a.V, a.ldv, a.R = _p(V), V.stride(0), V.shape[1]
-    a.r_valid = V.shape[1] if r_valid is None else r_valid
+    Gs = G if isinstance(G, (tuple, list)) else (G,)
+    R = Vt[0].shape[0]
+    a.Vt_hi, a.Vt_lo, a.ldvt, a.R = _p(Vt[0]), _p(Vt[1]), Vt[0].stride(0), R
+    a.group_R = R // len(Gs) if group_R is None else group_R
+    a.r_valid = a.group_R if r_valid is None else r_valid
     a.X, a.ldx, a.M, a.K = _p(X), X.stride(0), M, (X.shape[1] if K is None else K)
-    a.G, a.g_sr, a.g_sc = _p(G), g_sr, g_sc
+    a.G = _p(Gs[0]); a.G1 = _p(Gs[1]) if len(Gs) > 1 else None; a.G2 = _p(Gs[2]) if len(Gs) > 2 else None
+    a.g_sr, a.g_sc = g_sr, g_sc
     a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
     a.x_batch_rows, a.x_row_off = x_map
     a.out_scale = out_scale

@@ -64,6 +64,35 @@ def test_gemm_plain(M, N, K):
     check(f"gemm_plain_{M}x{N}x{K}", out, ref, 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(2432, 3072, 3072), (2048, 3072, 128), (2000, 3080, 192), (4096, 2048, 64)])
+def test_gemm_large_tile_kernel(M, N, K):
+    """shapes that select the 256x128 / 3-stage kernel (>= 160 tiles); odd M/N edges, K = 1..3 stages."""
+    ops = _ops()
+    a = randn(M, K, seed=1).to(BF)
+    b = randn(N, K, seed=2, scale=0.1).to(BF)
+    bias = randn(N, seed=3).to(BF)
+    ref = rb(a.float() @ b.float().t() + bias.float())
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV))
+    check(f"gemm256_{M}x{N}x{K}", out, ref, 1e-2)
+
+
+def test_gemm_grouped_six_problems():
+    ops = _ops()
+    K, N = 256, 384
+    Ms = [300, 300, 300, 70, 70, 70]
+    items, refs = [], []
+    for i, M in enumerate(Ms):
+        a = randn(M, K, seed=10 + i).to(BF)
+        b = randn(N, K, seed=20 + i, scale=0.1).to(BF)
+        bias = randn(N, seed=30 + i).to(BF)
+        out = torch.zeros(M, N, dtype=BF, device=DEV)
+        items.append((a.to(DEV), b.to(DEV), out, dict(bias=bias.to(DEV))))
+        refs.append(rb(a.float() @ b.float().t() + bias.float()))
+    ops.gemm_grouped(items)
+    for i, (it, ref) in enumerate(zip(items, refs)):
+        check(f"gemm_grouped_{i}", it[2], ref, 1e-2)
+
+
 def test_gemm_transpose_detect():
     """A = I-like asymmetric check: catches swapped row/col in the MFMA C layout."""
     ops = _ops()
@@ -165,17 +194,71 @@ def test_lora_down_grouped_ext():
     assert e[:, :, 3 * Rp:].abs().max() == 0
 
 
-def test_lora_grad():
+def test_tr_read_lane_mapping():
+    """gfx950 ds_read_b64_tr_b16: result[lane i][j] = data[lane 16*(i>>4) + 4j + ((i&15)>>2)][i&3] (documents the HW)."""
+    from qflux_amd import _lib as L
+    src = torch.arange(256, dtype=torch.int16, device=DEV)
+    out = torch.empty_like(src)
+    L.check(L.lib.qfx_debug_tr_read(src.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream), "tr")
+    o = out.cpu().view(64, 4)
+    exp = torch.empty(64, 4, dtype=torch.int16)
+    for i in range(64):
+        for j in range(4):
+            lane = 16 * (i >> 4) + 4 * j + ((i & 15) >> 2)
+            exp[i, j] = lane * 4 + (i & 3)
+    assert torch.equal(o, exp), (o[:20], exp[:20])
+
+
+@pytest.mark.parametrize("M,K,R,r", [(300, 1024, 16, 12), (2432, 3072, 16, 16), (77, 64, 32, 32)])
+def test_lora_grad(M, K, R, r):
     ops = _ops()
-    M, K, R, r = 300, 1024, 16, 12
     V = randn(M, R, seed=1)
     X = randn(M, K, seed=2).to(BF)
+    Mp = (M + 127) // 128 * 128
+    hi, lo = _split(V)
+    Vt_hi = torch.zeros(R, Mp, dtype=BF); Vt_lo = torch.zeros(R, Mp, dtype=BF)
+    Vt_hi[:, :M], Vt_lo[:, :M] = hi.t(), lo.t()
+    Vt = (Vt_hi.to(DEV), Vt_lo.to(DEV))
+    ref = ((hi.float() + lo.float()).t() @ X.float())[:r]
     G = torch.zeros(r, K, dtype=torch.float32, device=DEV)
-    ops.lora_grad(V.to(DEV), X.to(DEV), G, K, 1, r_valid=r)
-    check("lora_grad_A", G, (V.t() @ X.float())[:r], 1e-4)
+    ops.lora_grad(Vt, X.to(DEV), G, K, 1, M=M, r_valid=r)
+    check(f"lora_grad_A_{M}", G, ref, 1e-4)
     Gt = torch.zeros(K, r, dtype=torch.float32, device=DEV)
-    ops.lora_grad(V.to(DEV), X.to(DEV), Gt, 1, r, r_valid=r)
-    check("lora_grad_Bt", Gt, (V.t() @ X.float())[:r].t(), 1e-4)
+    ops.lora_grad(Vt, X.to(DEV), Gt, 1, r, M=M, r_valid=r, out_scale=2.0)
+    check(f"lora_grad_Bt_{M}", Gt, 2.0 * ref.t(), 1e-4)
+
+
+def test_lora_grad_fused_three_targets_and_remap():
+    ops = _ops()
+    Bn, rpb, T, K, Rp, r = 2, 70, 10, 256, 16, 8
+    S = T + rpb
+    M = Bn * rpb
+    Mp = (M + 127) // 128 * 128
+    V = randn(M, 3 * Rp, seed=1)
+    Xj = randn(Bn * S, K, seed=2).to(BF)
+    X = Xj.view(Bn, S, K)[:, T:].reshape(M, K)
+    hi, lo = _split(V)
+    Vt_hi = torch.zeros(3 * Rp, Mp, dtype=BF); Vt_lo = torch.zeros(3 * Rp, Mp, dtype=BF)
+    Vt_hi[:, :M], Vt_lo[:, :M] = hi.t(), lo.t()
+    Gs = [torch.zeros(r, K, dtype=torch.float32, device=DEV) for _ in range(3)]
+    ops.lora_grad((Vt_hi.to(DEV), Vt_lo.to(DEV)), Xj.to(DEV), Gs, K, 1, M=M, r_valid=r, group_R=Rp, rows_per_batch=rpb, x_map=(S, T))
+    ref = (hi.float() + lo.float()).t() @ X.float()
+    for i in range(3):
+        check(f"lora_grad_fused_{i}", Gs[i], ref[i * Rp:i * Rp + r], 1e-4)
+
+
+def test_lora_down_transposed_output():
+    ops = _ops()
+    M, K, R = 100, 256, 32
+    x = randn(M, K, seed=1).to(BF)
+    w = randn(R, K, seed=2, scale=0.1)
+    hi, lo = _split(w)
+    Ut = (torch.zeros(R, 128, dtype=BF, device=DEV), torch.zeros(R, 128, dtype=BF, device=DEV))
+    U = torch.empty(M, R, dtype=torch.float32, device=DEV)
+    ops.lora_down(x.to(DEV), hi.to(DEV), lo.to(DEV), U=U, Ut=Ut)
+    rec = (Ut[0].float() + Ut[1].float()).cpu()
+    check("lora_down_Ut", rec[:, :M], U.cpu().t(), 1e-4)
+    assert rec[:, M:].abs().max() == 0
 
 
 def test_lora_pack():
