@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (see README/DESIGN for the field meanings).
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -48,6 +49,9 @@ def gemm_flops_of(prog):
         if isinstance(g, L.GemmArgs):
             tot += 2 * g.M * g.N * (g.K1 + g.K2)
             n += 1
+        elif isinstance(g, C.Array) and len(g) and isinstance(g[0], L.GemmArgs):
+            tot += sum(2 * x.M * x.N * (x.K1 + x.K2) for x in g)
+            n += 1
     return tot, n
 
 
@@ -60,7 +64,7 @@ def run_profiled(prog, fn_target):
         if fn is None:
             args()
             continue
-        if fn is fn_target:
+        if fn in fn_target:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st_obj)
             rc = fn(*args, st)
@@ -176,10 +180,11 @@ def main():
     # ---- dominant kernel (gemm_kernel): per-launch HIP-event timing on the launch stream, one extra replayed step
     plan = list(dit._plans.values())[0]
     dit.refresh_lora_operands()
-    ev = run_profiled(plan.fwd, L.lib.qfx_gemm_bf16)
+    gemm_fns = (L.lib.qfx_gemm_bf16, L.lib.qfx_gemm_grouped)
+    ev = run_profiled(plan.fwd, gemm_fns)
     loss2, dpred = None, None
     from qflux_amd import ops
-    ev += run_profiled(plan.bwd, L.lib.qfx_gemm_bf16)
+    ev += run_profiled(plan.bwd, gemm_fns)
     torch.cuda.synchronize()
     gemm_ms = sum(a.elapsed_time(b) for a, b in ev)
     gf_f, n_f = gemm_flops_of(plan.fwd)
@@ -203,7 +208,7 @@ def main():
                    "step_tflop_algorithmic": round((fwd_fl + bwd_fl) * B / 1e12, 2),
                    "whole_step_tflops_per_gpu": round((fwd_fl + bwd_fl) * B / (ms_per_step * 1e-3) / 1e12, 1),
                    "loss": float(loss.item())},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel (qfx_gemm_bf16, all epilogue variants)",
+        "roofline": {"bound": "mfma", "kernel": "gemm256_kernel / gemm_kernel (qfx_gemm_grouped + qfx_gemm_bf16, all epilogue variants)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                      "gemm_share_of_step": round(gemm_ms / ms_per_step, 3)},
