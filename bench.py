@@ -77,13 +77,14 @@ def run_profiled(prog, fn_target):
     return evs
 
 
-def cpu_baseline(cfg_dims, blocks=2, steps=2):
+def cpu_baseline(cfg_dims, blocks=1, steps=1):
     """The oracle (a CPU restatement of the reference's module graph, fp32 eager PyTorch) timed on this host's
-    cores: K=2 blocks + head/tail, forward+backward+AdamW on the LoRA params; extrapolated x(60/K)."""
+    cores on a BOUNDED sample: K=1 of the 60 blocks + head/tail at the full sequence length, one forward+backward+AdamW
+    step on the LoRA params (no warm-up: eager CPU has nothing to warm), extrapolated x(60/K)."""
     sys.path.insert(0, ROOT)
     from oracle import qwen_dit as O
     D_h, H, Jd, S_t, T = cfg_dims
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)   # eager CPU GEMMs stop scaling (and start thrashing) beyond ~64 threads
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     m = O.OracleQwenDiT(num_layers=blocks, attention_head_dim=D_h, num_attention_heads=H, joint_attention_dim=Jd)
@@ -93,14 +94,13 @@ def cpu_baseline(cfg_dims, blocks=2, steps=2):
                prompt_embeds=torch.randn(1, T, Jd) * 4, prompt_embeds_mask=torch.ones(1, T, dtype=torch.int64),
                img_shapes=[[(1, 32, 32), (1, 32, 32)]])
     times = []
-    for i in range(steps + 1):
+    for i in range(steps):
         t0 = time.time()
         loss = O.qwen_compute_loss(m, emb, torch.randn(1, S_t, 64), torch.rand(1), torch.float32)
         loss.backward()
         opt.step()
         opt.zero_grad()
-        if i > 0:
-            times.append(time.time() - t0)
+        times.append(time.time() - t0)
     per_step = sum(times) / len(times)
     full = per_step * (60.0 / blocks)
     return {"value": 1.0 / full, "unit": "images/s", "cores": cores, "kind": "port",
