@@ -85,6 +85,17 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return r;
 }
 
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs <= 0 here)
+
+__device__ __forceinline__ bf16x8 colfrag_at(const char* lds, int o1, int o2) {
+  const bf16x4 lo = *(const bf16x4*)(lds + o1);
+  const bf16x4 hi = *(const bf16x4*)(lds + o2);
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // =============================================================================================
@@ -119,6 +130,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
   const float c2 = a.scale * LOG2E;
   const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
 
+  // lane-constant LDS byte offsets of the fragment reads (tile/fragment index only adds an immediate)
+  int koff[KC], voff[4];
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) koff[kk] = li * (DH * 2) + (((kk * 4 + g) ^ swz_row<DH>(li)) << 4);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int sw = (li >> 1) & 7, c1 = 4 * t + (g >> 1);
+    voff[2 * t] = li * 128 + ((c1 ^ sw) << 4) + 8 * (g & 1);
+    voff[2 * t + 1] = li * 128 + (((c1 + 2) ^ sw) << 4) + 8 * (g & 1);
+  }
   const int ntiles = (S + 63) / 64;
   stage_rows<DH>(smem, Kb, a.ldk, 0, S, w, lane);
   stage_cols<DH>(smem + TB, Vtb, a.S_pad, 0, w, lane);
@@ -138,28 +159,44 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
       sacc[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sacc[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < KC; ++kk) {
-        const bf16x8 kfr = read_rowfrag<DH>(sK, kf, kk, g, li);
+        const bf16x8 kfr = *(const bf16x8*)(sK + koff[kk] + kf * (16 * DH * 2));
         sacc[kf][0] = MFMA(kfr, qf[0][kk], sacc[kf][0]);
         sacc[kf][1] = MFMA(kfr, qf[1][kk], sacc[kf][1]);
       }
     }
-    // scale, mask, online softmax (lane owns query column li of each q-fragment; keys 16kf+4g+r)
+    // online softmax in the log2 domain (lane owns query column li of each q-fragment; keys 16kf+4g+r).
+    // Masking work only where it can matter: the ragged last tile or an additive key mask.
+    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);   // wave-uniform
     float mx[2] = {-INFINITY, -INFINITY};
+    if (need_mask) {
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = j0 + kf * 16 + 4 * g + r;
-        const bool ok = key < S;
-        const float mk = (maskb && ok) ? maskb[key] * LOG2E : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const int key = j0 + kf * 16 + 4 * g + r;
+          const bool ok = key < S;
+          const float mk = (maskb && ok) ? maskb[key] * LOG2E : 0.f;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const float s = ok ? sacc[kf][f][r] * c2 + mk : -INFINITY;
-          sacc[kf][f][r] = s;
-          mx[f] = fmaxf(mx[f], s);
+          for (int f = 0; f < 2; ++f) {
+            const float sv = ok ? sacc[kf][f][r] * c2 + mk : -INFINITY;
+            sacc[kf][f][r] = sv;
+            mx[f] = fmaxf(mx[f], sv);
+          }
         }
-      }
+    } else {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const float sv = sacc[kf][f][r] * c2;
+            sacc[kf][f][r] = sv;
+            mx[f] = fmaxf(mx[f], sv);
+          }
+    }
     bf16x8 pb[2][2];
+    float alpha[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       float m = mx[f];
@@ -167,30 +204,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
       m = fmaxf(m, __shfl_xor(m, 32));
       const float mnew = fmaxf(mrow[f], m);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = exp2f(mrow[f] - msafe);
+      alpha[f] = fexp2(mrow[f] - msafe);
       mrow[f] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(sacc[kf][f][r] - msafe);
+          const float p = fexp2(sacc[kf][f][r] - msafe);
           sacc[kf][f][r] = p;
           ps += p;
         }
-      lrow[f] = lrow[f] * alpha + ps;
+      lrow[f] = lrow[f] * alpha[f] + ps;
+      pb[f][0] = pack8(sacc[0][f], sacc[1][f]);
+      pb[f][1] = pack8(sacc[2][f], sacc[3][f]);
+    }
+    // rescale O only when some running max of this wave moved (exact: alpha == 1 otherwise)
+    if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
 #pragma unroll
       for (int d = 0; d < DF; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[d][f][r] *= alpha;
-      pb[f][0] = pack8(sacc[0][f], sacc[1][f]);
-      pb[f][1] = pack8(sacc[2][f], sacc[3][f]);
+        for (int r = 0; r < 4; ++r) { oacc[d][0][r] *= alpha[0]; oacc[d][1][r] *= alpha[1]; }
     }
 #pragma unroll
     for (int d = 0; d < DF; ++d)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8 vfr = read_colfrag(sVt, d, t, g, li);
+        const bf16x4 lo = *(const bf16x4*)(sVt + voff[2 * t] + d * 2048);
+        const bf16x4 hi = *(const bf16x4*)(sVt + voff[2 * t + 1] + d * 2048);
+        bf16x8 vfr;
+        vfr[0] = lo[0]; vfr[1] = lo[1]; vfr[2] = lo[2]; vfr[3] = lo[3];
+        vfr[4] = hi[0]; vfr[5] = hi[1]; vfr[6] = hi[2]; vfr[7] = hi[3];
         oacc[d][0] = MFMA(vfr, pb[0][t], oacc[d][0]);
         oacc[d][1] = MFMA(vfr, pb[1][t], oacc[d][1]);
       }
@@ -280,12 +324,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
   const float c2 = a.scale * LOG2E;
   const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
 
+  // lane-constant LDS byte offsets of the fragment reads (tile/fragment index only adds an immediate)
+  int koff[KC], voff[4];
+#pragma unroll
+  for (int kk = 0; kk < KC; ++kk) koff[kk] = li * (DH * 2) + (((kk * 4 + g) ^ swz_row<DH>(li)) << 4);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int sw = (li >> 1) & 7, c1 = 4 * t + (g >> 1);
+    voff[2 * t] = li * 128 + ((c1 ^ sw) << 4) + 8 * (g & 1);
+    voff[2 * t + 1] = li * 128 + (((c1 + 2) ^ sw) << 4) + 8 * (g & 1);
+  }
   const int ntiles = (S + 63) / 64;
   for (int jt = 0; jt < ntiles; ++jt) {
     const int j0 = jt * 64;
     stage_rows<DH>(sK, Kb, a.ldk, j0, S, w, lane);
     stage_rows<DH>(sV, Vb, a.ldv, j0, S, w, lane);
     stage_cols<DH>(sKt, Ktb, a.S_pad, j0, w, lane);
+    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);   // wave-uniform
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -296,30 +351,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
         sa[k2][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sa[k2][1] = sa[k2][0]; da[k2][0] = sa[k2][0]; da[k2][1] = sa[k2][0];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          const bf16x8 kfr = read_rowfrag<DH>(sK, kf, kk, g, li);
-          const bf16x8 vfr = read_rowfrag<DH>(sV, kf, kk, g, li);
+          const bf16x8 kfr = *(const bf16x8*)(sK + koff[kk] + kf * (16 * DH * 2));
+          const bf16x8 vfr = *(const bf16x8*)(sV + koff[kk] + kf * (16 * DH * 2));
           sa[k2][0] = MFMA(kfr, qf[0][kk], sa[k2][0]);
           sa[k2][1] = MFMA(kfr, qf[1][kk], sa[k2][1]);
           da[k2][0] = MFMA(vfr, dof[0][kk], da[k2][0]);
           da[k2][1] = MFMA(vfr, dof[1][kk], da[k2][1]);
         }
+        if (need_mask) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = j0 + kf * 16 + 4 * g + r;
-          const bool ok = key < S;
-          const float mk = (maskb && ok) ? maskb[key] * LOG2E : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            const int key = j0 + kf * 16 + 4 * g + r;
+            const bool ok = key < S;
+            const float mk = (maskb && ok) ? maskb[key] * LOG2E : 0.f;
 #pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const float p = ok ? exp2f(sa[k2][f][r] * c2 + mk - lse[f]) : 0.f;
-            sa[k2][f][r] = ok ? p * (da[k2][f][r] - dsm[f]) : 0.f;
+            for (int f = 0; f < 2; ++f) {
+              const float p = ok ? fexp2(sa[k2][f][r] * c2 + mk - lse[f]) : 0.f;
+              sa[k2][f][r] = ok ? p * (da[k2][f][r] - dsm[f]) : 0.f;
+            }
           }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+              const float p = fexp2(sa[k2][f][r] * c2 - lse[f]);
+              sa[k2][f][r] = p * (da[k2][f][r] - dsm[f]);
+            }
         }
       }
       const bf16x8 ds0 = pack8(sa[0][0], sa[1][0]);
       const bf16x8 ds1 = pack8(sa[0][1], sa[1][1]);
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        const bf16x8 ktf = read_colfrag(sKt, d, t, g, li);
+        const bf16x8 ktf = colfrag_at(sKt + d * 2048, voff[2 * t], voff[2 * t + 1]);
         dq[d][0] = MFMA(ktf, ds0, dq[d][0]);
         dq[d][1] = MFMA(ktf, ds1, dq[d][1]);
       }
@@ -343,94 +408,176 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
 }
 
 // =============================================================================================
-// dK, dV: block = 64 keys (4 waves x 16), loop over 64-query tiles (Q, dO row tiles + Q^T, dO^T column tiles)
+// staging helpers for NW-wave blocks (64-row / 64-column tiles)
+template <int DH, int NW>
+__device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int64_t ld, int s0, int S, int w, int lane) {
+  constexpr int CPR = DH / 8, RPI = 64 / CPR, RPW = 64 / NW, NI = RPW / RPI;
+  static_assert(NI >= 1, "too many waves for this tile");
+  const int rr = lane / CPR, c = lane % CPR;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = w * RPW + i * RPI + rr;
+    int s = s0 + row; s = s < S ? s : S - 1;
+    const int sc = c ^ swz_row<DH>(row);
+    glds16(base + (int64_t)s * ld + sc * 8, lds + (w * RPW + i * RPI) * (DH * 2));
+  }
+}
+template <int DH, int NW>
+__device__ __forceinline__ void stage_cols_n(char* lds, const bf16_t* base, int64_t S_pad, int s0, int w, int lane) {
+  constexpr int RPW = DH / NW, NI = RPW / 8;
+  static_assert(NI >= 1, "too many waves for this tile");
+  const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = w * RPW + i * 8 + rr;
+    const int sc = c ^ ((row >> 1) & 7);
+    glds16(base + (int64_t)row * S_pad + s0 + sc * 8, lds + (w * RPW + i * 8) * 128);
+  }
+}
+
+__device__ __forceinline__ bf16x4 pack4(const f32x4& a) {
+  bf16x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (short)f2bf(a[i]);
+  return r;
+}
+__device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+// =============================================================================================
+// dK, dV: block = 256 keys (8 waves x 32), loop over 64-query tiles (Q, dO row tiles + Q^T, dO^T column tiles).
+// 32 keys per wave halves the LDS fragment traffic per MFMA versus 16; the 8 waves share every staged query
+// tile; K fragments live in registers, V fragments are re-read from a resident LDS copy of the block's V rows.
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const qfx_attn_args a) {
-  constexpr int KC = DH / 32, DF = DH / 16;
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_args a) {
+  constexpr int KC = DH / 32, DF = DH / 16, NW = 8;
   constexpr int TB = 64 * DH * 2;
-  __shared__ __attribute__((aligned(16))) char smem[4 * TB];
+  __shared__ __attribute__((aligned(16))) char smem[8 * TB];   // [Q | dO | Q^T | dO^T | V(4 tiles of 64 keys)]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int key0 = blockIdx.x * 64 + w * 16;
+  const int kb = blockIdx.x * 256;
+  const int key0 = kb + w * 32;
   const int S = a.S;
   const bf16_t* Qb = a.Q + (int64_t)b * S * a.ldq + h * DH;
   const bf16_t* dOb = a.dO + (int64_t)b * S * a.lddo + h * DH;
+  const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
   const bf16_t* Qtb = a.Qt + ((int64_t)b * a.H + h) * DH * a.S_pad;
   const bf16_t* dOtb = a.dOt + ((int64_t)b * a.H + h) * DH * a.S_pad;
   const float* lseb = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;
   const float* dsb = a.dsum + ((int64_t)b * a.H + h) * a.S_pad;
   char* sQ = smem; char* sdO = smem + TB; char* sQt = smem + 2 * TB; char* sdOt = smem + 3 * TB;
+  char* sV = smem + 4 * TB;
+  const char* myV = sV + (w >> 1) * TB;    // 64-key tile holding this wave's 32 keys (fragments (w&1)*2 + {0,1})
 
-  bf16x8 kf[KC], vf[KC];
-  int mykey = key0 + li;
-  const bool keyok = mykey < S;
-  mykey = keyok ? mykey : S - 1;
-  {
-    const bf16_t* kp = a.K + ((int64_t)b * S + mykey) * a.ldk + h * DH + 8 * g;
-    const bf16_t* vp = a.V + ((int64_t)b * S + mykey) * a.ldv + h * DH + 8 * g;
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk) { kf[kk] = *(const bf16x8*)(kp + kk * 32); vf[kk] = *(const bf16x8*)(vp + kk * 32); }
+  for (int i = 0; i < 4; ++i) stage_rows_n<DH, NW>(sV + i * TB, Vb, a.ldv, kb + 64 * i, S, w, lane);
+
+  bf16x8 kf[2][KC];
+  bool keyok[2];
+  int mykey[2];
+  float mk[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int k = key0 + f * 16 + li;
+    keyok[f] = k < S;
+    k = keyok[f] ? k : S - 1;
+    mykey[f] = k;
+    const bf16_t* kp = a.K + ((int64_t)b * S + k) * a.ldk + h * DH + 8 * g;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) kf[f][kk] = *(const bf16x8*)(kp + kk * 32);
+    mk[f] = (a.key_mask && keyok[f]) ? a.key_mask[(int64_t)b * S + k] * LOG2E : 0.f;
   }
-  const float mk = (a.key_mask && keyok) ? a.key_mask[(int64_t)b * S + mykey] * LOG2E : 0.f;
-  f32x4 dk[DF], dv[DF];
+  f32x4 dk[DF][2], dv[DF][2];
 #pragma unroll
-  for (int d = 0; d < DF; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = dk[d]; }
+  for (int d = 0; d < DF; ++d)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) { dk[d][f] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d][f] = dk[d][f]; }
   const float c2 = a.scale * LOG2E;
 
   const int ntiles = (S + 63) / 64;
   for (int it = 0; it < ntiles; ++it) {
     const int i0 = it * 64;
-    stage_rows<DH>(sQ, Qb, a.ldq, i0, S, w, lane);
-    stage_rows<DH>(sdO, dOb, a.lddo, i0, S, w, lane);
-    stage_cols<DH>(sQt, Qtb, a.S_pad, i0, w, lane);
-    stage_cols<DH>(sdOt, dOtb, a.S_pad, i0, w, lane);
+    stage_rows_n<DH, NW>(sQ, Qb, a.ldq, i0, S, w, lane);
+    stage_rows_n<DH, NW>(sdO, dOb, a.lddo, i0, S, w, lane);
+    stage_cols_n<DH, NW>(sQt, Qtb, a.S_pad, i0, w, lane);
+    stage_cols_n<DH, NW>(sdOt, dOtb, a.S_pad, i0, w, lane);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      f32x4 sa[2], da[2];
+      bf16x4 p4[2][2], d4[2][2];   // [key frag][q frag of this half]
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
         const int qfi = 2 * t + q2;
-        sa[q2] = (f32x4){0.f, 0.f, 0.f, 0.f}; da[q2] = sa[q2];
+        f32x4 sa[2], da[2];
+        sa[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; da[0] = sa[0]; da[1] = sa[0];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          sa[q2] = MFMA(read_rowfrag<DH>(sQ, qfi, kk, g, li), kf[kk], sa[q2]);     // D[i=q][j=key]
-          da[q2] = MFMA(read_rowfrag<DH>(sdO, qfi, kk, g, li), vf[kk], da[q2]);
-        }
-        const int qb = i0 + qfi * 16 + 4 * g;  // rows qb..qb+3 (multiple of 4, < S_pad)
-        const f32x4 l4 = *(const f32x4*)(lseb + qb);
-        const f32x4 d4 = *(const f32x4*)(dsb + qb);
+          const bf16x8 qa = read_rowfrag<DH>(sQ, qfi, kk, g, li);
+          const bf16x8 oa = read_rowfrag<DH>(sdO, qfi, kk, g, li);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = (qb + r) < S;
-          const float p = ok ? exp2f(sa[q2][r] * c2 + mk - l4[r]) : 0.f;
-          da[q2][r] = ok ? p * (da[q2][r] - d4[r]) : 0.f;
-          sa[q2][r] = p;
+          for (int f = 0; f < 2; ++f) {
+            sa[f] = MFMA(qa, kf[f][kk], sa[f]);                                             // D[i=q][j=key]
+            da[f] = MFMA(oa, read_rowfrag<DH>(myV, (w & 1) * 2 + f, kk, g, li), da[f]);
+          }
+        }
+        const int qb = i0 + qfi * 16 + 4 * g;
+        const f32x4 l4 = *(const f32x4*)(lseb + qb);
+        const f32x4 s4 = *(const f32x4*)(dsb + qb);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          if (i0 + 64 > S) {   // ragged last query tile (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = (qb + r) < S;
+              const float p = ok ? fexp2(sa[f][r] * c2 + mk[f] - l4[r]) : 0.f;
+              da[f][r] = ok ? p * (da[f][r] - s4[r]) : 0.f;
+              sa[f][r] = p;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = fexp2(sa[f][r] * c2 + mk[f] - l4[r]);
+              da[f][r] = p * (da[f][r] - s4[r]);
+              sa[f][r] = p;
+            }
+          }
+          p4[f][q2] = pack4(sa[f]);
+          d4[f][q2] = pack4(da[f]);
         }
       }
-      const bf16x8 pb = pack8(sa[0], sa[1]);
-      const bf16x8 dsbf = pack8(da[0], da[1]);
+      const bf16x8 pb0 = cat8(p4[0][0], p4[0][1]), pb1 = cat8(p4[1][0], p4[1][1]);
+      const bf16x8 ds0 = cat8(d4[0][0], d4[0][1]), ds1 = cat8(d4[1][0], d4[1][1]);
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        dv[d] = MFMA(read_colfrag(sdOt, d, t, g, li), pb, dv[d]);     // D[i=dv][j=key]
-        dk[d] = MFMA(read_colfrag(sQt, d, t, g, li), dsbf, dk[d]);
+        const bf16x8 ot = read_colfrag(sdOt, d, t, g, li);
+        const bf16x8 qt = read_colfrag(sQt, d, t, g, li);
+        dv[d][0] = MFMA(ot, pb0, dv[d][0]);     // D[i=dv][j=key]
+        dv[d][1] = MFMA(ot, pb1, dv[d][1]);
+        dk[d][0] = MFMA(qt, ds0, dk[d][0]);
+        dk[d][1] = MFMA(qt, ds1, dk[d][1]);
       }
     }
     __syncthreads();
   }
-  if (keyok) {
-    bf16_t* kp = a.dK + ((int64_t)b * S + mykey) * a.lddk + h * DH + 4 * g;
-    bf16_t* vp = a.dV + ((int64_t)b * S + mykey) * a.lddv + h * DH + 4 * g;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    if (!keyok[f]) continue;
+    bf16_t* kp = a.dK + ((int64_t)b * S + mykey[f]) * a.lddk + h * DH + 4 * g;
+    bf16_t* vp = a.dV + ((int64_t)b * S + mykey[f]) * a.lddv + h * DH + 4 * g;
 #pragma unroll
     for (int d = 0; d < DF; ++d) {
       u32x2 u;
-      u[0] = pack2bf(dk[d][0] * a.scale, dk[d][1] * a.scale);
-      u[1] = pack2bf(dk[d][2] * a.scale, dk[d][3] * a.scale);
+      u[0] = pack2bf(dk[d][f][0] * a.scale, dk[d][f][1] * a.scale);
+      u[1] = pack2bf(dk[d][f][2] * a.scale, dk[d][f][3] * a.scale);
       *(u32x2*)(kp + d * 16) = u;
-      u[0] = pack2bf(dv[d][0], dv[d][1]);
-      u[1] = pack2bf(dv[d][2], dv[d][3]);
+      u[0] = pack2bf(dv[d][f][0], dv[d][f][1]);
+      u[1] = pack2bf(dv[d][f][2], dv[d][f][3]);
       *(u32x2*)(vp + d * 16) = u;
     }
   }
@@ -485,9 +632,9 @@ extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
   if (rc) return rc;
   if (!a->Q || !a->Qt || !a->K || !a->V || !a->dO || !a->dOt || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
-  dim3 grid((a->S + 63) / 64, a->H, a->B);
-  if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  dim3 grid((a->S + 255) / 256, a->H, a->B);
+  if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(512), 0, (hipStream_t)stream, *a);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

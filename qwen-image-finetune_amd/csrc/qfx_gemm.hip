@@ -357,61 +357,91 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
     buf = buf + 1 == NSTAGE ? 0 : buf + 1;
   }
 
+  // ---- epilogue, stage 1: bf16(acc + bias) -- the nn.Linear output, first rounding point of every epilogue --
+  // goes to an LDS image of the C tile so that stage 2 can use full-row 16-byte global accesses
+  // (the MFMA layout would give 8-byte pieces scattered over 16 rows per store instruction).
+  constexpr int CROW = BN * 2 + 16;  // padded row stride (bytes)
   const bool bias_pending = (p.bias != nullptr) && (nt2 == 0);
+  __syncthreads();
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wr * 64 + mi * 16 + li;
-    if (m >= p.M) continue;
-    const int bidx = m / p.rows_per_batch;
-    const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+  for (int ni = 0; ni < 4; ++ni) {
+    const int nl = wc * 64 + ni * 16 + 4 * g;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias_pending && n0 + nl + 3 < p.N) {
+      const bf16x4 bb = *(const bf16x4*)(p.bias + n0 + nl);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
-      if (n + 3 >= p.N) continue;
-      float v[4];
+      for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
-      if (bias_pending) {
-        const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+    for (int mi = 0; mi < 4; ++mi) {
+      const int ml = wr * 64 + mi * 16 + li;
+      u32x2 u;
+      u[0] = pack2bf(acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]);
+      u[1] = pack2bf(acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]);
+      *(u32x2*)(smem + ml * CROW + nl * 2) = u;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: thread -> (row tid/16 + 32 i, 16-byte chunk tid%16); a wave covers 4 full 256-byte rows
+  const int ch = tid & 15;
+  const int n = n0 + ch * 8;
+  if (n + 7 < p.N) {
+    float gt[8];
+    int last_b = -1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bf2f((bf16_t)bb[r]);
-      }
-      bf16x4 o;
+    for (int i = 0; i < 8; ++i) {
+      const int ml = (tid >> 4) + 32 * i;
+      const int m = m0 + ml;
+      if (m >= p.M) continue;
+      const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+      const u32x4 yv = *(const u32x4*)(smem + ml * CROW + ch * 16);
+      float y[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { y[2 * q] = __uint_as_float(yv[q] << 16); y[2 * q + 1] = __uint_as_float(yv[q] & 0xffff0000u); }
       if constexpr (EPI == QFX_EPI_NONE) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(v[r]);
-        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+        *(u32x4*)(p.C + crow * p.ldc + n) = yv;
       } else if constexpr (EPI == QFX_EPI_GELU) {
-        bf16x4 o2;
+        u32x4 o2;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bf16_t h = f2bf(v[r]);
-          o[r] = (short)h;
-          o2[r] = (short)f2bf(gelu_tanh_f(bf2f(h)));
-        }
-        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
-        *(bf16x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+        for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
+        *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+        *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
       } else if constexpr (EPI == QFX_EPI_GATE_RES) {
-        const bf16x4 gt = *(const bf16x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
-        const bf16x4 rs = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+        const int bidx = m / p.rows_per_batch;
+        if (bidx != last_b) {
+          const u32x4 gv = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float y = rbf(v[r]);
-          const float gy = rbf(bf2f((bf16_t)gt[r]) * y);
-          o[r] = (short)f2bf(bf2f((bf16_t)rs[r]) + gy);
+          for (int q = 0; q < 4; ++q) { gt[2 * q] = __uint_as_float(gv[q] << 16); gt[2 * q + 1] = __uint_as_float(gv[q] & 0xffff0000u); }
+          last_b = bidx;
         }
-        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
-      } else {
-        const bf16x4 hx = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+        const u32x4 rv = *(const u32x4*)(p.aux + crow * p.ldaux + n);
+        u32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float y = rbf(v[r]);
-          o[r] = (short)f2bf(y * gelu_tanh_grad_f(bf2f((bf16_t)hx[r])));
+        for (int q = 0; q < 4; ++q) {
+          const float r0 = __uint_as_float(rv[q] << 16), r1 = __uint_as_float(rv[q] & 0xffff0000u);
+          o[q] = pack2bf(r0 + rbf(gt[2 * q] * y[2 * q]), r1 + rbf(gt[2 * q + 1] * y[2 * q + 1]));
         }
-        *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+        *(u32x4*)(p.C + crow * p.ldc + n) = o;
+      } else {  // QFX_EPI_DGELU
+        const u32x4 hv = *(const u32x4*)(p.aux + crow * p.ldaux + n);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float h0 = __uint_as_float(hv[q] << 16), h1 = __uint_as_float(hv[q] & 0xffff0000u);
+          o[q] = pack2bf(y[2 * q] * gelu_tanh_grad_f(h0), y[2 * q + 1] * gelu_tanh_grad_f(h1));
+        }
+        *(u32x4*)(p.C + crow * p.ldc + n) = o;
       }
     }
   }
+}
+
+bool ok256(const qfx_gemm_args* a) {
+  if ((a->N % 8) || (a->ldc % 8)) return false;
+  if (a->epi == QFX_EPI_GELU && (a->ldc2 % 8)) return false;
+  if ((a->epi == QFX_EPI_GATE_RES || a->epi == QFX_EPI_DGELU) && (a->ldaux % 8)) return false;
+  if (a->epi == QFX_EPI_GATE_RES && (a->gate_bstride % 8)) return false;
+  return true;
 }
 
 int validate(const qfx_gemm_args* a) {
@@ -437,6 +467,7 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
     const int rc = validate(&groups[i]);
     if (rc) return rc;
     if (groups[i].epi != groups[0].epi) return QFX_EINVAL;
+    if (!ok256(&groups[i])) return QFX_EINVAL;  /* 16-byte epilogue accesses */
     ga.g[i] = groups[i];
     ga.tile_start[i] = tiles;
     tiles += ((groups[i].M + BM2 - 1) / BM2) * ((groups[i].N + BN - 1) / BN);
@@ -460,7 +491,7 @@ extern "C" int qfx_gemm_bf16(const qfx_gemm_args* a, void* stream) {
   if (rc) return rc;
   // large problems: 256x128 tiles / 3-stage ring; small ones keep the 128x128 kernel (more tiles, 2 blocks per CU)
   const int tiles256 = ((a->M + BM2 - 1) / BM2) * ((a->N + BN - 1) / BN);
-  if (tiles256 >= 160) return qfx_gemm_grouped(a, 1, stream);
+  if (tiles256 >= 160 && ok256(a)) return qfx_gemm_grouped(a, 1, stream);
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   hipStream_t s = (hipStream_t)stream;
   switch (a->epi) {

@@ -280,6 +280,203 @@ __global__ __launch_bounds__(512, 1) void k256(const bf16_t* __restrict__ A, con
   }
 }
 
+// VAR 7: 4 waves (2x2), each 128x64 (8x4 fragments), ONE wave per SIMD, 512-register budget, everything interleaved
+__global__ __launch_bounds__(256, 1) void k256w4(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                 int M, int N, int K, int GM) {
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  int tm, tn;
+  if (GM <= 0) { tm = swz % tiles_m; tn = swz / tiles_m; }
+  else {
+    const int per = GM * tiles_n; const int grp_ = swz / per; const int first = grp_ * GM;
+    const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+    const int in = swz - grp_ * per;
+    tm = first + in % gsz; tn = in / gsz;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int srow = lane >> 3, schunk = lane & 7;
+  const bf16_t* pa[8]; const bf16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lr = w * 64 + i * 8 + srow;
+    int gm = m0 + lr; gm = gm < M ? gm : M - 1;
+    pa[i] = A + (int64_t)gm * K + (schunk ^ ((lr >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int lr = w * 32 + i * 8 + srow;
+    int gn = n0 + lr; gn = gn < N ? gn : N - 1;
+    pb[i] = B + (int64_t)gn * K + (schunk ^ ((lr >> 1) & 7)) * 8;
+  }
+  const int nt = K / BK;
+  auto stageA = [&](int t, int buf, int i) { glds16(pa[i] + t * BK, smem + buf * STAGE + (w * 64 + i * 8) * 128); };
+  auto stageB = [&](int t, int buf, int i) { glds16(pb[i] + t * BK, smem + buf * STAGE + BM * 128 + (w * 32 + i * 8) * 128); };
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto rdA = [&](const char* sA, int kk, int mi) {
+    const int row = wr * 128 + mi * 16 + li; const int chunk = kk * 4 + g;
+    return *(const bf16x8*)(sA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  };
+  auto rdB = [&](const char* sB, int kk, int ni) {
+    const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
+    return *(const bf16x8*)(sB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stageA(0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) stageB(0, 0, i);
+  if (nt > 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stageA(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stageB(1, 1, i);
+  }
+  int buf = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int nb = buf + 2; nb = nb >= NST ? nb - NST : nb;
+    const bool pre = t + 2 < nt;
+    const char* sA = smem + buf * STAGE; const char* sB = sA + BM * 128;
+    bf16x8 a0[8], b0[4], a1[8], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b0[i] = rdB(sB, 0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a0[i] = rdA(sA, 0, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+      a1[mi] = rdA(sA, 1, mi);
+      if (mi < 4) b1[mi] = rdB(sB, 1, mi);
+      if (pre) { stageA(t + 2, nb, mi); if (mi < 4) stageB(t + 2, nb, mi); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+    buf = buf + 1 == NST ? 0 : buf + 1;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wr * 128 + mi * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+      if (n + 3 >= N) continue;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(acc[mi][ni][r]);
+      *(bf16x4*)(C + (int64_t)m * N + n) = o;
+    }
+  }
+}
+
+// VAR 8: 256x256x64 tile, 4 waves (2x2) each 128x128 (8x8 fragments, 256 accumulator registers), one wave per SIMD,
+// 2-stage LDS-DMA (64 KiB per stage).  Less global->LDS fill per flop than 256x128.
+__global__ __launch_bounds__(256, 1) void k256sq(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                 int M, int N, int K, int GM) {
+  constexpr int BN2 = 256, ST2 = (BM + BN2) * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * ST2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN2 - 1) / BN2;
+  int tm, tn;
+  if (GM <= 0) { tm = swz % tiles_m; tn = swz / tiles_m; }
+  else {
+    const int per = GM * tiles_n; const int grp_ = swz / per; const int first = grp_ * GM;
+    const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+    const int in = swz - grp_ * per;
+    tm = first + in % gsz; tn = in / gsz;
+  }
+  const int m0 = tm * BM, n0 = tn * BN2;
+  const int srow = lane >> 3, schunk = lane & 7;
+  const bf16_t* pa[8]; const bf16_t* pb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lr = w * 64 + i * 8 + srow;
+    int gm = m0 + lr; gm = gm < M ? gm : M - 1;
+    int gn = n0 + lr; gn = gn < N ? gn : N - 1;
+    pa[i] = A + (int64_t)gm * K + (schunk ^ ((lr >> 1) & 7)) * 8;
+    pb[i] = B + (int64_t)gn * K + (schunk ^ ((lr >> 1) & 7)) * 8;
+  }
+  const int nt = K / BK;
+  auto stageA = [&](int t, int buf, int i) { glds16(pa[i] + t * BK, smem + buf * ST2 + (w * 64 + i * 8) * 128); };
+  auto stageB = [&](int t, int buf, int i) { glds16(pb[i] + t * BK, smem + buf * ST2 + BM * 128 + (w * 64 + i * 8) * 128); };
+  const int g = lane >> 4, li = lane & 15;
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto rdA = [&](const char* sA, int kk, int mi) {
+    const int row = wr * 128 + mi * 16 + li; const int chunk = kk * 4 + g;
+    return *(const bf16x8*)(sA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  };
+  auto rdB = [&](const char* sB, int kk, int ni) {
+    const int row = wc * 128 + ni * 16 + li; const int chunk = kk * 4 + g;
+    return *(const bf16x8*)(sB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { stageA(0, 0, i); stageB(0, 0, i); }
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool pre = t + 1 < nt;
+    const char* sA = smem + buf * ST2; const char* sB = sA + BM * 128;
+    bf16x8 a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { b0[i] = rdB(sB, 0, i); a0[i] = rdA(sA, 0, i); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+      a1[mi] = rdA(sA, 1, mi); b1[mi] = rdB(sB, 1, mi);
+      if (pre) { stageA(t + 1, buf ^ 1, mi); stageB(t + 1, buf ^ 1, mi); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wr * 128 + mi * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+      const int n = n0 + wc * 128 + ni * 16 + 4 * g;
+      if (n + 3 >= N) continue;
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(acc[mi][ni][r]);
+      *(bf16x4*)(C + (int64_t)m * N + n) = o;
+    }
+  }
+}
+
 extern "C" int lab_gemm(int var, const void* A, const void* B, void* C, int M, int N, int K, int GM, void* stream) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipStream_t s = (hipStream_t)stream;
@@ -292,6 +489,8 @@ extern "C" int lab_gemm(int var, const void* A, const void* B, void* C, int M, i
     case 4: hipLaunchKernelGGL(k256<4>, dim3(tiles), dim3(512), 0, s, a, b, c, M, N, K, GM); break;
     case 5: hipLaunchKernelGGL(k256<5>, dim3(tiles), dim3(512), 0, s, a, b, c, M, N, K, GM); break;
     case 6: hipLaunchKernelGGL(k256<6>, dim3(tiles), dim3(512), 0, s, a, b, c, M, N, K, GM); break;
+    case 7: hipLaunchKernelGGL(k256w4, dim3(tiles), dim3(256), 0, s, a, b, c, M, N, K, GM); break;
+    case 8: { const int t2 = ((M + BM - 1) / BM) * ((N + 255) / 256); hipLaunchKernelGGL(k256sq, dim3(t2), dim3(256), 0, s, a, b, c, M, N, K, GM); } break;
     default: return -1;
   }
   return (int)hipGetLastError();
