@@ -531,21 +531,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
         const f32x4 s4 = *(const f32x4*)(dsb + qb);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          if (i0 + 64 > S) {   // ragged last query tile (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const bool ok = (qb + r) < S;
-              const float p = ok ? fexp2(sa[f][r] * c2 + mk[f] - l4[r]) : 0.f;
-              da[f][r] = ok ? p * (da[f][r] - s4[r]) : 0.f;
-              sa[f][r] = p;
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = fexp2(sa[f][r] * c2 + mk[f] - l4[r]);
-              da[f][r] = p * (da[f][r] - s4[r]);
-              sa[f][r] = p;
-            }
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = (qb + r) < S;
+            const float p = ok ? fexp2(sa[f][r] * c2 + mk[f] - l4[r]) : 0.f;
+            da[f][r] = ok ? p * (da[f][r] - s4[r]) : 0.f;
+            sa[f][r] = p;
           }
           p4[f][q2] = pack4(sa[f]);
           d4[f][q2] = pack4(da[f]);

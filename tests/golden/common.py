@@ -13,6 +13,12 @@ TINY = dict(patch_size=2, in_channels=64, out_channels=16, num_layers=2, attenti
             num_attention_heads=4, joint_attention_dim=512, axes_dims_rope=(8, 28, 28))
 
 
+# tiny FLUX config = the reference's own test config (tests/src/models/test_flux_per_sample_rope.py:266-278), 2 single blocks
+FLUX_TINY = dict(patch_size=1, in_channels=64, out_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=64,
+                 num_attention_heads=2, joint_attention_dim=32, pooled_projection_dim=16, guidance_embeds=False,
+                 axes_dims_rope=(8, 28, 28))
+
+
 def det_uniform(shape, seed: int) -> torch.Tensor:
     """Deterministic U(-1,1) fp32 tensor: 24-bit integer hash of the flat index (exact in fp32)."""
     n = 1

@@ -50,7 +50,8 @@ def register_to_config(init):
         init(self, *a, **kw)
     return wrapper
 ''',
-    "diffusers/loaders/__init__.py": "class FromOriginalModelMixin: pass\nclass PeftAdapterMixin: pass\n",
+    "diffusers/loaders/__init__.py": "class FromOriginalModelMixin: pass\nclass PeftAdapterMixin: pass\nclass FluxTransformer2DLoadersMixin: pass\n",
+    "diffusers/models/_modeling_parallel.py": "class ContextParallelInput:\n    def __init__(self, **k): pass\nclass ContextParallelOutput:\n    def __init__(self, **k): pass\n",
     "diffusers/models/__init__.py": "",
     "diffusers/models/attention.py": '''
 import torch.nn as nn, torch.nn.functional as F
@@ -59,6 +60,10 @@ class GELU(nn.Module):
         super().__init__(); self.proj = nn.Linear(dim_in, dim_out, bias=bias); self.approximate = approximate
     def forward(self, x):
         return F.gelu(self.proj(x), approximate=self.approximate)
+class AttentionMixin: pass
+class AttentionModuleMixin:
+    fused_projections = False
+    def set_processor(self, processor): self.processor = processor
 class FeedForward(nn.Module):
     def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", bias=True):
         super().__init__()
@@ -71,7 +76,7 @@ class FeedForward(nn.Module):
 ''',
     "diffusers/models/attention_dispatch.py": '''
 import torch.nn.functional as F
-def dispatch_attention_fn(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, backend=None, **kw):
+def dispatch_attention_fn(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, backend=None, parallel_config=None, **kw):
     q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale)
     return o.permute(0, 2, 1, 3)
@@ -128,6 +133,47 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
     def forward(self, sample):
         return self.linear_2(self.act(self.linear_1(sample)))
+class PixArtAlphaTextProjection(nn.Module):
+    def __init__(self, in_features, hidden_size, out_features=None, act_fn="gelu_tanh"):
+        super().__init__(); out_features = out_features or hidden_size
+        self.linear_1 = nn.Linear(in_features, hidden_size); self.act_1 = nn.SiLU(); self.linear_2 = nn.Linear(hidden_size, out_features)
+    def forward(self, caption):
+        return self.linear_2(self.act_1(self.linear_1(caption)))
+class CombinedTimestepTextProjEmbeddings(nn.Module):
+    def __init__(self, embedding_dim, pooled_projection_dim):
+        super().__init__()
+        self.time_proj = Timesteps(num_channels=256, flip_sin_to_cos=True, downscale_freq_shift=0)
+        self.timestep_embedder = TimestepEmbedding(in_channels=256, time_embed_dim=embedding_dim)
+        self.text_embedder = PixArtAlphaTextProjection(pooled_projection_dim, embedding_dim, act_fn="silu")
+    def forward(self, timestep, pooled_projection):
+        timesteps_proj = self.time_proj(timestep)
+        timesteps_emb = self.timestep_embedder(timesteps_proj.to(dtype=pooled_projection.dtype))
+        return timesteps_emb + self.text_embedder(pooled_projection)
+class CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
+    def __init__(self, embedding_dim, pooled_projection_dim):
+        super().__init__()
+        self.time_proj = Timesteps(num_channels=256, flip_sin_to_cos=True, downscale_freq_shift=0)
+        self.timestep_embedder = TimestepEmbedding(in_channels=256, time_embed_dim=embedding_dim)
+        self.guidance_embedder = TimestepEmbedding(in_channels=256, time_embed_dim=embedding_dim)
+        self.text_embedder = PixArtAlphaTextProjection(pooled_projection_dim, embedding_dim, act_fn="silu")
+    def forward(self, timestep, guidance, pooled_projection):
+        timesteps_emb = self.timestep_embedder(self.time_proj(timestep).to(dtype=pooled_projection.dtype))
+        guidance_emb = self.guidance_embedder(self.time_proj(guidance).to(dtype=pooled_projection.dtype))
+        return (timesteps_emb + guidance_emb) + self.text_embedder(pooled_projection)
+def get_1d_rotary_pos_embed(dim, pos, theta=10000.0, use_real=False, linear_factor=1.0, ntk_factor=1.0, repeat_interleave_real=True, freqs_dtype=torch.float32):
+    theta = theta * ntk_factor
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=freqs_dtype, device=pos.device) / dim)) / linear_factor
+    freqs = torch.outer(pos, freqs)
+    assert use_real and repeat_interleave_real
+    return freqs.cos().repeat_interleave(2, dim=1, output_size=freqs.shape[1] * 2).float(), freqs.sin().repeat_interleave(2, dim=1, output_size=freqs.shape[1] * 2).float()
+def apply_rotary_emb(x, freqs_cis, use_real=True, use_real_unbind_dim=-1, sequence_dim=2):
+    cos, sin = freqs_cis
+    assert sequence_dim == 1
+    cos = cos[None, :, None, :]; sin = sin[None, :, None, :]
+    cos, sin = cos.to(x.device), sin.to(x.device)
+    x_real, x_imag = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rotated = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
+    return (x.float() * cos + x_rotated.float() * sin).to(x.dtype)
 ''',
     "diffusers/models/modeling_outputs.py": "class Transformer2DModelOutput:\n    def __init__(self, sample): self.sample = sample\n",
     "diffusers/models/modeling_utils.py": "import torch.nn as nn\nclass ModelMixin(nn.Module): pass\n",
@@ -143,6 +189,26 @@ class RMSNorm(nn.Module):
         if self.weight.dtype in [torch.float16, torch.bfloat16]:
             hidden_states = hidden_states.to(self.weight.dtype)
         return hidden_states * self.weight
+class AdaLayerNormZero(nn.Module):
+    def __init__(self, embedding_dim, num_embeddings=None, norm_type="layer_norm", bias=True):
+        super().__init__(); self.emb = None; self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, 6 * embedding_dim, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, elementwise_affine=False, eps=1e-6)
+    def forward(self, x, timestep=None, class_labels=None, hidden_dtype=None, emb=None):
+        emb = self.linear(self.silu(emb))
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa, shift_mlp, scale_mlp, gate_mlp
+class AdaLayerNormZeroSingle(nn.Module):
+    def __init__(self, embedding_dim, norm_type="layer_norm", bias=True):
+        super().__init__(); self.silu = nn.SiLU()
+        self.linear = nn.Linear(embedding_dim, 3 * embedding_dim, bias=bias)
+        self.norm = nn.LayerNorm(embedding_dim, elementwise_affine=False, eps=1e-6)
+    def forward(self, x, emb=None):
+        emb = self.linear(self.silu(emb))
+        shift_msa, scale_msa, gate_msa = emb.chunk(3, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa
 class AdaLayerNormContinuous(nn.Module):
     def __init__(self, embedding_dim, conditioning_embedding_dim, elementwise_affine=True, eps=1e-5, bias=True, norm_type="layer_norm"):
         super().__init__(); self.silu = nn.SiLU()
@@ -179,6 +245,10 @@ def import_reference_qwen():
         m.__path__ = [os.path.join(REF, "src", *name.split("."))]
         sys.modules[name] = m
     return importlib.import_module("qflux.models.transformer_qwenimage")
+
+
+def import_reference_flux():
+    return importlib.import_module("qflux.models.transformer_flux")
 
 
 sys.path.insert(0, HERE)
@@ -280,6 +350,48 @@ def main():
     save_file(step, os.path.join(HERE, "qwen_tiny_lora_step.safetensors"),
               metadata={"targets": repr(names), "r": "4", "lora_alpha": "8", "adapter": "lora_edit",
                         "pinned": "oracle-only (peft unavailable offline): parity unpinned for LoRA half"})
+    # ---------------- FLUX: reference transformer_flux.py vs oracle ----------------
+    from oracle import flux_dit as FO
+    from common import FLUX_TINY
+    reff = import_reference_flux()
+    for ge in (False, True):
+        cfg = dict(FLUX_TINY, guidance_embeds=ge)
+        fm = reff.FluxTransformer2DModel(**cfg).eval()
+        fill_weights(fm, seed=3)
+        fo = FO.OracleFluxDiT(**cfg)
+        fo.load_state_dict(fm.state_dict(), strict=True)
+        g = torch.Generator().manual_seed(21)
+        B, hh, ww, T = 2, 4, 6, 7
+        S_t = hh * ww
+        x = torch.randn(B, 2 * S_t, 64, generator=g)
+        pe = torch.randn(B, T, cfg["joint_attention_dim"], generator=g)
+        pooled = torch.randn(B, cfg["pooled_projection_dim"], generator=g)
+        tt = torch.tensor([0.7109, 0.1611])
+        gd = torch.ones(B) if ge else None
+        lat = FO.prepare_latent_image_ids(hh, ww)
+        ctl = lat.clone(); ctl[:, 0] = 1
+        img_ids = torch.cat([lat, ctl], 0)
+        txt_ids = torch.zeros(T, 3)
+        xr = x.clone().requires_grad_(True)
+        out = fm(hidden_states=xr, encoder_hidden_states=pe, pooled_projections=pooled, timestep=tt, img_ids=img_ids, txt_ids=txt_ids,
+                 guidance=gd, joint_attention_kwargs={}, return_dict=False)[0]
+        tgt = torch.randn(out.shape, generator=g)
+        lossr = ((out - tgt) ** 2).mean()
+        gxr, gwr = torch.autograd.grad(lossr, [xr, fm.single_transformer_blocks[0].attn.to_q.weight.requires_grad_(True)])
+        xo = x.clone().requires_grad_(True)
+        oo = fo(hidden_states=xo, encoder_hidden_states=pe, pooled_projections=pooled, timestep=tt, img_ids=img_ids, txt_ids=txt_ids,
+                guidance=gd)[0]
+        lo2 = ((oo - tgt) ** 2).mean()
+        gxo, gwo = torch.autograd.grad(lo2, [xo, fo.single_transformer_blocks[0].attn.to_q.weight])
+        print("flux(guidance=%s) oracle vs reference: fwd %.3e gx %.3e gw %.3e" % (ge, (oo - out).abs().max().item(),
+              (gxo - gxr).abs().max().item(), (gwo - gwr).abs().max().item()))
+        assert (oo - out).abs().max() < 1e-5 and (gxo - gxr).abs().max() < 1e-6
+        if ge:
+            save_file({"in.hidden_states": x, "in.encoder_hidden_states": pe, "in.pooled": pooled, "in.timestep": tt,
+                       "in.img_ids": img_ids, "in.txt_ids": txt_ids, "in.target": tgt, "out.sample": out.detach().contiguous(),
+                       "grad.hidden_states": gxr.contiguous(), "grad.single0_to_q_weight": gwr.contiguous(),
+                       "w.checksum": weight_checksum(fm)}, os.path.join(HERE, "flux_tiny_fwd.safetensors"),
+                      metadata={"cfg": repr(cfg), "weights": "common.fill_weights seed 3"})
     print("wrote golden vectors to", HERE)
 
 

@@ -86,3 +86,35 @@ def test_lora_step_vectors(golden_dir):
         else:
             assert not prm.requires_grad
     assert n == 2 * 4 * TINY["num_layers"]
+
+
+def test_flux_forward_and_grads_match_reference_vectors(golden_dir):
+    """FLUX oracle vs vectors captured from the reference's own transformer_flux.py (guidance_embeds=True)."""
+    from common import FLUX_TINY
+    from oracle import flux_dit as FO
+    t = load_file(os.path.join(golden_dir, "flux_tiny_fwd.safetensors"))
+    cfg = dict(FLUX_TINY, guidance_embeds=True)
+    m = FO.OracleFluxDiT(**cfg)
+    fill_weights(m, seed=3)
+    assert torch.equal(weight_checksum(m), t["w.checksum"])
+    x = t["in.hidden_states"].clone().requires_grad_(True)
+    out = m(hidden_states=x, encoder_hidden_states=t["in.encoder_hidden_states"], pooled_projections=t["in.pooled"],
+            timestep=t["in.timestep"], img_ids=t["in.img_ids"], txt_ids=t["in.txt_ids"], guidance=torch.ones(2))[0]
+    assert (out - t["out.sample"]).abs().max() < 1e-5
+    loss = ((out - t["in.target"]) ** 2).mean()
+    gx, gw = torch.autograd.grad(loss, [x, m.single_transformer_blocks[0].attn.to_q.weight])
+    assert (gx - t["grad.hidden_states"]).abs().max() < 1e-6
+    assert (gw - t["grad.single0_to_q_weight"]).abs().max() < 1e-6
+
+
+def test_flux_rope_identity_on_text_and_image_index():
+    from oracle import flux_dit as FO
+    lat = FO.prepare_latent_image_ids(3, 4)
+    ctl = lat.clone(); ctl[:, 0] = 1
+    ids = torch.cat([torch.zeros(5, 3), lat, ctl])
+    cos, sin = FO.flux_rope_tables(ids, (16, 56, 56))
+    assert cos.shape == (5 + 24, 128)
+    assert torch.all(cos[:5] == 1) and torch.all(sin[:5] == 0)          # text ids are zero: identity rotation
+    assert torch.equal(cos[5:17, 16:], cos[17:, 16:])                    # control image differs only on axis 0
+    assert not torch.equal(cos[5:17, :16], cos[17:, :16])
+    assert torch.equal(cos[:, 0::2], cos[:, 1::2])                       # repeat_interleave_real
