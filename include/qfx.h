@@ -60,6 +60,8 @@ typedef struct qfx_gemm_args {
   int32_t a_batch_rows; int32_t a_row_off;   /* applied to A1 rows; a_batch_rows==0 => identity */
   int32_t c_batch_rows; int32_t c_row_off;   /* applied to C/C2/aux rows; c_batch_rows==0 => identity */
   int32_t epi;
+  int32_t seg2_plain;              /* 1: the second K segment is an ordinary continuation of the contraction (FLUX single block:
+                                      [attn | mlp] @ W_out as two segments) -- no bf16 mid-rounding, bias added at the end */
 } qfx_gemm_args;
 
 int qfx_gemm_bf16(const qfx_gemm_args* args, void* stream);
@@ -155,7 +157,13 @@ int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const uint16_t* con
 /* ---- sinusoidal timestep projection (diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0, scale);
  * transformer_qwenimage.py:147,151-152,623-624): t is first rounded to bf16 (timestep.to(bf16)),
  * out[b] = bf16([cos(t*scale*f_i) | sin(t*scale*f_i)]), f_i = exp(-ln(1e4) * i / (dim/2)). */
-int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, uint16_t* out, void* stream);
+int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, float pre_scale, uint16_t* out, void* stream);
+/* pre_scale != 1: the value embedded is bf16(bf16(t) * pre_scale) (FLUX: `timestep.to(dtype) * 1000`, transformer_flux.py:729-730,
+ * with scale = 1); Qwen passes pre_scale = 1, scale = 1000. */
+
+/* out = bf16(bf16(a + b) + c)  (c may be NULL): sum of the time / guidance / pooled-text embeddings
+ * (diffusers CombinedTimestepGuidanceTextProjEmbeddings, transformer_flux.py:731-735) */
+int qfx_add3_bf16(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, void* stream);
 
 /* ---- QK RMSNorm + RoPE on the joint [text|image] qkv buffer ---------------------------------
  * qkv [B,S,3*H*dh] (q|k|v sections), in place on the q and k sections:
@@ -166,11 +174,13 @@ int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, uint
  */
 int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope,
                          const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,
-                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream);
+                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream);
+/* flags bit0: torch.nn.RMSNorm rounding (FLUX, transformer_flux.py:342-343: one rounding after x*rstd*w) instead of the
+ * diffusers RMSNorm double rounding (Qwen). */
 /* in place on the q,k sections of dqkv (v section untouched): un-rotate, RMSNorm backward. */
 int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope,
                          const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,
-                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream);
+                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream);
 
 /* ---- [B,S,H,dh] (row stride ld_in, column offset applied by caller) -> [B,H,dh,S_pad] with zero pad */
 int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_t B, int32_t S, int32_t S_pad,
@@ -208,7 +218,10 @@ int qfx_mse_loss_fwd_bwd(const uint16_t* pred, const uint16_t* target, float* lo
 /* ---- flow-matching input preparation (qwen_image_edit_trainer.py:811-812,841), bf16 eager rounding:
  * packed[b] = cat(bf16(bf16(bf16(1-sigma)*x0) + bf16(sigma*noise)), ctrl) ; target = bf16(noise - x0) */
 int qfx_flowmatch_prepare(const uint16_t* x0, const uint16_t* noise, const uint16_t* ctrl, const uint16_t* sigma,
-                          uint16_t* packed, uint16_t* target, int32_t B, int32_t S_t, int32_t S_c, int32_t C, void* stream);
+                          uint16_t* packed, uint16_t* target, int32_t B, int32_t S_t, int32_t S_c, int32_t C, int32_t mode,
+                          void* stream);
+/* mode 0 (Qwen): everything bf16 as documented above. mode 1 (FLUX, flux_kontext_trainer.py:522-525,567-568): x0 holds FP16
+ * bits (the cache dtype), packed = bf16(fp32(bf16(1-t))*x0 + fp32(bf16(t*noise))), target = bf16(noise - bf16(x0)). */
 
 /* ---- fused global-norm clip + AdamW over the flat LoRA parameter buffer ----------------------
  * (base_trainer.py:449-455 clip_grad_norm_ ; optimizer.step :531 with torch.optim.AdamW semantics) */

@@ -3,6 +3,7 @@
 // All bf16 traffic is 16 bytes per lane; one wave owns one row so reductions are shuffle-only.
 // Rounding points replicate the reference's bf16 eager graph (every torch op rounds its output).
 #include "qfx_common.h"
+#include <hip/hip_fp16.h>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            const float* __restrict__ rope,
                                                            const bf16_t* __restrict__ wq_txt, const bf16_t* __restrict__ wk_txt,
                                                            const bf16_t* __restrict__ wq_img, const bf16_t* __restrict__ wk_img,
-                                                           int B, int S, int T, int H, float eps) {
+                                                           int B, int S, int T, int H, float eps, int flags) {
   constexpr int LPI = DH / 8;        // lanes per (token, q|k, head) item
   constexpr int IPB = 256 / LPI;     // items per block
   const int sub = threadIdx.x % LPI;
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
     float o8[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float t0 = rbf(rbf(x[2 * j] * rstd) * w[2 * j]);
-      const float t1 = rbf(rbf(x[2 * j + 1] * rstd) * w[2 * j + 1]);
+      const float t0 = (flags & 1) ? rbf(x[2 * j] * rstd * w[2 * j]) : rbf(rbf(x[2 * j] * rstd) * w[2 * j]);
+      const float t1 = (flags & 1) ? rbf(x[2 * j + 1] * rstd * w[2 * j + 1]) : rbf(rbf(x[2 * j + 1] * rstd) * w[2 * j + 1]);
       const float c = cs[2 * j], sn = cs[2 * j + 1];
       o8[2 * j] = t0 * c - t1 * sn;
       o8[2 * j + 1] = t0 * sn + t1 * c;
@@ -324,8 +325,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
       const float c = cs[2 * j], sn = cs[2 * j + 1];
       const float d0 = rbf(dy[2 * j] * c + dy[2 * j + 1] * sn);     // dy * conj(f)
       const float d1 = rbf(-dy[2 * j] * sn + dy[2 * j + 1] * c);
-      dn[2 * j] = rbf(d0 * w[2 * j]);
-      dn[2 * j + 1] = rbf(d1 * w[2 * j + 1]);
+      dn[2 * j] = (flags & 1) ? d0 * w[2 * j] : rbf(d0 * w[2 * j]);
+      dn[2 * j + 1] = (flags & 1) ? d1 * w[2 * j + 1] : rbf(d1 * w[2 * j + 1]);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xh[i] = x[i] * rstd; dot += dn[i] * xh[i]; }
@@ -430,11 +431,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __restrict__ t, int B, int dim, float scale,
-                                                             bf16_t* __restrict__ out) {
+                                                             float pre_scale, bf16_t* __restrict__ out) {
   const int half = dim / 2;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * half; i += gridDim.x * blockDim.x) {
     const int b = i / half, j = i % half;
-    const float tv = rbf(t[b]);
+    const float tv = pre_scale != 1.0f ? rbf(rbf(t[b]) * pre_scale) : rbf(t[b]);
     const float f = expf(-9.210340371976184f * (float)j / (float)half);  // ln(10000)
     const float e = scale * (tv * f);
     out[b * dim + j] = f2bf(cosf(e));
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __rest
 __global__ __launch_bounds__(256) void flowmatch_prepare_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ noise,
                                                                 const bf16_t* __restrict__ ctrl, const bf16_t* __restrict__ sigma,
                                                                 bf16_t* __restrict__ packed, bf16_t* __restrict__ target,
-                                                                int B, int S_t, int S_c, int C) {
+                                                                int B, int S_t, int S_c, int C, int mode) {
   const int64_t total = (int64_t)B * (S_t + S_c) * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
@@ -453,33 +454,58 @@ __global__ __launch_bounds__(256) void flowmatch_prepare_kernel(const bf16_t* __
     const int s = (int)(r % (S_t + S_c)), b = (int)(r / (S_t + S_c));
     if (s < S_t) {
       const int64_t j = ((int64_t)b * S_t + s) * C + c;
-      const float sg = bf2f(sigma[b]), a = bf2f(x0[j]), n = bf2f(noise[j]);
-      packed[i] = f2bf(rbf(rbf(1.0f - sg) * a) + rbf(sg * n));
-      target[j] = f2bf(n - a);
+      const float sg = bf2f(sigma[b]), n = bf2f(noise[j]);
+      if (mode == 0) {
+        const float a = bf2f(x0[j]);
+        packed[i] = f2bf(rbf(rbf(1.0f - sg) * a) + rbf(sg * n));
+        target[j] = f2bf(n - a);
+      } else {   // x0 is fp16 (cache dtype): bf16 * fp16 promotes to fp32 in the reference
+        const float a = __half2float(__ushort_as_half(x0[j]));
+        packed[i] = f2bf(rbf(1.0f - sg) * a + rbf(sg * n));
+        target[j] = f2bf(n - rbf(a));
+      }
     } else {
       packed[i] = ctrl[((int64_t)b * S_c + (s - S_t)) * C + c];
     }
   }
 }
 
+__global__ __launch_bounds__(256) void add3_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                   const bf16_t* __restrict__ c, bf16_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = rbf(bf2f(a[i]) + bf2f(b[i]));
+    if (c) v = v + bf2f(c[i]);
+    out[i] = f2bf(v);
+  }
+}
+
 }  // namespace
 
-extern "C" int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, uint16_t* out, void* stream) {
+extern "C" int qfx_add3_bf16(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint16_t* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n <= 0) return QFX_EINVAL;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(add3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_timestep_embed(const float* t, int32_t B, int32_t dim, float scale, float pre_scale, uint16_t* out, void* stream) {
   if (!t || !out || B <= 0 || dim <= 0 || (dim % 2)) return QFX_EINVAL;
-  hipLaunchKernelGGL(timestep_embed_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, B, dim, scale, out);
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, B, dim, scale, pre_scale, out);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
 
 extern "C" int qfx_flowmatch_prepare(const uint16_t* x0, const uint16_t* noise, const uint16_t* ctrl, const uint16_t* sigma,
                                      uint16_t* packed, uint16_t* target, int32_t B, int32_t S_t, int32_t S_c, int32_t C,
-                                     void* stream) {
+                                     int32_t mode, void* stream) {
   if (!x0 || !noise || !sigma || !packed || !target || B <= 0 || S_t <= 0 || S_c < 0 || C <= 0 || (S_c > 0 && !ctrl)) return QFX_EINVAL;
   const int64_t total = (int64_t)B * (S_t + S_c) * C;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(flowmatch_prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x0, noise, ctrl, sigma, packed,
-                     target, B, S_t, S_c, C);
+                     target, B, S_t, S_c, C, mode);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
@@ -539,7 +565,7 @@ extern "C" int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const ui
 
 static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope, const uint16_t* wq_txt,
                      const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B, int32_t S,
-                     int32_t T, int32_t H, int32_t dh, float eps, void* stream) {
+                     int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream) {
   if (!qkv || !rope || !wq_txt || !wk_txt || !wq_img || !wk_img || B <= 0 || S <= 0 || T < 0 || T > S || H <= 0) return QFX_EINVAL;
   if (bwd && !saved) return QFX_EINVAL;
   const int64_t nitems = (int64_t)B * S * 2 * H;
@@ -547,13 +573,13 @@ static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope
   if (dh == 128) {
     const int ipb = 256 / 16;
     dim3 grid((unsigned)((nitems + ipb - 1) / ipb));
-    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<128, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
-    else hipLaunchKernelGGL((qk_norm_rope_kernel<128, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
+    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<128, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<128, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
   } else if (dh == 64) {
     const int ipb = 256 / 8;
     dim3 grid((unsigned)((nitems + ipb - 1) / ipb));
-    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<64, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
-    else hipLaunchKernelGGL((qk_norm_rope_kernel<64, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps);
+    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<64, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<64, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
   } else {
     return QFX_EUNSUPPORTED;
   }
@@ -563,13 +589,13 @@ static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope
 
 extern "C" int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope, const uint16_t* wq_txt,
                                     const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
-                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream) {
-  return launch_qk(false, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, stream);
+                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream) {
+  return launch_qk(false, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, stream);
 }
 extern "C" int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope, const uint16_t* wq_txt,
                                     const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
-                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, void* stream) {
-  return launch_qk(true, dqkv, (uint16_t*)saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, stream);
+                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream) {
+  return launch_qk(true, dqkv, (uint16_t*)saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, stream);
 }
 
 extern "C" int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_t B, int32_t S, int32_t S_pad,

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
     }
-    if (nt2 > 0 && t == nt1 - 1) {
+    if (nt2 > 0 && !p.seg2_plain && t == nt1 - 1) {
       // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
   }
 
   // ---- epilogue: lane holds C[m = ..+li][n = ..+4g+r], r=0..3
-  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0);
+  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0 || p.seg2_plain);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = m0 + wr * 64 + mi * 16 + li;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-    if (nt2 > 0 && t == nt1 - 1) {
+    if (nt2 > 0 && !p.seg2_plain && t == nt1 - 1) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + wc * 64 + ni * 16 + 4 * g;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
   // goes to an LDS image of the C tile so that stage 2 can use full-row 16-byte global accesses
   // (the MFMA layout would give 8-byte pieces scattered over 16 rows per store instruction).
   constexpr int CROW = BN * 2 + 16;  // padded row stride (bytes)
-  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0);
+  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0 || p.seg2_plain);
   __syncthreads();
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {

@@ -575,7 +575,7 @@ class _QwenPlan:
         rows, rpb, off = self.rows, self.rpb, self.off
         eps = 1e-6
         # head: timestep embedding -> temb ; img_in ; txt_norm + txt_in ; all modulation vectors in one GEMV launch
-        p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1000.0, _ptr(A["tproj"]))
+        p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1000.0, 1.0, _ptr(A["tproj"]))
         p.c(lib.qfx_mod_gemv, _ptr(A["tproj"]), B, 256, _ptr(P["t1_Wp"]), _ptr(P["t1_bp"]), 1, D, 0, _ptr(A["t1"]))
         p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
         p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
@@ -585,21 +585,35 @@ class _QwenPlan:
         p.c(lib.qfx_rmsnorm_fwd, _ptr(A["in_txt"]), _ptr(model.txt_norm.weight.data), _ptr(A["txt_n"]), rows["txt"], Jd, eps)
         self._gemm(p, A1=A["txt_n"], lda1=Jd, B1=P["txt_in"].W, K1=Jd, M=rows["txt"], N=D, C_=A["X"]["txt"][0], ldc=D,
                    bias=P["txt_in"].b)
-        scale = 1.0 / math.sqrt(dh)
         self.attn_args = []
-        STREAMS = (("img", 0), ("txt", 1))
         for i in range(Lyr):
-            w, bb = P["blocks"][i], A["blk"][i]
-            last = i == Lyr - 1
+            mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
+            self._emit_double_fwd(p, P["blocks"][i], A["blk"][i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
+                                  {s: (A["X"][s][i + 1], (0, 0)) for s in ("img", "txt")}, last=(i == Lyr - 1), norm_flags=0)
+        mo = A["mod_out"][0]  # [B, 2D]: scale | shift  (AdaLayerNormContinuous chunk order)
+        p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
+            rows["img"], D, rpb["img"], eps)
+        po = P["proj_out"]
+        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b)
+
+    def _emit_double_fwd(self, p, w, bb, mods, x_in, x_out, last, norm_flags):
+        """One double-stream block (reference: transformer_qwenimage.py:425-494; FLUX: transformer_flux.py:467-523).
+        x_in[s]: [rows_s, D] block input; x_out[s] = (tensor, c_map): where the block output goes (possibly a joint buffer)."""
+        A, B, D, S, H, dh, T = self.A, self.B, self.D, self.S, self.H, self.dh, self.T
+        S_pad = self.S_pad
+        rows, rpb, off = self.rows, self.rpb, self.off
+        eps = 1e-6
+        scale = 1.0 / math.sqrt(dh)
+        STREAMS = (("img", 0), ("txt", 1))
+        if True:
             qkv = bb["qkv"]
             q2 = qkv.view(B * S, 3 * D)
             ao2 = bb["ao"].view(B * S, D)
-            mods = {s: A["mods"][2 * i + sidx] for s, sidx in STREAMS}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
             # ---- LN1 + modulate, LoRA down-projections, then ONE grouped launch for the 6 q/k/v projections
             groups = []
             for s, sidx in STREAMS:
                 mod = mods[s]
-                x = A["X"][s][i]
+                x = x_in[s]
                 grp = w[s + ".qkv_lora"]
                 xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
                 p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 6 * D, _ptr(xm1), rows[s], D, rpb[s], eps)
@@ -618,7 +632,7 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_fwd, _ptr(qkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i),
-                B, S, T, H, dh, eps)
+                B, S, T, H, dh, eps, norm_flags)
             p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["VtA"]), B, S, S_pad, H, dh)
             a = L.AttnArgs()
             a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
@@ -645,7 +659,7 @@ class _QwenPlan:
                                rpb=rpb[s], x_map=(S, off[s]))
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
                 groups.append(self._gargs(A1=ao2, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=bb["x1"][s], ldc=D, bias=lw.b,
-                                          epi=L.EPI_GATE_RES, aux=A["X"][s][i], ldaux=D, gate=mods[s][:, 2 * D:3 * D], gate_bs=6 * D,
+                                          epi=L.EPI_GATE_RES, aux=x_in[s], ldaux=D, gate=mods[s][:, 2 * D:3 * D], gate_bs=6 * D,
                                           rpb=rpb[s], a_map=(S, off[s]), **kw))
             self._gemm_group(p, groups)
             groups = []
@@ -660,15 +674,10 @@ class _QwenPlan:
             groups = []
             for s, sidx in live:
                 f2 = w[s + ".fc2"]
-                groups.append(self._gargs(A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=A["X"][s][i + 1], ldc=D,
+                groups.append(self._gargs(A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
                                           bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
-                                          gate_bs=6 * D, rpb=rpb[s]))
+                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1]))
             self._gemm_group(p, groups)
-        mo = A["mod_out"][0]  # [B, 2D]: scale | shift  (AdaLayerNormContinuous chunk order)
-        p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
-            rows["img"], D, rpb["img"], eps)
-        po = P["proj_out"]
-        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b)
 
     # ------------------------------------------------------------------ backward program
     def _build_backward(self, P):
@@ -687,15 +696,28 @@ class _QwenPlan:
         cur = 0
         p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"]), _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, 0:D]), 2 * D, None,
             _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][cur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps)
+        for i in range(Lyr - 1, -1, -1):
+            nxt = cur ^ 1
+            mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}
+            gate_prev = None if i == 0 else {"img": A["mods"][2 * (i - 1)][:, 5 * D:6 * D], "txt": A["mods"][2 * (i - 1) + 1][:, 5 * D:6 * D]}
+            self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
+                                  dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
+                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0), norm_flags=0)
+            cur = nxt
+
+    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags):
+        """Backward of one double-stream block.  In: dx2[s] = d(block output), A["dyg2"][s] = gate2*dx2 (emitted by whoever
+        produced dx2).  Out: out_dx[s] = d(block input) and A["dyg2"][s] = gate_prev*out_dx (for the previous block)."""
+        A, B, D, S, H, dh, T = self.A, self.B, self.D, self.S, self.H, self.dh, self.T
+        S_pad = self.S_pad
+        rows, rpb, off = self.rows, self.rpb, self.off
+        eps = 1e-6
         dao2 = A["dao"].view(B * S, D)
         dq2 = A["dqkv"].view(B * S, 3 * D)
         STREAMS = (("img", 0), ("txt", 1))
-        for i in range(Lyr - 1, -1, -1):
-            w, bb = P["blocks"][i], A["blk"][i]
-            last = i == Lyr - 1
-            nxt = cur ^ 1
+        i = 0 if first else 1
+        if True:
             ao2 = bb["ao"].view(B * S, D)
-            mods = {s: A["mods"][2 * i + sidx] for s, sidx in STREAMS}
             live = [(s, sidx) for s, sidx in STREAMS if not (last and s == "txt")]
             if last:
                 # no gradient reaches the last block's text tail: d(attn out) of the text rows is zero
@@ -709,7 +731,7 @@ class _QwenPlan:
             for s, sidx in live:
                 mod = mods[s]
                 p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(bb["x1"][s]), _ptr(mod[:, 4 * D:5 * D]), 6 * D,
-                    _ptr(A["dX"][s][cur]), _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps)
+                    _ptr(dx2[s]), _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps)
                 # attention out-projection backward (+ LoRA)
                 lw = w[s + ".o"]
                 kw = {}
@@ -727,7 +749,6 @@ class _QwenPlan:
                                           c_map=(S, off[s]), **kw))
             self._gemm_group(p, groups)
             # ---- attention backward
-            a = self.attn_args[i]
             q2 = bb["qkv"].view(B * S, 3 * D)
             p.c(lib.qfx_transpose_heads, _ptr(dao2), D, _ptr(A["dOt"]), B, S, S_pad, H, dh)
             p.c(lib.qfx_transpose_heads, _ptr(q2[:, 0:]), 3 * D, _ptr(A["Qt"]), B, S, S_pad, H, dh)
@@ -737,7 +758,7 @@ class _QwenPlan:
             p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
-                _ptr(nk_i), B, S, T, H, dh, eps)
+                _ptr(nk_i), B, S, T, H, dh, eps, norm_flags)
             # ---- q/k/v projection backward (+ LoRA), both streams in one launch
             groups = []
             for s, sidx in STREAMS:
@@ -776,11 +797,11 @@ class _QwenPlan:
             if i > 0:
                 self._gemm_group(p, groups)
                 for s, sidx in STREAMS:
-                    modp = A["mods"][2 * (i - 1) + sidx]
                     dres = None if (last and s == "txt") else A["dx1"][s]
-                    p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(A["X"][s][i]), _ptr(mods[s][:, D:2 * D]), 6 * D, _ptr(dres),
-                        _ptr(modp[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"][s][nxt]), _ptr(A["dyg2"][s]), rows[s], D, rpb[s], eps)
-            cur = nxt
+                    gp = gate_prev[s] if gate_prev is not None else None
+                    p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(x_in[s]), _ptr(mods[s][:, D:2 * D]), 6 * D, _ptr(dres),
+                        _ptr(gp), (gp.stride(0) if gp is not None else 0), _ptr(out_dx[s]), _ptr(A["dyg2"][s] if gp is not None else None),
+                        rows[s], D, rpb[s], eps)
 
     # ------------------------------------------------------------------ execution
     def run_forward(self, hidden_states, encoder_hidden_states, timestep):

@@ -166,15 +166,22 @@ def mod_gemv(temb, weights, biases, apply_silu=True):
     return out
 
 
-def timestep_embed(t, dim=256, scale=1000.0):
+def timestep_embed(t, dim=256, scale=1000.0, pre_scale=1.0):
     out = torch.empty(t.shape[0], dim, dtype=BF, device=t.device)
-    L.check(lib.qfx_timestep_embed(_p(t.float().contiguous()), t.shape[0], dim, scale, _p(out), stream_ptr()), "qfx_timestep_embed")
+    L.check(lib.qfx_timestep_embed(_p(t.float().contiguous()), t.shape[0], dim, scale, pre_scale, _p(out), stream_ptr()),
+            "qfx_timestep_embed")
     return out
 
 
-def qk_norm_rope(qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps=1e-6, backward=False):
+def add3(a, b, c=None):
+    out = torch.empty_like(a)
+    L.check(lib.qfx_add3_bf16(_p(a), _p(b), _p(c), _p(out), a.numel(), stream_ptr()), "qfx_add3_bf16")
+    return out
+
+
+def qk_norm_rope(qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps=1e-6, backward=False, flags=0):
     fn = lib.qfx_qk_norm_rope_bwd if backward else lib.qfx_qk_norm_rope_fwd
-    L.check(fn(_p(qkv), _p(saved), _p(rope), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img), B, S, T, H, dh, eps, stream_ptr()),
+    L.check(fn(_p(qkv), _p(saved), _p(rope), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img), B, S, T, H, dh, eps, flags, stream_ptr()),
             "qfx_qk_norm_rope")
 
 
@@ -206,12 +213,12 @@ def mse_loss_fwd_bwd(pred, target, S_t, gscale=1.0, want_grad=True):
     return loss, dpred
 
 
-def flowmatch_prepare(x0, noise, ctrl, sigma):
+def flowmatch_prepare(x0, noise, ctrl, sigma, mode=0):
     B, S_t, Cc = x0.shape
     S_c = ctrl.shape[1] if ctrl is not None else 0
     packed = torch.empty(B, S_t + S_c, Cc, dtype=BF, device=x0.device)
     target = torch.empty_like(x0)
-    L.check(lib.qfx_flowmatch_prepare(_p(x0), _p(noise), _p(ctrl), _p(sigma), _p(packed), _p(target), B, S_t, S_c, Cc, stream_ptr()),
+    L.check(lib.qfx_flowmatch_prepare(_p(x0), _p(noise), _p(ctrl), _p(sigma), _p(packed), _p(target), B, S_t, S_c, Cc, mode, stream_ptr()),
             "qfx_flowmatch_prepare")
     return packed, target
 
