@@ -60,6 +60,7 @@ typedef struct qfx_gemm_args {
   int32_t a_batch_rows; int32_t a_row_off;   /* applied to A1 rows; a_batch_rows==0 => identity */
   int32_t c_batch_rows; int32_t c_row_off;   /* applied to C/C2/aux rows; c_batch_rows==0 => identity */
   int32_t epi;
+  int32_t aux_unmapped;            /* 1: aux rows are indexed by m (compact) even when C uses the c_* row remap */
   int32_t seg2_plain;              /* 1: the second K segment is an ordinary continuation of the contraction (FLUX single block:
                                       [attn | mlp] @ W_out as two segments) -- no bf16 mid-rounding, bias added at the end */
 } qfx_gemm_args;

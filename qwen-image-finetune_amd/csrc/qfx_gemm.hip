@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
         *(bf16x4*)(p.C2 + crow * p.ldc2 + n) = o2;
       } else if constexpr (EPI == QFX_EPI_GATE_RES) {
         const bf16x4 gt = *(const bf16x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
-        const bf16x4 rs = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+        const bf16x4 rs = *(const bf16x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = rbf(v[r]);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
         }
         *(bf16x4*)(p.C + crow * p.ldc + n) = o;
       } else {  // QFX_EPI_DGELU
-        const bf16x4 hx = *(const bf16x4*)(p.aux + crow * p.ldaux + n);
+        const bf16x4 hx = *(const bf16x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = rbf(v[r]);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
           for (int q = 0; q < 4; ++q) { gt[2 * q] = __uint_as_float(gv[q] << 16); gt[2 * q + 1] = __uint_as_float(gv[q] & 0xffff0000u); }
           last_b = bidx;
         }
-        const u32x4 rv = *(const u32x4*)(p.aux + crow * p.ldaux + n);
+        const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
         }
         *(u32x4*)(p.C + crow * p.ldc + n) = o;
       } else {  // QFX_EPI_DGELU
-        const u32x4 hv = *(const u32x4*)(p.aux + crow * p.ldaux + n);
+        const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

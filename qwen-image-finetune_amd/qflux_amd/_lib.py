@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
         ("rows_per_batch", C.c_int32),
         ("a_batch_rows", C.c_int32), ("a_row_off", C.c_int32),
         ("c_batch_rows", C.c_int32), ("c_row_off", C.c_int32),
-        ("epi", C.c_int32), ("seg2_plain", C.c_int32),
+        ("epi", C.c_int32), ("aux_unmapped", C.c_int32), ("seg2_plain", C.c_int32),
     ]
 
 

@@ -212,13 +212,11 @@ class QwenImageTransformer2DModel(nn.Module):
         cfg = adapter_config
         names = [n for n, m in self.named_modules() if isinstance(m, QfxLinear) and ".base_layer" not in n
                  and not n.endswith("base_layer") and match_target(n, cfg.target_modules)]
-        supported = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj", "attn.add_k_proj",
-                     "attn.add_v_proj", "attn.to_add_out")
         for n in names:
-            if not (n.startswith("transformer_blocks.") and n.endswith(supported)):
+            if not self._lora_supported(n):
                 raise NotImplementedError(
-                    f"LoRA target '{n}': round-1 fused path covers the attention projections of both streams "
-                    f"({', '.join(s.split('.', 1)[1] for s in supported)}); MLP / modulation / embedder targets are next (DESIGN.md)")
+                    f"LoRA target '{n}': round-1 fused path covers the attention projections (to_q/to_k/to_v/to_out.0/add_*_proj/"
+                    f"to_add_out); MLP / modulation / embedder targets are next (DESIGN.md)")
         for n in names:
             parent_name, _, child = n.rpartition(".")
             parent = self.get_submodule(parent_name)
@@ -234,6 +232,12 @@ class QwenImageTransformer2DModel(nn.Module):
             p.requires_grad_("lora" in pn)
         self._invalidate()
         return names
+
+    _LORA_SUFFIXES = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj", "attn.add_k_proj",
+                      "attn.add_v_proj", "attn.to_add_out")
+
+    def _lora_supported(self, name: str) -> bool:
+        return name.startswith("transformer_blocks.") and name.endswith(self._LORA_SUFFIXES)
 
     def set_adapter(self, adapter_name):
         self._adapter_name = adapter_name
@@ -304,45 +308,59 @@ class QwenImageTransformer2DModel(nn.Module):
         keep = []
         max_dim = 1
         for w, blk in zip(P["blocks"], self.transformer_blocks):
-            a = blk.attn
-            for s, names in (("img", ("to_q", "to_k", "to_v")), ("txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
-                mods = [getattr(a, n) for n in names]
-                lmods = [m for m in mods if isinstance(m, QfxLoraLinear)]
-                w[s + ".qkv_lora"] = None
-                if not lmods:
-                    continue
-                r = lmods[0].r[lmods[0].active_adapter]
-                Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
-                A_hi = torch.zeros(3 * Rp, D, dtype=BF, device=dev)
-                A_lo = torch.zeros_like(A_hi)
-                WeT = torch.zeros(D, 3 * Kext, dtype=BF, device=dev)
-                grp = dict(Rp=Rp, Kext=Kext, A_hi=A_hi, A_lo=A_lo, WeT=WeT, present=[isinstance(m, QfxLoraLinear) for m in mods])
-                w[s + ".qkv_lora"] = grp
-                for sec, (m, lw) in enumerate(zip(mods, w[s + ".qkv"])):
-                    if not isinstance(m, QfxLoraLinear):
-                        continue
-                    lo = self._make_lora(m, Rp, Kext, A_hi[sec * Rp:(sec + 1) * Rp], A_lo[sec * Rp:(sec + 1) * Rp],
-                                         WeT[:, sec * Kext:(sec + 1) * Kext], dev)
-                    lw.lora = lo
-                    descs.append(self._pack_desc(lo))
-                    max_dim = max(max_dim, lw.N, lw.K)
-            for key, m in (("img.o", a.to_out[0]), ("txt.o", a.to_add_out)):
-                if isinstance(m, QfxLoraLinear):
-                    r = m.r[m.active_adapter]
-                    Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
-                    lw = w[key]
-                    lo = self._make_lora(m, Rp, Kext, torch.zeros(Rp, lw.K, dtype=BF, device=dev),
-                                         torch.zeros(Rp, lw.K, dtype=BF, device=dev),
-                                         torch.zeros(lw.K, Kext, dtype=BF, device=dev), dev)
-                    lw.lora = lo
-                    descs.append(self._pack_desc(lo))
-                    max_dim = max(max_dim, lw.N, lw.K)
+            max_dim = max(max_dim, self._prep_double_lora(w, blk.attn, descs))
         prep = dict(n=len(descs), max_dim=max_dim, descs=None)
         if descs:
             arr = (L.LoraPackArgs * len(descs))(*descs)
             prep["descs"] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._lora_prep = prep
         return prep
+
+    def _prep_qkv_lora(self, w, prefix, mods, descs, WeT=None):
+        """LoRA operand buffers of a q/k/v projection group sharing one input: concatenated A_hi/A_lo [3Rp,D] (one fused
+        down-projection) and WeT [D, 3*Kext] (one K-extension of the dX GEMM).  WeT may be a column slice of a bigger B2."""
+        dev, D = self.device, self.inner_dim
+        lmods = [m for m in mods if isinstance(m, QfxLoraLinear)]
+        w[prefix + "qkv_lora"] = None
+        if not lmods:
+            return 1
+        r = lmods[0].r[lmods[0].active_adapter]
+        Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
+        A_hi = torch.zeros(3 * Rp, D, dtype=BF, device=dev)
+        A_lo = torch.zeros_like(A_hi)
+        if WeT is None:
+            WeT = torch.zeros(D, 3 * Kext, dtype=BF, device=dev)
+        else:
+            WeT = WeT(Kext)
+        w[prefix + "qkv_lora"] = dict(Rp=Rp, Kext=Kext, A_hi=A_hi, A_lo=A_lo, WeT=WeT, present=[isinstance(m, QfxLoraLinear) for m in mods])
+        md = 1
+        for sec, (m, lw) in enumerate(zip(mods, w[prefix + "qkv"])):
+            if not isinstance(m, QfxLoraLinear):
+                continue
+            lo = self._make_lora(m, Rp, Kext, A_hi[sec * Rp:(sec + 1) * Rp], A_lo[sec * Rp:(sec + 1) * Rp],
+                                 WeT[:, sec * Kext:(sec + 1) * Kext], dev)
+            lw.lora = lo
+            descs.append(self._pack_desc(lo))
+            md = max(md, lw.N, lw.K)
+        return md
+
+    def _prep_double_lora(self, w, a, descs):
+        dev = self.device
+        md = 1
+        for s, names in (("img", ("to_q", "to_k", "to_v")), ("txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
+            md = max(md, self._prep_qkv_lora(w, s + ".", [getattr(a, n) for n in names], descs))
+        for key, m in (("img.o", a.to_out[0]), ("txt.o", a.to_add_out)):
+            if isinstance(m, QfxLoraLinear):
+                r = m.r[m.active_adapter]
+                Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
+                lw = w[key]
+                lo = self._make_lora(m, Rp, Kext, torch.zeros(Rp, lw.K, dtype=BF, device=dev),
+                                     torch.zeros(Rp, lw.K, dtype=BF, device=dev),
+                                     torch.zeros(lw.K, Kext, dtype=BF, device=dev), dev)
+                lw.lora = lo
+                descs.append(self._pack_desc(lo))
+                md = max(md, lw.N, lw.K)
+        return md
 
     def _make_lora(self, m: QfxLoraLinear, Rp, Kext, A_hi, A_lo, WeT, dev):
         lo = _LoraW()
@@ -409,61 +427,78 @@ class QwenImageTransformer2DModel(nn.Module):
 class _QwenPlan:
     """Launch programs (forward, backward) + persistent arena for one shape signature."""
 
-    def __init__(self, model: QwenImageTransformer2DModel, B: int, S_i: int, T: int, shapes):
+    def __init__(self, model, B: int, S_i: int, T: int, shapes):
+        self._setup(model, B, S_i, T)
+        cfg = model.config
+        D, S = self.D, self.S
+        buf = self.buf
+        rows = self.rows
+        Lyr = cfg.num_layers
+        Cin, Cout, Jd = cfg.in_channels, model.proj_out.out_features, cfg.joint_attention_dim
+        P = model._prepared
+        self.rope = qwen_joint_rope(shapes, T, cfg.axes_dims_rope).to(model.device)
+        assert self.rope.shape == (S, self.dh // 2, 2)
+        A = self.A
+        A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, Jd); A["t"] = buf(B, dtype=F32)
+        A["tproj"] = buf(B, 256); A["t1"] = buf(1, B, D); A["temb"] = buf(1, B, D)
+        A["txt_n"] = buf(B * T, Jd)
+        A["X"] = {s: [buf(rows[s], D) for _ in range(Lyr + 1)] for s in ("img", "txt")}
+        A["mods"] = buf(2 * Lyr, B, 6 * D); A["mod_out"] = buf(1, B, 2 * D)
+        A["xn_out"] = buf(B * S_i, D); A["out"] = buf(B * S_i, Cout)
+        A["dpred"] = buf(B * S_i, Cout); A["dxn"] = buf(B * S_i, D)
+        A["blk"] = [self._alloc_double_block(w) for w in P["blocks"]]
+        self._alloc_double_scratch(P["blocks"])
+        self.fwd = _Prog()
+        self.bwd = _Prog()
+        self._build_forward(P)
+        self._build_backward(P)
+
+    def _setup(self, model, B, S_i, T):
         self.model = model
         cfg = model.config
         dev = model.device
         self.B, self.S_i, self.T = B, S_i, T
-        H, dh = cfg.num_attention_heads, cfg.attention_head_dim
-        D = H * dh
-        S = T + S_i
-        S_pad = _ceil(S, 64)
-        Lyr = cfg.num_layers
-        Cin, Cout, Jd = cfg.in_channels, model.proj_out.out_features, cfg.joint_attention_dim
-        P = model._prepared
-        self.D, self.S, self.H, self.dh = D, S, H, dh
+        self.H, self.dh = cfg.num_attention_heads, cfg.attention_head_dim
+        self.D = self.H * self.dh
+        self.S = T + S_i
+        self.S_pad = _ceil(self.S, 64)
         if B > 8:
             raise NotImplementedError("per-GPU batch > 8 (modulation GEMV holds <= 8 rows in LDS)")
 
         def buf(*shape, dtype=BF, zero=False):
             return (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=dev)
 
-        rows = {"img": B * S_i, "txt": B * T}
-        rpb = {"img": S_i, "txt": T}
-        off = {"img": T, "txt": 0}
-        self.rope = qwen_joint_rope(shapes, T, cfg.axes_dims_rope).to(dev)
-        assert self.rope.shape == (S, dh // 2, 2)
+        self.buf = buf
+        self.rows = {"img": B * S_i, "txt": B * T}
+        self.rpb = {"img": S_i, "txt": T}
+        self.off = {"img": T, "txt": 0}
+        self.A = {}
 
-        # ---- arena
-        A = {}
-        A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, Jd); A["t"] = buf(B, dtype=F32)
-        A["tproj"] = buf(B, 256); A["t1"] = buf(1, B, D); A["temb"] = buf(1, B, D)
-        A["txt_n"] = buf(B * T, Jd)
-        A["X"] = {s: [buf(rows[s], D) for _ in range(Lyr + 1)] for s in ("img", "txt")}
-        A["mods"] = buf(2 * Lyr, B, 6 * D); A["mod_out"] = buf(1, B, 2 * D)
+    def _alloc_double_block(self, w):
+        """Per-block saved activations of a double-stream block."""
+        buf, rows, B, S, D, H, S_pad = self.buf, self.rows, self.B, self.S, self.D, self.H, self.S_pad
+        b = dict(qkv=buf(B, S, 3 * D), sqk=buf(B, S, 2 * D), ao=buf(B, S, D), lse=buf(B, H, S_pad, dtype=F32, zero=True),
+                 x1={s: buf(rows[s], D) for s in ("img", "txt")}, h={s: buf(rows[s], 4 * D) for s in ("img", "txt")})
+        for s in ("img", "txt"):
+            grp = w[s + ".qkv_lora"]
+            mp = _ceil(rows[s], 128)
+            if grp is not None:
+                b["xm1." + s] = buf(rows[s], D)
+                b["Uqkv." + s] = (buf(3 * grp["Rp"], mp, zero=True), buf(3 * grp["Rp"], mp, zero=True))   # u^T hi/lo
+            if w[s + ".o"].lora is not None:
+                rp_o = w[s + ".o"].lora.Rp
+                b["Uo." + s] = (buf(rp_o, mp, zero=True), buf(rp_o, mp, zero=True))
+        return b
+
+    def _alloc_double_scratch(self, blocks):
+        """Scratch shared by all double-stream blocks (forward + backward)."""
+        buf, rows, B, S, D, H, dh, S_pad, A = self.buf, self.rows, self.B, self.S, self.D, self.H, self.dh, self.S_pad, self.A
         A["xm"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["g"] = {s: buf(rows[s], 4 * D) for s in ("img", "txt")}
         A["VtA"] = buf(B, H, dh, S_pad)
-        A["xn_out"] = buf(B * S_i, D); A["out"] = buf(B * S_i, Cout)
-        A["blk"] = []
-        for i in range(Lyr):
-            w = P["blocks"][i]
-            b = dict(qkv=buf(B, S, 3 * D), sqk=buf(B, S, 2 * D), ao=buf(B, S, D), lse=buf(B, H, S_pad, dtype=F32, zero=True),
-                     x1={s: buf(rows[s], D) for s in ("img", "txt")}, h={s: buf(rows[s], 4 * D) for s in ("img", "txt")})
-            for s in ("img", "txt"):
-                grp = w[s + ".qkv_lora"]
-                mp = _ceil(rows[s], 128)
-                if grp is not None:
-                    b["xm1." + s] = buf(rows[s], D)
-                    b["Uqkv." + s] = (buf(3 * grp["Rp"], mp, zero=True), buf(3 * grp["Rp"], mp, zero=True))   # u^T hi/lo
-                if w[s + ".o"].lora is not None:
-                    rp_o = w[s + ".o"].lora.Rp
-                    b["Uo." + s] = (buf(rp_o, mp, zero=True), buf(rp_o, mp, zero=True))
-            A["blk"].append(b)
-        # LoRA scratch (pad columns stay zero forever)
         kext_max = 0
         rp_max = 0
-        for w in P["blocks"]:
+        for w in blocks:   # LoRA scratch (pad columns stay zero forever)
             for s in ("img", "txt"):
                 if w[s + ".qkv_lora"] is not None:
                     kext_max = max(kext_max, w[s + ".qkv_lora"]["Kext"]); rp_max = max(rp_max, w[s + ".qkv_lora"]["Rp"])
@@ -475,9 +510,6 @@ class _QwenPlan:
             A["ext1"] = {s: buf(rows[s], kext_max, zero=True) for s in ("img", "txt")}
             A["Vt"] = {s: (buf(3 * rp_max, _ceil(rows[s], 128), zero=True), buf(3 * rp_max, _ceil(rows[s], 128), zero=True))
                        for s in ("img", "txt")}   # v^T hi/lo scratch (pad columns stay zero)
-        # backward scratch
-        A["dpred"] = buf(B * S_i, Cout)
-        A["dxn"] = buf(B * S_i, D)
         A["dX"] = {s: [buf(rows[s], D), buf(rows[s], D)] for s in ("img", "txt")}
         A["dyg2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["dyg1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
@@ -488,18 +520,12 @@ class _QwenPlan:
         A["dOt"] = buf(B, H, dh, S_pad); A["Qt"] = buf(B, H, dh, S_pad); A["Kt"] = buf(B, H, dh, S_pad)
         A["dsum"] = buf(B, H, S_pad, dtype=F32, zero=True)
         A["dqkv"] = buf(B, S, 3 * D)
-        self.A = A
-        self.rows, self.rpb, self.off = rows, rpb, off
-        self.S_pad = S_pad
-        self.fwd = _Prog()
-        self.bwd = _Prog()
-        self._build_forward(P)
-        self._build_backward(P)
 
     # ------------------------------------------------------------------ emit helpers
     @staticmethod
     def _gargs(*, A1, lda1, B1, K1, M, N, C_, ldc, ldb1=None, bias=None, A2=None, lda2=0, B2=None, ldb2=0, K2=0,
-               epi=L.EPI_NONE, C2=None, ldc2=0, aux=None, ldaux=0, gate=None, gate_bs=0, rpb=None, a_map=(0, 0), c_map=(0, 0)):
+               epi=L.EPI_NONE, C2=None, ldc2=0, aux=None, ldaux=0, gate=None, gate_bs=0, rpb=None, a_map=(0, 0), c_map=(0, 0),
+               seg2_plain=0, aux_unmapped=0):
         g = L.GemmArgs()
         g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _ptr(A1), _ptr(B1), lda1, (K1 if ldb1 is None else ldb1), K1
         if K2:
@@ -514,6 +540,8 @@ class _QwenPlan:
         g.a_batch_rows, g.a_row_off = a_map
         g.c_batch_rows, g.c_row_off = c_map
         g.epi = epi
+        g.seg2_plain = seg2_plain
+        g.aux_unmapped = aux_unmapped
         return g
 
     def _gemm(self, prog, **kw):
@@ -676,7 +704,7 @@ class _QwenPlan:
                 f2 = w[s + ".fc2"]
                 groups.append(self._gargs(A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
                                           bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
-                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1]))
+                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1))
             self._gemm_group(p, groups)
 
     # ------------------------------------------------------------------ backward program

@@ -217,7 +217,7 @@ def flowmatch_prepare(x0, noise, ctrl, sigma, mode=0):
     B, S_t, Cc = x0.shape
     S_c = ctrl.shape[1] if ctrl is not None else 0
     packed = torch.empty(B, S_t + S_c, Cc, dtype=BF, device=x0.device)
-    target = torch.empty_like(x0)
+    target = torch.empty(x0.shape, dtype=BF, device=x0.device)   # x0 may hold fp16 bits (mode 1); outputs are always bf16
     L.check(lib.qfx_flowmatch_prepare(_p(x0), _p(noise), _p(ctrl), _p(sigma), _p(packed), _p(target), B, S_t, S_c, Cc, mode, stream_ptr()),
             "qfx_flowmatch_prepare")
     return packed, target

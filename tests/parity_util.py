@@ -101,3 +101,75 @@ def run_tiny_step_parity(device="cuda:0", verbose=False, cfg=None, shapes=((1, 4
     if verbose:
         print(res)
     return res
+
+
+def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=7, B=2, r=4, guidance=True, fused=True,
+                         targets=("to_k", "to_q", "to_v", "to_out.0")):
+    """FLUX-Kontext LoRA step: HIP path vs the bf16 oracle (1 target + 1 control image of the same size)."""
+    from common import FLUX_TINY, fill_weights
+    from oracle import flux_dit as FO
+    from oracle import qwen_dit as O
+    from qflux_amd.models import FluxTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import FluxKontextTrainStep
+
+    cfg = dict(FLUX_TINY if cfg is None else cfg)
+    cfg["guidance_embeds"] = guidance
+    if cfg["joint_attention_dim"] % 64:
+        cfg["joint_attention_dim"] = 64      # the GEMM contracts in 64-wide K tiles
+    oracle = FO.OracleFluxDiT(**cfg)
+    O.add_lora(oracle, r=r, lora_alpha=2 * r, adapter_name="lora_edit", target_modules=targets)
+    fill_weights(oracle, seed=5)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    with torch.device(device):
+        hip = FluxTransformer2DModel(**cfg)
+    hip.add_adapter(LoraConfig(r=r, lora_alpha=2 * r, target_modules=list(targets)), "lora_edit")
+    missing, unexpected = hip.load_state_dict(oracle.state_dict(), strict=True)
+    assert not missing and not unexpected
+    g = torch.Generator().manual_seed(31)
+    h, w = hw
+    S_t = h * w
+    ctl_ids = FO.prepare_latent_image_ids(h, w)
+    ctl_ids[:, 0] = 1
+    emb = dict(image_latents=torch.randn(B, S_t, 64, generator=g).half(), control_latents=torch.randn(B, S_t, 64, generator=g).half(),
+               control_ids=ctl_ids, text_ids=torch.zeros(T, 3), latent_hw=(h, w),
+               pooled_prompt_embeds=torch.randn(B, cfg["pooled_projection_dim"], generator=g).half(),
+               prompt_embeds=torch.randn(B, T, cfg["joint_attention_dim"], generator=g).half())
+    noise = torch.randn(B, S_t, 64, generator=g).to(BF)
+    t = torch.tensor([0.7109, 0.1611, 0.43, 0.9][:B]).to(BF)
+    emb_o = dict(emb, control_latents=emb["control_latents"].to(BF))
+    loss_o, pred_o = FO.flux_compute_loss(oracle, emb_o, noise, t, BF, return_pred=True)
+    loss_o.float().backward()
+    step = FluxKontextTrainStep(hip)
+    res = {}
+    if fused:
+        loss_h = step.forward_backward(emb, noise=noise, t=t)
+        plan = list(hip._plans.values())[0]
+        pred_h = plan.A["out"].view(B, -1, plan.A["out"].shape[-1])[:, :S_t]
+        res["pred_rel"] = relmax(pred_h, pred_o)
+    else:
+        loss_h = step.compute_loss(emb, noise=noise, t=t)
+        plan = list(hip._plans.values())[0]
+        res["pred_rel"] = relmax(plan.A["out"].view(B, -1, plan.A["out"].shape[-1])[:, :S_t], pred_o)
+        loss_h.backward()
+    torch.cuda.synchronize()
+    res["loss_oracle"], res["loss_hip"] = loss_o.item(), loss_h.item()
+    res["loss_rel"] = abs(loss_h.item() - loss_o.item()) / abs(loss_o.item())
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    worst, worst_name, bad = 0.0, None, 0
+    for n, p in hip.named_parameters():
+        if "lora" in n:
+            if og[n] is None:
+                assert p.grad.abs().max().item() == 0.0, n
+                continue
+            e = relmax(p.grad, og[n])
+            bad += int((p.grad.abs().max().item() > 0) != (og[n].abs().max().item() > 0))
+            if e > worst:
+                worst, worst_name = e, n
+    res["grad_rel_worst"], res["grad_worst_name"], res["n_lora"] = worst, worst_name, len(og)
+    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 4e-2 and worst < 8e-2 and bad == 0)
+    if verbose:
+        print(res)
+    return res
