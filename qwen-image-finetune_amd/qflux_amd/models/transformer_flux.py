@@ -174,6 +174,12 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
             P[k + "_Wp"] = torch.tensor([P[k].W.data_ptr()], dtype=torch.int64, device=dev)
             P[k + "_bp"] = torch.tensor([P[k].b.data_ptr()], dtype=torch.int64, device=dev)
         P["proj_out"] = _LinW(self.proj_out, True)
+        Jd = self.config.joint_attention_dim
+        if Jd % 64:   # the GEMM contracts in 64-wide K tiles: zero-pad the context embedder's K once
+            Jp = _ceil(Jd, 64)
+            wpad = torch.zeros(self.inner_dim, Jp, dtype=BF, device=dev)
+            wpad[:, :Jd].copy_(P["c_in"].W)
+            P["c_in"].W, P["c_in"].K = wpad, Jp
         mods = [w[s + ".mod"] for w in P["blocks"] for s in ("img", "txt")]
         P["mod_W"] = torch.tensor([m.W.data_ptr() for m in mods], dtype=torch.int64, device=dev)
         P["mod_b"] = torch.tensor([m.b.data_ptr() for m in mods], dtype=torch.int64, device=dev)
@@ -255,7 +261,7 @@ class _FluxPlan(_QwenPlan):
         self.rope = flux_joint_rope(ids, cfg.axes_dims_rope).to(model.device)
         assert self.rope.shape == (S, dh // 2, 2)
         A = self.A
-        A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, Jd); A["pooled"] = buf(B, Pd)
+        A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, P["c_in"].K, zero=True); A["pooled"] = buf(B, Pd)
         A["t"] = buf(B, dtype=F32); A["gd"] = buf(B, dtype=F32)
         for k in ("tproj", "gproj"):
             A[k] = buf(B, 256)
@@ -333,7 +339,7 @@ class _FluxPlan(_QwenPlan):
         first_out = {s: ((A["X"][s][0], (0, 0)) if Ld else (A["J"][0], (S, off[s]))) for s in ("img", "txt")}
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["x_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
                    C_=first_out["img"][0], ldc=D, bias=P["x_in"].b, rpb=rpb["img"], c_map=first_out["img"][1])
-        self._gemm(p, A1=A["in_txt"], lda1=cfg.joint_attention_dim, B1=P["c_in"].W, K1=cfg.joint_attention_dim, M=rows["txt"], N=D,
+        self._gemm(p, A1=A["in_txt"], lda1=P["c_in"].K, B1=P["c_in"].W, K1=P["c_in"].K, M=rows["txt"], N=D,
                    C_=first_out["txt"][0], ldc=D, bias=P["c_in"].b, rpb=rpb["txt"], c_map=first_out["txt"][1])
         self.attn_args = []
         for i in range(Ld):
@@ -521,7 +527,7 @@ class _FluxPlan(_QwenPlan):
         hidden_states, pooled, guidance = inputs
         A = self.A
         A["in_img"].view(self.B, self.S_i, -1).copy_(hidden_states)
-        A["in_txt"].view(self.B, self.T, -1).copy_(encoder_hidden_states)
+        A["in_txt"].view(self.B, self.T, -1)[:, :, : encoder_hidden_states.shape[-1]].copy_(encoder_hidden_states)
         A["pooled"].copy_(pooled)
         A["t"].copy_(timestep.reshape(self.B).to(F32))
         if guidance is not None:

@@ -55,3 +55,26 @@ def test_flux_optimizer_steps_reduce_loss():
     losses = [step.train_step(emb, noise=noise, t=t).item() for _ in range(8)]
     print(losses)
     assert losses[-1] < losses[0]
+
+
+def test_flux_forward_matches_reference_golden_vectors(golden_dir):
+    """bf16 HIP forward vs the fp32 output captured from the reference's transformer_flux.py (tests/golden/flux_tiny_fwd)."""
+    import os
+    from safetensors.torch import load_file
+    from common import FLUX_TINY, fill_weights
+    from oracle import flux_dit as FO
+    from qflux_amd.models import FluxTransformer2DModel
+    t = load_file(os.path.join(golden_dir, "flux_tiny_fwd.safetensors"))
+    cfg = dict(FLUX_TINY, guidance_embeds=True)
+    oracle = FO.OracleFluxDiT(**cfg)
+    fill_weights(oracle, seed=3)
+    with torch.device(DEV):
+        hip = FluxTransformer2DModel(**cfg)
+    hip.load_state_dict({k: v.to(BF) for k, v in oracle.state_dict().items()}, strict=True)
+    with torch.no_grad():
+        out = hip(hidden_states=t["in.hidden_states"].to(DEV).to(BF), encoder_hidden_states=t["in.encoder_hidden_states"].to(DEV).to(BF),
+                  pooled_projections=t["in.pooled"].to(DEV).to(BF), timestep=t["in.timestep"].to(DEV), img_ids=t["in.img_ids"],
+                  txt_ids=t["in.txt_ids"], guidance=torch.ones(2, device=DEV), return_dict=False)[0]
+    e = relmax(out, t["out.sample"])
+    print("flux hip bf16 vs reference fp32 golden: rel", e)
+    assert e < 5e-2
