@@ -242,6 +242,18 @@ class QwenImageTransformer2DModel(nn.Module):
     def set_adapter(self, adapter_name):
         self._adapter_name = adapter_name
 
+    def save_lora_weights(self, save_folder, style="diffusers"):
+        """pytorch_lora_weights.safetensors as BaseTrainer.save_lora writes it (base_trainer.py:858-875)."""
+        from ..lora_io import save_lora_weights
+        return save_lora_weights(self, save_folder, style)
+
+    def load_lora_adapter(self, path, adapter_name="default", lora_alpha=None):
+        """DIFFUSERS- or PEFT-style LoRA file/folder (base_trainer.py:977-999)."""
+        from ..lora_io import load_lora_adapter
+        names = load_lora_adapter(self, path, adapter_name, lora_alpha)
+        self._invalidate()
+        return names
+
     def lora_parameters(self):
         return [p for n, p in self.named_parameters() if "lora_" in n]
 
