@@ -60,6 +60,8 @@ typedef struct qfx_gemm_args {
   int32_t a_batch_rows; int32_t a_row_off;   /* applied to A1 rows; a_batch_rows==0 => identity */
   int32_t c_batch_rows; int32_t c_row_off;   /* applied to C/C2/aux rows; c_batch_rows==0 => identity */
   int32_t epi;
+  const float* row_mask;           /* optional [M] (compact row m): rows with mask 0 are written as exact zeros (multi-resolution
+                                      padding, transformer_flux_custom.py:427-442,648-660,724-733); NULL = no masking */
   int32_t aux_unmapped;            /* 1: aux rows are indexed by m (compact) even when C uses the c_* row remap */
   int32_t seg2_plain;              /* 1: the second K segment is an ordinary continuation of the contraction (FLUX single block:
                                       [attn | mlp] @ W_out as two segments) -- no bf16 mid-rounding, bias added at the end */
@@ -139,7 +141,8 @@ int qfx_ln_modulate_fwd(const uint16_t* x, const uint16_t* shift, const uint16_t
 int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* scale, int64_t mod_bstride,
                         const uint16_t* dres, const uint16_t* gate, int64_t gate_bstride,
                         uint16_t* dx, uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch,
-                        float eps, void* stream);
+                        float eps, const float* row_mask, void* stream);
+/* row_mask (optional, [rows]): rows with mask 0 get dx = dyg = 0 (backward of the padded-token zeroing). */
 /* dyg = bf16(gate[b] * dx) only (used where no LayerNorm precedes). */
 int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg,
                  int32_t rows, int32_t D, int32_t rows_per_batch, void* stream);
@@ -173,15 +176,19 @@ int qfx_add3_bf16(const uint16_t* a, const uint16_t* b, const uint16_t* c, uint1
  * (transformer_qwenimage.py:305-320, apply_rotary_emb_qwen :134-140). Pre-norm q,k are first copied to
  * `saved` [B,S,2*H*dh] (needed by the backward) when saved != NULL.
  */
+/* rope_bstride: elements between consecutive samples' tables (per-sample RoPE of the multi-resolution path,
+ * transformer_flux_custom.py:537-560); 0 = one table shared by the batch. */
 int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope,
                          const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,
-                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream);
+                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bstride,
+                         void* stream);
 /* flags bit0: torch.nn.RMSNorm rounding (FLUX, transformer_flux.py:342-343: one rounding after x*rstd*w) instead of the
  * diffusers RMSNorm double rounding (Qwen). */
 /* in place on the q,k sections of dqkv (v section untouched): un-rotate, RMSNorm backward. */
 int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope,
                          const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,
-                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream);
+                         int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bstride,
+                         void* stream);
 
 /* ---- [B,S,H,dh] (row stride ld_in, column offset applied by caller) -> [B,H,dh,S_pad] with zero pad */
 int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_t B, int32_t S, int32_t S_pad,
@@ -215,6 +222,12 @@ int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream);   /* needs Q,Qt,K,V,
  * dpred [B,S_all,C] bf16 = bf16(2*(pred-target)/(B*S_t*C) * gscale), zero for rows >= S_t. */
 int qfx_mse_loss_fwd_bwd(const uint16_t* pred, const uint16_t* target, float* loss, uint16_t* dpred,
                          int32_t B, int32_t S_all, int32_t S_t, int32_t C, float gscale, void* stream);
+
+/* token-weighted variant (src/qflux/losses/attention_mask_loss.py:146-226, reduction="mean"): token_w [B,S_t] fp32 =
+ * attention_mask * edit weight; loss += sum_{b,s} token_w * mean_c (pred-target)^2 * inv_denom, inv_denom = 1/(num_valid+eps)
+ * (the caller knows the valid-token count on the host: no device sync). dpred as above with the same weights. */
+int qfx_mse_token_weighted_fwd_bwd(const uint16_t* pred, const uint16_t* target, const float* token_w, float* loss, uint16_t* dpred,
+                                   int32_t B, int32_t S_all, int32_t S_t, int32_t C, float inv_denom, float gscale, void* stream);
 
 /* ---- flow-matching input preparation (qwen_image_edit_trainer.py:811-812,841), bf16 eager rounding:
  * packed[b] = cat(bf16(bf16(bf16(1-sigma)*x0) + bf16(sigma*noise)), ctrl) ; target = bf16(noise - x0) */

@@ -30,8 +30,12 @@ def flux_rope_tables(ids: torch.Tensor, axes_dim=(16, 56, 56), theta: float = 10
 
 
 def apply_rotary_emb_real(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
-    """diffusers apply_rotary_emb(x, (cos, sin), sequence_dim=1), use_real_unbind_dim=-1: x [B,S,H,D]."""
-    cos, sin = cos[None, :, None, :], sin[None, :, None, :]
+    """diffusers apply_rotary_emb(x, (cos, sin), sequence_dim=1), use_real_unbind_dim=-1: x [B,S,H,D].
+    cos/sin [S,D] (shared) or [B,S,D] (per-sample RoPE of transformer_flux_custom.py:194-212)."""
+    if cos.ndim == 3:
+        cos, sin = cos[:, :, None, :], sin[:, :, None, :]
+    else:
+        cos, sin = cos[None, :, None, :], sin[None, :, None, :]
     x_real, x_imag = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
     x_rot = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
     return (x.float() * cos + x_rot.float() * sin).to(x.dtype)
@@ -203,7 +207,10 @@ class OracleFluxDiT(nn.Module):
         self.proj_out = nn.Linear(D, patch_size * patch_size * (out_channels or in_channels), bias=True)
 
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None,
-                txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=False, key_mask=None):
+                txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=False, key_mask=None, attention_mask=None):
+        if attention_mask is not None:
+            return self.forward_multires(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                                         guidance, attention_mask)
         x = self.x_embedder(hidden_states)
         timestep = timestep.to(x.dtype) * 1000           # (:729-730) computed in the model dtype
         if guidance is not None:
@@ -218,6 +225,108 @@ class OracleFluxDiT(nn.Module):
             ctx, x = blk(x, ctx, temb, rope, key_mask)
         x = self.norm_out(x, temb)
         return (self.proj_out(x),)
+
+
+def _forward_multires(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance,
+                      attention_mask):
+    """Multi-resolution forward of the custom model (src/qflux/models/transformer_flux_custom.py:372-741): bool
+    attention_mask [B, T+S_max]; per-sample RoPE with identity rotation on padding (:537-560); additive -inf key mask
+    (:585-616); padded image tokens zeroed after x_embedder (:427-442), after EVERY block (:648-660,696-708) and in
+    the output (:724-733).  The text stream is never masked."""
+    B, S_i = hidden_states.shape[:2]
+    T = txt_ids.shape[0]
+    mask = attention_mask if attention_mask.dtype == torch.bool else attention_mask > 0
+    img_mask = mask[:, T:T + S_i]
+    x = self.x_embedder(hidden_states)
+    if not img_mask.all():
+        x = x.masked_fill(~img_mask.unsqueeze(-1), 0)
+    timestep = timestep.to(x.dtype) * 1000
+    if guidance is not None:
+        guidance = guidance.to(x.dtype) * 1000
+    temb = self.time_text_embed(timestep, guidance, pooled_projections)
+    ctx = self.context_embedder(encoder_hidden_states)
+    if img_ids.ndim == 2:
+        img_ids = img_ids.unsqueeze(0).expand(B, -1, -1)
+    Dh = sum(self.axes_dims_rope)
+    cos = torch.ones(B, T + S_i, Dh)
+    sin = torch.zeros(B, T + S_i, Dh)
+    for b in range(B):
+        n = int(img_mask[b].sum().item())
+        c, s_ = flux_rope_tables(torch.cat([txt_ids.float(), img_ids[b, :n].float()], dim=0), self.axes_dims_rope)
+        cos[b, : T + n], sin[b, : T + n] = c, s_
+    rope = (cos, sin)
+    km = torch.zeros(B, T + S_i, dtype=x.dtype).masked_fill(~mask[:, : T + S_i], float("-inf"))
+    for blk in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+        ctx, x = blk(x, ctx, temb, rope, km)
+        if not img_mask.all():
+            x = x * img_mask.unsqueeze(-1)
+    x = self.norm_out(x, temb)
+    out = self.proj_out(x)
+    if not img_mask.all():
+        out = out.masked_fill(~img_mask.unsqueeze(-1), 0)
+    return (out,)
+
+
+OracleFluxDiT.forward_multires = _forward_multires
+
+
+def attention_mask_mse_loss(model_pred, target, attention_mask, edit_mask=None, fg=1.0, bg=1.0, eps=1e-12):
+    """AttentionMaskMseLoss.forward, reduction='mean' (src/qflux/losses/attention_mask_loss.py:146-226)."""
+    el = (model_pred.float() - target.float()) ** 2
+    if edit_mask is None:
+        ew = torch.ones_like(attention_mask, dtype=torch.float32).unsqueeze(-1)
+    else:
+        m = edit_mask.float()
+        ew = (m * fg + (1.0 - m) * bg).unsqueeze(-1)
+    tok = (el * ew * attention_mask.float().unsqueeze(-1)).mean(dim=2)
+    nv = attention_mask.sum().to(model_pred.dtype)
+    return tok.sum() / (nv + eps)
+
+
+def flux_compute_loss_multires(dit: nn.Module, samples: list, txt: dict, dtype: torch.dtype, return_pred=False):
+    """FluxKontextLoraTrainer._compute_loss_multi_resolution_mode (flux_kontext_trainer.py:579-796) with (noise, t) injected.
+    samples[i] = dict(image_latents [n_t,64], control_latents [n_c,64], hw=(h,w), control_hw=[(h,w),...], noise [n_t,64], t scalar);
+    txt = dict(text_ids [T,3], pooled_prompt_embeds [B,P], prompt_embeds [B,T,J])."""
+    B = len(samples)
+    seqs, ids, tmask_len = [], [], []
+    for smp in samples:
+        h, w = smp["hw"]
+        lat_ids = prepare_latent_image_ids(h, w, dtype)
+        cids = []
+        for j, (ch, cw) in enumerate(smp["control_hw"]):
+            ci = prepare_latent_image_ids(ch, cw, dtype)
+            ci[..., 0] = j + 1
+            cids.append(ci)
+        t_ = smp["t"].to(dtype).reshape(1, 1)
+        x_t = (1.0 - t_) * smp["image_latents"] + t_ * smp["noise"].to(dtype)
+        seqs.append(torch.cat([x_t, smp["control_latents"]], dim=0))
+        ids.append(torch.cat([lat_ids] + cids, dim=0))
+        tmask_len.append(smp["image_latents"].shape[0])
+    S_max = max(s.shape[0] for s in seqs)
+    n_t_max = max(tmask_len)
+    T = txt["text_ids"].shape[0]
+    inp = torch.zeros(B, S_max, 64)
+    idb = torch.zeros(B, S_max, 3)
+    full = torch.ones(B, T + S_max, dtype=torch.bool)
+    lat_mask = torch.zeros(B, n_t_max, dtype=dtype)
+    noise_in = torch.zeros(B, n_t_max, 64, dtype=dtype)
+    x0_pad = torch.zeros(B, n_t_max, 64)
+    for i, (sq, di) in enumerate(zip(seqs, ids)):
+        inp[i, : sq.shape[0]] = sq.float()
+        idb[i, : di.shape[0]] = di.float()
+        full[i, T + sq.shape[0]:] = False
+        lat_mask[i, : tmask_len[i]] = 1
+        noise_in[i, : tmask_len[i]] = samples[i]["noise"].to(dtype)
+        x0_pad[i, : tmask_len[i]] = samples[i]["image_latents"].float()
+    timestep = torch.stack([s["t"].to(dtype).reshape(()) for s in samples])
+    guidance = torch.ones((B,)).to(dtype) if getattr(dit, "guidance_embeds", False) else None
+    pred = dit(hidden_states=inp.to(dtype), timestep=timestep, guidance=guidance, pooled_projections=txt["pooled_prompt_embeds"].to(dtype),
+               encoder_hidden_states=txt["prompt_embeds"].to(dtype), txt_ids=txt["text_ids"], img_ids=idb, attention_mask=full,
+               return_dict=False)[0]
+    pred = pred[:, :n_t_max]
+    target = noise_in - x0_pad.to(dtype)
+    loss = attention_mask_mse_loss(pred, target, lat_mask)
+    return (loss, pred) if return_pred else loss
 
 
 def prepare_latent_image_ids(height: int, width: int, dtype=torch.float32) -> torch.Tensor:

@@ -79,12 +79,22 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restric
                                                          const bf16_t* __restrict__ scale, int64_t mod_bstride,
                                                          const bf16_t* __restrict__ dres, const bf16_t* __restrict__ gate,
                                                          int64_t gate_bstride, bf16_t* __restrict__ dx,
-                                                         bf16_t* __restrict__ dyg, int rows, int D, int rpb, float eps) {
+                                                         bf16_t* __restrict__ dyg, int rows, int D, int rpb, float eps,
+                                                         const float* __restrict__ row_mask) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int b = row / rpb;
   const int64_t ro = (int64_t)row * D;
+  if (row_mask != nullptr && row_mask[row] == 0.f) {   // padded token: no gradient flows through it
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < D) { *(u32x4*)(dx + ro + col) = z; if (dyg) *(u32x4*)(dyg + ro + col) = z; }
+    }
+    return;
+  }
   float v[MAXP][8];   // x, later xhat
   float gq[MAXP][8];  // g = bf16(dy * bf16(1+scale))
   float s = 0.f;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
                                                            const float* __restrict__ rope,
                                                            const bf16_t* __restrict__ wq_txt, const bf16_t* __restrict__ wk_txt,
                                                            const bf16_t* __restrict__ wq_img, const bf16_t* __restrict__ wk_img,
-                                                           int B, int S, int T, int H, float eps, int flags) {
+                                                           int B, int S, int T, int H, float eps, int flags, int64_t rope_bs) {
   constexpr int LPI = DH / 8;        // lanes per (token, q|k, head) item
   constexpr int IPB = 256 / LPI;     // items per block
   const int sub = threadIdx.x % LPI;
@@ -283,8 +293,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   float w[8], cs[8];
   ld8(wsel + sub * 8, w);
   {
-    const f32x4 c0 = *(const f32x4*)(rope + ((int64_t)s * (DH / 2) + sub * 4) * 2);
-    const f32x4 c1 = *(const f32x4*)(rope + ((int64_t)s * (DH / 2) + sub * 4) * 2 + 4);
+    const float* rp = rope + (token / S) * rope_bs + ((int64_t)s * (DH / 2) + sub * 4) * 2;
+    const f32x4 c0 = *(const f32x4*)(rp);
+    const f32x4 c1 = *(const f32x4*)(rp + 4);
     cs[0] = c0[0]; cs[1] = c0[1]; cs[2] = c0[2]; cs[3] = c0[3];
     cs[4] = c1[0]; cs[5] = c1[1]; cs[6] = c1[2]; cs[7] = c1[3];
   }
@@ -396,6 +407,33 @@ __global__ __launch_bounds__(256) void mse_kernel(const bf16_t* __restrict__ pre
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+__global__ __launch_bounds__(256) void mse_tw_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ target,
+                                                     const float* __restrict__ tw, float* __restrict__ loss,
+                                                     bf16_t* __restrict__ dpred, int B, int S_all, int S_t, int C, float inv_denom,
+                                                     float gscale) {
+  __shared__ float red[4];
+  const int64_t total = (int64_t)B * S_all * C;
+  const float invc = 1.0f / (float)C;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t t = i / C;
+    const int s = (int)(t % S_all), b = (int)(t / S_all);
+    float g = 0.f;
+    if (s < S_t) {
+      const float w = tw[(int64_t)b * S_t + s];
+      const float d = bf2f(pred[i]) - bf2f(target[((int64_t)b * S_t + s) * C + c]);
+      acc += w * d * d * invc;
+      g = 2.0f * w * d * invc * inv_denom * gscale;
+    }
+    if (dpred) dpred[i] = f2bf(g);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_denom);
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
@@ -522,12 +560,13 @@ extern "C" int qfx_ln_modulate_fwd(const uint16_t* x, const uint16_t* shift, con
 
 extern "C" int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* scale, int64_t mod_bstride,
                                    const uint16_t* dres, const uint16_t* gate, int64_t gate_bstride, uint16_t* dx,
-                                   uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, void* stream) {
+                                   uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, const float* row_mask,
+                                   void* stream) {
   if (!dy || !x || !scale || !dx || rows <= 0 || D <= 0 || (D % 8) || D > MAXP * 512 || rows_per_batch <= 0 || (mod_bstride % 8))
     return QFX_EINVAL;
   if (dyg && (!gate || (gate_bstride % 8))) return QFX_EINVAL;
   hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, scale,
-                     mod_bstride, dres, gate, gate_bstride, dx, dyg, rows, D, rows_per_batch, eps);
+                     mod_bstride, dres, gate, gate_bstride, dx, dyg, rows, D, rows_per_batch, eps, row_mask);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
@@ -565,7 +604,7 @@ extern "C" int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const ui
 
 static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope, const uint16_t* wq_txt,
                      const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B, int32_t S,
-                     int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream) {
+                     int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bs, void* stream) {
   if (!qkv || !rope || !wq_txt || !wk_txt || !wq_img || !wk_img || B <= 0 || S <= 0 || T < 0 || T > S || H <= 0) return QFX_EINVAL;
   if (bwd && !saved) return QFX_EINVAL;
   const int64_t nitems = (int64_t)B * S * 2 * H;
@@ -573,13 +612,13 @@ static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope
   if (dh == 128) {
     const int ipb = 256 / 16;
     dim3 grid((unsigned)((nitems + ipb - 1) / ipb));
-    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<128, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
-    else hipLaunchKernelGGL((qk_norm_rope_kernel<128, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
+    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<128, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags, rope_bs);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<128, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags, rope_bs);
   } else if (dh == 64) {
     const int ipb = 256 / 8;
     dim3 grid((unsigned)((nitems + ipb - 1) / ipb));
-    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<64, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
-    else hipLaunchKernelGGL((qk_norm_rope_kernel<64, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags);
+    if (bwd) hipLaunchKernelGGL((qk_norm_rope_kernel<64, true>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags, rope_bs);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<64, false>), grid, dim3(256), 0, s, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, eps, flags, rope_bs);
   } else {
     return QFX_EUNSUPPORTED;
   }
@@ -589,13 +628,15 @@ static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope
 
 extern "C" int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope, const uint16_t* wq_txt,
                                     const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
-                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream) {
-  return launch_qk(false, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, stream);
+                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bstride,
+                                    void* stream) {
+  return launch_qk(false, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, rope_bstride, stream);
 }
 extern "C" int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope, const uint16_t* wq_txt,
                                     const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
-                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, void* stream) {
-  return launch_qk(true, dqkv, (uint16_t*)saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, stream);
+                                    int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bstride,
+                                    void* stream) {
+  return launch_qk(true, dqkv, (uint16_t*)saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, rope_bstride, stream);
 }
 
 extern "C" int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_t B, int32_t S, int32_t S_pad,
@@ -615,6 +656,19 @@ extern "C" int qfx_mse_loss_fwd_bwd(const uint16_t* pred, const uint16_t* target
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, loss, dpred, B, S_all, S_t, C,
                      gscale);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_mse_token_weighted_fwd_bwd(const uint16_t* pred, const uint16_t* target, const float* token_w, float* loss,
+                                              uint16_t* dpred, int32_t B, int32_t S_all, int32_t S_t, int32_t C, float inv_denom,
+                                              float gscale, void* stream) {
+  if (!pred || !target || !token_w || !loss || B <= 0 || S_all <= 0 || S_t <= 0 || S_t > S_all || C <= 0) return QFX_EINVAL;
+  const int64_t total = (int64_t)B * S_all * C;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(mse_tw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, token_w, loss, dpred, B, S_all,
+                     S_t, C, inv_denom, gscale);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

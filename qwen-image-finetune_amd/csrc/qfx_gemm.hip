@@ -145,10 +145,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
     if (m >= p.M) continue;
     const int bidx = m / p.rows_per_batch;
     const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+    const bool keep = p.row_mask == nullptr || p.row_mask[m] != 0.f;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wc * 64 + ni * 16 + 4 * g;
       if (n + 3 >= p.N) continue;
+      if (!keep) {
+        const bf16x4 z = {0, 0, 0, 0};
+        *(bf16x4*)(p.C + crow * p.ldc + n) = z;
+        if constexpr (EPI == QFX_EPI_GELU) *(bf16x4*)(p.C2 + crow * p.ldc2 + n) = z;
+        continue;
+      }
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
@@ -394,6 +401,12 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
       const int m = m0 + ml;
       if (m >= p.M) continue;
       const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+      if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *(u32x4*)(p.C + crow * p.ldc + n) = z;
+        if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
+        continue;
+      }
       const u32x4 yv = *(const u32x4*)(smem + ml * CROW + ch * 16);
       float y[8];
 #pragma unroll

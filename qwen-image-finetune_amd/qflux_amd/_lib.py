@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
         ("rows_per_batch", C.c_int32),
         ("a_batch_rows", C.c_int32), ("a_row_off", C.c_int32),
         ("c_batch_rows", C.c_int32), ("c_row_off", C.c_int32),
-        ("epi", C.c_int32), ("aux_unmapped", C.c_int32), ("seg2_plain", C.c_int32),
+        ("epi", C.c_int32), ("row_mask", C.c_void_p), ("aux_unmapped", C.c_int32), ("seg2_plain", C.c_int32),
     ]
 
 
@@ -86,20 +86,21 @@ SYMBOLS = {
     "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),
     "qfx_lora_pack": (C.c_int, [_vp, _i32, _i32, _vp]),
     "qfx_ln_modulate_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f, _vp]),
-    "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp]),
+    "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
     "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "qfx_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "qfx_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f, _f, _vp, _vp]),
     "qfx_add3_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
-    "qfx_qk_norm_rope_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _vp]),
-    "qfx_qk_norm_rope_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _vp]),
+    "qfx_qk_norm_rope_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _i64, _vp]),
+    "qfx_qk_norm_rope_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _i64, _vp]),
     "qfx_transpose_heads": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "qfx_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "qfx_attn_bwd_prep": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "qfx_attn_bwd_dq": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "qfx_attn_bwd_dkv": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "qfx_mse_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
+    "qfx_mse_token_weighted_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _f, _vp]),
     "qfx_flowmatch_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "qfx_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
     "qfx_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _vp]),

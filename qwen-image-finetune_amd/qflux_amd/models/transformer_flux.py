@@ -219,12 +219,22 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None, img_ids=None, txt_ids=None,
                 guidance=None, joint_attention_kwargs=None, controlnet_block_samples=None, controlnet_single_block_samples=None,
-                return_dict=True, controlnet_blocks_repeat=False):
+                return_dict=True, controlnet_blocks_repeat=False, attention_mask=None):
         if controlnet_block_samples is not None or controlnet_single_block_samples is not None:
             raise NotImplementedError("controlnet residuals are not part of the LoRA training path")
         if self.config.guidance_embeds and guidance is None:
             raise ValueError("guidance_embeds=True requires `guidance`")
-        plan = self.get_plan(hidden_states.shape[0], hidden_states.shape[1], encoder_hidden_states.shape[1], img_ids, txt_ids)
+        B, S_i, T = hidden_states.shape[0], hidden_states.shape[1], encoder_hidden_states.shape[1]
+        if attention_mask is not None:
+            m = attention_mask if attention_mask.dtype == torch.bool else attention_mask > 0
+            if m.dim() != 2 or m.shape[1] < T + S_i:
+                raise ValueError("attention_mask must have shape (batch, total_sequence_length).")
+            if not bool(m.all()):
+                plan = self.get_plan_multires(B, S_i, T, img_ids, m[:, T:T + S_i].sum(dim=1).tolist())
+            else:
+                attention_mask = None
+        if attention_mask is None:
+            plan = self.get_plan(B, S_i, T, img_ids[0] if img_ids.ndim == 3 else img_ids, txt_ids)
         from .transformer_qwenimage import _QwenDiTFn
         out = _QwenDiTFn.apply(self, plan, (hidden_states, pooled_projections, guidance), encoder_hidden_states, timestep,
                                *self.lora_parameters())
@@ -247,20 +257,48 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
         return self._plans[key]
 
 
+def _get_plan_multires(self, B, S_i, T, img_ids, valid_lens):
+    """Multi-resolution plan (one per padded shape); RoPE / masks are refreshed every call."""
+    if img_ids.ndim == 2:
+        img_ids = img_ids.unsqueeze(0).expand(B, -1, -1)
+    self._prepare()
+    self._prepare_lora()
+    key = (B, S_i, T, "multires", self._version)
+    if key not in self._plans:
+        self._plans[key] = _FluxPlan(self, B, S_i, T, None, multires=True)
+    plan = self._plans[key]
+    plan.set_multires(img_ids, valid_lens)
+    return plan
+
+
+FluxTransformer2DModel.get_plan_multires = _get_plan_multires
+
+
 class _FluxPlan(_QwenPlan):
     NORM_FLAGS = 1  # torch.nn.RMSNorm rounding
 
-    def __init__(self, model: FluxTransformer2DModel, B, S_i, T, ids):
+    def __init__(self, model: FluxTransformer2DModel, B, S_i, T, ids, multires=False):
         self._setup(model, B, S_i, T)
+        self.multires = multires
         cfg = model.config
         D, S, H, dh, S_pad = self.D, self.S, self.H, self.dh, self.S_pad
         buf, rows = self.buf, self.rows
         Ld, Ls = cfg.num_layers, cfg.num_single_layers
         Cin, Cout, Jd, Pd = cfg.in_channels, model.proj_out.out_features, cfg.joint_attention_dim, cfg.pooled_projection_dim
         P = model._prepared
-        self.rope = flux_joint_rope(ids, cfg.axes_dims_rope).to(model.device)
-        assert self.rope.shape == (S, dh // 2, 2)
         A = self.A
+        if multires:
+            # dynamic per-step buffers: per-sample RoPE, additive key mask, padded-row masks (set_multires fills them)
+            A["rope_b"] = buf(B, S, dh // 2, 2, dtype=F32)
+            A["kmask"] = buf(B, S, dtype=F32, zero=True)
+            A["rm_img"] = buf(B * S_i, dtype=F32)
+            A["rm_joint"] = buf(B * S, dtype=F32)
+            self.rope, self.rope_bs = A["rope_b"], S * (dh // 2) * 2
+            self.kmask = A["kmask"]
+            self.rmask = {"img": A["rm_img"], "txt": None, "joint": A["rm_joint"]}
+        else:
+            self.rope = flux_joint_rope(ids, cfg.axes_dims_rope).to(model.device)
+            assert self.rope.shape == (S, dh // 2, 2)
         A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, P["c_in"].K, zero=True); A["pooled"] = buf(B, Pd)
         A["t"] = buf(B, dtype=F32); A["gd"] = buf(B, dtype=F32)
         for k in ("tproj", "gproj"):
@@ -338,7 +376,7 @@ class _FluxPlan(_QwenPlan):
             raise NotImplementedError("FLUX model without any transformer block")
         first_out = {s: ((A["X"][s][0], (0, 0)) if Ld else (A["J"][0], (S, off[s]))) for s in ("img", "txt")}
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["x_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
-                   C_=first_out["img"][0], ldc=D, bias=P["x_in"].b, rpb=rpb["img"], c_map=first_out["img"][1])
+                   C_=first_out["img"][0], ldc=D, bias=P["x_in"].b, rpb=rpb["img"], c_map=first_out["img"][1], row_mask=self.rmask["img"])
         self._gemm(p, A1=A["in_txt"], lda1=P["c_in"].K, B1=P["c_in"].W, K1=P["c_in"].K, M=rows["txt"], N=D,
                    C_=first_out["txt"][0], ldc=D, bias=P["c_in"].b, rpb=rpb["txt"], c_map=first_out["txt"][1])
         self.attn_args = []
@@ -362,7 +400,8 @@ class _FluxPlan(_QwenPlan):
             p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Ld]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
                 rows["img"], D, rpb["img"], eps)
         po = P["proj_out"]
-        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b)
+        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b,
+                   row_mask=self.rmask["img"])
 
     def _emit_single_fwd(self, p, w, bb, mod, x, x_next):
         """FluxSingleTransformerBlock.forward (transformer_flux.py:407-436) on the joint buffer; mod [B,3D] = shift|scale|gate."""
@@ -390,13 +429,14 @@ class _FluxPlan(_QwenPlan):
         self._gemm(p, A1=xm, lda1=D, B1=ml.W, K1=D, M=M, N=4 * D, C_=bb["h"], ldc=4 * D, bias=ml.b, epi=L.EPI_GELU, C2=A["g_j"], ldc2=4 * D)
         nq, nk = w["norms"]
         p.c(lib.qfx_qk_norm_rope_fwd, _ptr(bb["qkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
-            B, S, T, H, dh, eps, self.NORM_FLAGS)
+            B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
         p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["VtA"]), B, S, S_pad, H, dh)
         a = L.AttnArgs()
         a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, 1.0 / math.sqrt(dh)
         a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
         a.ldq = a.ldk = a.ldv = 3 * D
         a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["VtA"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
+        a.key_mask = _ptr(self.kmask)
         a.Qt, a.Kt, a.dOt, a.dsum = _ptr(A["Qt"]), _ptr(A["Kt"]), _ptr(A["dOt"]), _ptr(A["dsum"])
         a.dO, a.lddo = _ptr(A["dao"]), D
         dq2 = A["dqkv"].view(M, 3 * D)
@@ -408,7 +448,7 @@ class _FluxPlan(_QwenPlan):
         wo = w["out"]
         self._gemm(p, A1=bb["ao"].view(M, D), lda1=D, B1=wo.W, ldb1=5 * D, K1=D, A2=A["g_j"], lda2=4 * D, B2=wo.W[:, D:], ldb2=5 * D,
                    K2=4 * D, M=M, N=D, C_=x_next, ldc=D, bias=wo.b, epi=L.EPI_GATE_RES, aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D],
-                   gate_bs=3 * D, rpb=S, seg2_plain=1)
+                   gate_bs=3 * D, rpb=S, seg2_plain=1, row_mask=self.rmask["joint"])
 
     # ------------------------------------------------------------------ backward
     def _build_backward(self, P):
@@ -431,7 +471,8 @@ class _FluxPlan(_QwenPlan):
             for b in range(B):
                 r0 = b * S + T
                 p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"][b * S_i:]), _ptr(A["J"][Ls][r0:]), _ptr(mo[b:b + 1, 0:D]), 2 * D, None,
-                    _ptr(gl[b:b + 1, 2 * D:3 * D]), 3 * D, _ptr(dJ[r0:]), _ptr(dyg[r0:]), S_i, D, S_i, eps)
+                    _ptr(gl[b:b + 1, 2 * D:3 * D]), 3 * D, _ptr(dJ[r0:]), _ptr(dyg[r0:]), S_i, D, S_i, eps,
+                    _ptr(self.rmask["img"][b * S_i:]) if self.rmask["img"] is not None else None)
             for i in range(Ls - 1, -1, -1):
                 nxt = cur ^ 1
                 self._emit_single_bwd(p, P["singles"][i], A["sblk"][i], self.sattn_args[i], A["smods"][i], A["J"][i],
@@ -444,7 +485,7 @@ class _FluxPlan(_QwenPlan):
             dcur = 0
             modL = A["mods"][2 * (Ld - 1)]
             p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"]), _ptr(A["X"]["img"][Ld]), _ptr(mo[:, 0:D]), 2 * D, None,
-                _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][dcur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps)
+                _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][dcur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps, None)
         for i in range(Ld - 1, -1, -1):
             nxt = dcur ^ 1
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}
@@ -480,7 +521,7 @@ class _FluxPlan(_QwenPlan):
         p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
         nq, nk = w["norms"]
         p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
-            B, S, T, H, dh, eps, self.NORM_FLAGS)
+            B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
         K2 = 4 * D
         if grp is not None:
             Rp, Kext = grp["Rp"], grp["Kext"]
@@ -511,7 +552,7 @@ class _FluxPlan(_QwenPlan):
         if i > 0:
             gp = A["smods"][i - 1][:, 2 * D:3 * D]
             p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm_j"]), _ptr(x), _ptr(mod[:, D:2 * D]), 3 * D, _ptr(dJ_out), _ptr(gp), 3 * D,
-                _ptr(dJ_in), _ptr(A["dyg_j"]), M, D, S, eps)
+                _ptr(dJ_in), _ptr(A["dyg_j"]), M, D, S, eps, _ptr(self.rmask["joint"]))
         elif Ld > 0:
             # hand the gradient over to the last double block: per (sample, stream) row ranges of the joint buffer
             mods_prev = {"img": A["mods"][2 * (Ld - 1)], "txt": A["mods"][2 * (Ld - 1) + 1]}
@@ -520,7 +561,33 @@ class _FluxPlan(_QwenPlan):
                     r0, n, c0 = b * S + off[s], rpb[s], b * rpb[s]
                     gp = mods_prev[s][b:b + 1, 5 * D:6 * D]
                     p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm_j"][r0:]), _ptr(x[r0:]), _ptr(mod[b:b + 1, D:2 * D]), 3 * D,
-                        _ptr(dJ_out[r0:]), _ptr(gp), 6 * D, _ptr(A["dX"][s][0][c0:]), _ptr(A["dyg2"][s][c0:]), n, D, n, eps)
+                        _ptr(dJ_out[r0:]), _ptr(gp), 6 * D, _ptr(A["dX"][s][0][c0:]), _ptr(A["dyg2"][s][c0:]), n, D, n, eps,
+                        _ptr(self.rmask[s][c0:]) if self.rmask[s] is not None else None)
+
+    def set_multires(self, img_ids_b: torch.Tensor, valid_lens):
+        """Per-step dynamic state of the multi-resolution path (transformer_flux_custom.py:499-616): per-sample RoPE with
+        identity rotation on padding, additive key mask (0 / -inf), row masks of the padded image tokens."""
+        cfg = self.model.config
+        B, S, T, S_i = self.B, self.S, self.T, self.S_i
+        dev = self.model.device
+        rope = torch.zeros(B, S, self.dh // 2, 2)
+        rope[..., 0] = 1.0
+        km = torch.zeros(B, S)
+        rm = torch.zeros(B, S_i)
+        txt = torch.zeros(T, 3)
+        for b in range(B):
+            n = int(valid_lens[b])
+            ids = torch.cat([txt, img_ids_b[b, :n].float().cpu()], dim=0)
+            rope[b, : T + n] = flux_joint_rope(ids, cfg.axes_dims_rope)
+            km[b, T + n:] = float("-inf")
+            rm[b, :n] = 1.0
+        A = self.A
+        A["rope_b"].copy_(rope.to(dev, non_blocking=True))
+        A["kmask"].copy_(km.to(dev, non_blocking=True))
+        A["rm_img"].copy_(rm.reshape(-1).to(dev, non_blocking=True))
+        rj = torch.ones(B, S)
+        rj[:, T:] = rm
+        A["rm_joint"].copy_(rj.reshape(-1).to(dev, non_blocking=True))
 
     # ------------------------------------------------------------------ execution
     def run_forward(self, inputs, encoder_hidden_states, timestep):

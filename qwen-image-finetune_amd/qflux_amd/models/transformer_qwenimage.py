@@ -485,6 +485,9 @@ class _QwenPlan:
         self.rpb = {"img": S_i, "txt": T}
         self.off = {"img": T, "txt": 0}
         self.A = {}
+        self.rope_bs = 0          # per-sample RoPE stride (multi-resolution plans set it)
+        self.rmask = {"img": None, "txt": None, "joint": None}   # fp32 row masks of padded tokens (multi-resolution)
+        self.kmask = None         # additive fp32 key mask [B,S] (multi-resolution)
 
     def _alloc_double_block(self, w):
         """Per-block saved activations of a double-stream block."""
@@ -537,7 +540,7 @@ class _QwenPlan:
     @staticmethod
     def _gargs(*, A1, lda1, B1, K1, M, N, C_, ldc, ldb1=None, bias=None, A2=None, lda2=0, B2=None, ldb2=0, K2=0,
                epi=L.EPI_NONE, C2=None, ldc2=0, aux=None, ldaux=0, gate=None, gate_bs=0, rpb=None, a_map=(0, 0), c_map=(0, 0),
-               seg2_plain=0, aux_unmapped=0):
+               seg2_plain=0, aux_unmapped=0, row_mask=None):
         g = L.GemmArgs()
         g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _ptr(A1), _ptr(B1), lda1, (K1 if ldb1 is None else ldb1), K1
         if K2:
@@ -554,6 +557,7 @@ class _QwenPlan:
         g.epi = epi
         g.seg2_plain = seg2_plain
         g.aux_unmapped = aux_unmapped
+        g.row_mask = _ptr(row_mask)
         return g
 
     def _gemm(self, prog, **kw):
@@ -672,13 +676,14 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_fwd, _ptr(qkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i),
-                B, S, T, H, dh, eps, norm_flags)
+                B, S, T, H, dh, eps, norm_flags, self.rope_bs)
             p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["VtA"]), B, S, S_pad, H, dh)
             a = L.AttnArgs()
             a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
             a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
             a.ldq = a.ldk = a.ldv = 3 * D
             a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["VtA"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
+            a.key_mask = _ptr(self.kmask)
             # backward fields (same struct reused by the backward program)
             a.Qt, a.Kt, a.dOt, a.dsum = _ptr(A["Qt"]), _ptr(A["Kt"]), _ptr(A["dOt"]), _ptr(A["dsum"])
             a.dO, a.lddo = _ptr(A["dao"]), D
@@ -716,7 +721,7 @@ class _QwenPlan:
                 f2 = w[s + ".fc2"]
                 groups.append(self._gargs(A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
                                           bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
-                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1))
+                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1, row_mask=self.rmask[s]))
             self._gemm_group(p, groups)
 
     # ------------------------------------------------------------------ backward program
@@ -735,7 +740,7 @@ class _QwenPlan:
         modL = A["mods"][2 * (Lyr - 1)]
         cur = 0
         p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"]), _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, 0:D]), 2 * D, None,
-            _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][cur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps)
+            _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][cur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps, None)
         for i in range(Lyr - 1, -1, -1):
             nxt = cur ^ 1
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}
@@ -771,7 +776,7 @@ class _QwenPlan:
             for s, sidx in live:
                 mod = mods[s]
                 p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(bb["x1"][s]), _ptr(mod[:, 4 * D:5 * D]), 6 * D,
-                    _ptr(dx2[s]), _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps)
+                    _ptr(dx2[s]), _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps, None)
                 # attention out-projection backward (+ LoRA)
                 lw = w[s + ".o"]
                 kw = {}
@@ -798,7 +803,7 @@ class _QwenPlan:
             p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
-                _ptr(nk_i), B, S, T, H, dh, eps, norm_flags)
+                _ptr(nk_i), B, S, T, H, dh, eps, norm_flags, self.rope_bs)
             # ---- q/k/v projection backward (+ LoRA), both streams in one launch
             groups = []
             for s, sidx in STREAMS:
@@ -841,7 +846,7 @@ class _QwenPlan:
                     gp = gate_prev[s] if gate_prev is not None else None
                     p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(x_in[s]), _ptr(mods[s][:, D:2 * D]), 6 * D, _ptr(dres),
                         _ptr(gp), (gp.stride(0) if gp is not None else 0), _ptr(out_dx[s]), _ptr(A["dyg2"][s] if gp is not None else None),
-                        rows[s], D, rpb[s], eps)
+                        rows[s], D, rpb[s], eps, _ptr(self.rmask[s]))
 
     # ------------------------------------------------------------------ execution
     def run_forward(self, hidden_states, encoder_hidden_states, timestep):

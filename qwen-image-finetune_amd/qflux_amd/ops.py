@@ -27,7 +27,7 @@ def _bf(t, name):
 
 
 def gemm(a1, b1, *, bias=None, a2=None, b2=None, out=None, epi=L.EPI_NONE, out2=None, aux=None, gate=None,
-         rows_per_batch=None, a_map=(0, 0), c_map=(0, 0), M=None, c_rows=None):
+         rows_per_batch=None, a_map=(0, 0), c_map=(0, 0), M=None, c_rows=None, row_mask=None):
     """C = a1 @ b1.T (+ a2 @ b2.T) + bias -> epilogue.  a1 [*,K1] (row stride = a1.stride(0)), b1 [N,K1]."""
     _bf(a1, "a1"); _bf(b1, "b1")
     M = a1.shape[0] if M is None else M
@@ -51,6 +51,7 @@ def gemm(a1, b1, *, bias=None, a2=None, b2=None, out=None, epi=L.EPI_NONE, out2=
     g.a_batch_rows, g.a_row_off = a_map
     g.c_batch_rows, g.c_row_off = c_map
     g.epi = epi
+    g.row_mask = _p(row_mask)
     L.check(lib.qfx_gemm_bf16(C.byref(g), stream_ptr()), "qfx_gemm_bf16")
     return out
 
@@ -128,13 +129,13 @@ def ln_modulate_fwd(x, shift, scale, rows_per_batch, eps=1e-6, out=None):
     return out
 
 
-def ln_modulate_bwd(dy, x, scale, rows_per_batch, dres=None, gate=None, eps=1e-6, want_dyg=False):
+def ln_modulate_bwd(dy, x, scale, rows_per_batch, dres=None, gate=None, eps=1e-6, want_dyg=False, row_mask=None):
     rows, D = x.shape
     dx = torch.empty_like(x)
     dyg = torch.empty_like(x) if want_dyg else None
     L.check(lib.qfx_ln_modulate_bwd(_p(dy), _p(x), _p(scale), scale.stride(0), _p(dres), _p(gate),
                                     gate.stride(0) if gate is not None else 0, _p(dx), _p(dyg), rows, D, rows_per_batch, eps,
-                                    stream_ptr()), "qfx_ln_modulate_bwd")
+                                    _p(row_mask), stream_ptr()), "qfx_ln_modulate_bwd")
     return dx, dyg
 
 
@@ -179,9 +180,9 @@ def add3(a, b, c=None):
     return out
 
 
-def qk_norm_rope(qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps=1e-6, backward=False, flags=0):
+def qk_norm_rope(qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps=1e-6, backward=False, flags=0, rope_bstride=0):
     fn = lib.qfx_qk_norm_rope_bwd if backward else lib.qfx_qk_norm_rope_fwd
-    L.check(fn(_p(qkv), _p(saved), _p(rope), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img), B, S, T, H, dh, eps, flags, stream_ptr()),
+    L.check(fn(_p(qkv), _p(saved), _p(rope), _p(wq_txt), _p(wk_txt), _p(wq_img), _p(wk_img), B, S, T, H, dh, eps, flags, rope_bstride, stream_ptr()),
             "qfx_qk_norm_rope")
 
 
@@ -210,6 +211,15 @@ def mse_loss_fwd_bwd(pred, target, S_t, gscale=1.0, want_grad=True):
     dpred = torch.empty_like(pred) if want_grad else None
     L.check(lib.qfx_mse_loss_fwd_bwd(_p(pred), _p(target), _p(loss), _p(dpred), B, S_all, S_t, Cc, gscale, stream_ptr()),
             "qfx_mse_loss_fwd_bwd")
+    return loss, dpred
+
+
+def mse_token_weighted_fwd_bwd(pred, target, token_w, S_t, inv_denom, gscale=1.0, want_grad=True):
+    B, S_all, Cc = pred.shape
+    loss = torch.zeros((), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    L.check(lib.qfx_mse_token_weighted_fwd_bwd(_p(pred), _p(target), _p(token_w), _p(loss), _p(dpred), B, S_all, S_t, Cc, inv_denom,
+                                               gscale, stream_ptr()), "qfx_mse_token_weighted_fwd_bwd")
     return loss, dpred
 
 

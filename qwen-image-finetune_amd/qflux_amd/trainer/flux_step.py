@@ -62,3 +62,79 @@ class FluxKontextTrainStep(QwenLoraTrainStep):
         self.optimizer_step(grad_scale=scale)
         self.zero_grad()
         return loss
+
+
+def _build_multires_batch(step, samples, txt):
+    """Host/device plumbing of _compute_loss_multi_resolution_mode (flux_kontext_trainer.py:579-760): per-sample ids,
+    x_t, right-padding to the batch maximum, masks.  samples[i]: image_latents [n_t,64], control_latents [n_c,64],
+    hw, control_hw [(h,w),...], optional noise / t."""
+    dev, dt = step.dit.device, step.weight_dtype
+    B = len(samples)
+    seqs, ids, n_t = [], [], []
+    noises, ts = [], []
+    for smp in samples:
+        x0 = smp["image_latents"].to(dev)
+        ctrl = smp["control_latents"].to(dev)
+        noise = smp["noise"].to(dev).to(dt) if "noise" in smp else torch.randn(x0.shape, device=dev, dtype=dt)
+        t = smp["t"].to(dev).to(dt).reshape(1) if "t" in smp else torch.rand((1,), device=dev, dtype=dt)
+        t_ = t.unsqueeze(1)
+        x_t = (1.0 - t_) * x0 + t_ * noise                      # bf16 * cache dtype promotes like the reference
+        seqs.append(torch.cat([x_t.to(dt), ctrl.to(dt)], dim=0))
+        h, w = smp["hw"]
+        parts = [prepare_latent_image_ids(h, w)]
+        for j, (ch, cw) in enumerate(smp["control_hw"]):
+            ci = prepare_latent_image_ids(ch, cw)
+            ci[..., 0] = j + 1
+            parts.append(ci)
+        ids.append(torch.cat(parts, dim=0))
+        assert ids[-1].shape[0] == seqs[-1].shape[0]
+        n_t.append(x0.shape[0]); noises.append(noise); ts.append(t)
+    S_max, n_t_max = max(s.shape[0] for s in seqs), max(n_t)
+    T = txt["text_ids"].shape[0]
+    inp = torch.zeros(B, S_max, 64, device=dev, dtype=dt)
+    idb = torch.zeros(B, S_max, 3)
+    full = torch.ones(B, T + S_max, dtype=torch.bool)
+    tok_w = torch.zeros(B, n_t_max)
+    target = torch.zeros(B, n_t_max, 64, device=dev, dtype=dt)
+    for i in range(B):
+        L = seqs[i].shape[0]
+        inp[i, :L] = seqs[i]
+        idb[i, :L] = ids[i]
+        full[i, T + L:] = False
+        tok_w[i, : n_t[i]] = 1.0
+        target[i, : n_t[i]] = noises[i] - samples[i]["image_latents"].to(dev).to(dt)
+    timestep = torch.cat(ts)
+    guidance = torch.ones((B,), device=dev, dtype=dt) if step.dit.config.guidance_embeds else None
+    pe = txt["prompt_embeds"].to(dev).to(dt)
+    pooled = txt["pooled_prompt_embeds"].to(dev).to(dt)
+    return dict(inp=inp, ids=idb, mask=full, tok_w=tok_w.to(dev), target=target, timestep=timestep, guidance=guidance, pe=pe,
+                pooled=pooled, txt_ids=txt["text_ids"].float().cpu(), n_t_max=n_t_max, n_valid=float(sum(n_t)))
+
+
+def _compute_loss_multires(self, samples, txt):
+    """Autograd path: AttentionMaskMseLoss(reduction='mean') on the masked prediction (attention_mask_loss.py:146-226)."""
+    b = _build_multires_batch(self, samples, txt)
+    pred = self.dit(hidden_states=b["inp"], timestep=b["timestep"], guidance=b["guidance"], pooled_projections=b["pooled"],
+                    encoder_hidden_states=b["pe"], txt_ids=b["txt_ids"], img_ids=b["ids"], attention_mask=b["mask"],
+                    joint_attention_kwargs={}, return_dict=False)[0][:, : b["n_t_max"]]
+    el = (pred.float() - b["target"].float()) ** 2
+    tok = (el * b["tok_w"].unsqueeze(-1)).mean(dim=2)
+    return tok.sum() / (b["n_valid"] + 1e-12)
+
+
+def _forward_backward_multires(self, samples, txt, grad_scale=1.0):
+    b = _build_multires_batch(self, samples, txt)
+    dit = self.dit
+    B, S_i, T = b["inp"].shape[0], b["inp"].shape[1], b["pe"].shape[1]
+    valid = b["mask"][:, T:].sum(dim=1).tolist()
+    plan = dit.get_plan_multires(B, S_i, T, b["ids"], valid)
+    dit.lora_store
+    pred = plan.run_forward((b["inp"], b["pooled"], b["guidance"]), b["pe"], b["timestep"])
+    loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, b["target"], b["tok_w"].contiguous(), b["n_t_max"], 1.0 / (b["n_valid"] + 1e-12),
+                                                 gscale=grad_scale)
+    plan.run_backward(dpred)
+    return loss
+
+
+FluxKontextTrainStep.compute_loss_multires = _compute_loss_multires
+FluxKontextTrainStep.forward_backward_multires = _forward_backward_multires

@@ -392,6 +392,49 @@ def main():
                        "grad.hidden_states": gxr.contiguous(), "grad.single0_to_q_weight": gwr.contiguous(),
                        "w.checksum": weight_checksum(fm)}, os.path.join(HERE, "flux_tiny_fwd.safetensors"),
                       metadata={"cfg": repr(cfg), "weights": "common.fill_weights seed 3"})
+    # ---------------- FLUX multi-resolution: reference transformer_flux_custom.py vs oracle ----------------
+    try:
+        refc = importlib.import_module("qflux.models.transformer_flux_custom")
+        cfg = dict(FLUX_TINY, guidance_embeds=True)
+        cm = refc.FluxTransformer2DModel(**cfg).eval()
+        fill_weights(cm, seed=3)
+        fo = FO.OracleFluxDiT(**cfg)
+        fo.load_state_dict(cm.state_dict(), strict=True)
+        g = torch.Generator().manual_seed(41)
+        B, T = 2, 7
+        lens = [2 * 4 * 6, 4 * 6 + 3 * 5]            # sample 0: 4x6 target + 4x6 control ; sample 1: 4x6 + 3x5
+        S_max = max(lens)
+        x = torch.zeros(B, S_max, 64); idb = torch.zeros(B, S_max, 3)
+        full = torch.ones(B, T + S_max, dtype=torch.bool)
+        shapes = [[(4, 6), (4, 6)], [(4, 6), (3, 5)]]
+        for b in range(B):
+            x[b, : lens[b]] = torch.randn(lens[b], 64, generator=g)
+            ii = []
+            for j, (hh, ww) in enumerate(shapes[b]):
+                q = FO.prepare_latent_image_ids(hh, ww); q[:, 0] = j; ii.append(q)
+            idb[b, : lens[b]] = torch.cat(ii, 0)
+            full[b, T + lens[b]:] = False
+        pe = torch.randn(B, T, cfg["joint_attention_dim"], generator=g); pooled = torch.randn(B, cfg["pooled_projection_dim"], generator=g)
+        tt = torch.tensor([0.7109, 0.1611]); gd = torch.ones(B); txt_ids = torch.zeros(T, 3)
+        xr = x.clone().requires_grad_(True)
+        out = cm(hidden_states=xr, encoder_hidden_states=pe, pooled_projections=pooled, timestep=tt, img_ids=idb, txt_ids=txt_ids,
+                 guidance=gd, joint_attention_kwargs={}, return_dict=False, attention_mask=full)[0]
+        tgt = torch.randn(out.shape, generator=g)
+        (gxr,) = torch.autograd.grad(((out - tgt) ** 2).mean(), [xr])
+        xo = x.clone().requires_grad_(True)
+        oo = fo(hidden_states=xo, encoder_hidden_states=pe, pooled_projections=pooled, timestep=tt, img_ids=idb, txt_ids=txt_ids,
+                guidance=gd, attention_mask=full)[0]
+        (gxo,) = torch.autograd.grad(((oo - tgt) ** 2).mean(), [xo])
+        print("flux multi-res oracle vs reference custom model: fwd %.3e gx %.3e; padded output max %.1e" % (
+            (oo - out).abs().max().item(), (gxo - gxr).abs().max().item(), out[1, lens[1]:].abs().max().item()))
+        assert (oo - out).abs().max() < 1e-5 and (gxo - gxr).abs().max() < 1e-6
+        save_file({"in.hidden_states": x, "in.encoder_hidden_states": pe, "in.pooled": pooled, "in.timestep": tt, "in.img_ids": idb,
+                   "in.txt_ids": txt_ids, "in.attention_mask": full.to(torch.uint8), "in.target": tgt,
+                   "out.sample": out.detach().contiguous(), "grad.hidden_states": gxr.contiguous(), "w.checksum": weight_checksum(cm)},
+                  os.path.join(HERE, "flux_tiny_multires.safetensors"), metadata={"cfg": repr(cfg), "weights": "common.fill_weights seed 3"})
+    except Exception as e:  # noqa: BLE001
+        print("multi-res reference check FAILED:", repr(e))
+        raise
     print("wrote golden vectors to", HERE)
 
 

@@ -118,3 +118,37 @@ def test_flux_rope_identity_on_text_and_image_index():
     assert torch.equal(cos[5:17, 16:], cos[17:, 16:])                    # control image differs only on axis 0
     assert not torch.equal(cos[5:17, :16], cos[17:, :16])
     assert torch.equal(cos[:, 0::2], cos[:, 1::2])                       # repeat_interleave_real
+
+
+def test_flux_multires_matches_reference_custom_vectors(golden_dir):
+    """Ragged right-padded batch through the oracle vs vectors from the reference's transformer_flux_custom.py:
+    per-sample RoPE, additive key mask, padded rows zeroed after every block (flux_kontext_trainer.py:579-760 caller)."""
+    from common import FLUX_TINY
+    from oracle import flux_dit as FO
+    t = load_file(os.path.join(golden_dir, "flux_tiny_multires.safetensors"))
+    m = FO.OracleFluxDiT(**dict(FLUX_TINY, guidance_embeds=True))
+    fill_weights(m, seed=3)
+    assert torch.equal(weight_checksum(m), t["w.checksum"])
+    x = t["in.hidden_states"].clone().requires_grad_(True)
+    full = t["in.attention_mask"].bool()
+    out = m(hidden_states=x, encoder_hidden_states=t["in.encoder_hidden_states"], pooled_projections=t["in.pooled"],
+            timestep=t["in.timestep"], img_ids=t["in.img_ids"], txt_ids=t["in.txt_ids"], guidance=torch.ones(2), attention_mask=full)[0]
+    assert (out - t["out.sample"]).abs().max() < 1e-5
+    T = t["in.txt_ids"].shape[0]
+    pad = ~full[:, T:]
+    assert pad.any() and out[pad].abs().max() == 0
+    (gx,) = torch.autograd.grad(((out - t["in.target"]) ** 2).mean(), [x])
+    assert (gx - t["grad.hidden_states"]).abs().max() < 1e-6
+    assert gx[pad].abs().max() == 0
+
+
+def test_attention_mask_mse_loss_semantics():
+    """AttentionMaskMseLoss(reduction='mean') (losses/attention_mask_loss.py:146-226): masked per-token channel mean,
+    summed and divided by the number of valid tokens."""
+    from oracle import flux_dit as FO
+    g = torch.Generator().manual_seed(3)
+    p, q = torch.randn(2, 5, 8, generator=g), torch.randn(2, 5, 8, generator=g)
+    mk = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]], dtype=torch.bool)
+    want = sum(((p[b, :n] - q[b, :n]) ** 2).mean(dim=1).sum() for b, n in ((0, 3), (1, 5))) / 8
+    got = FO.attention_mask_mse_loss(p, q, mk)
+    assert abs(got.item() - want.item()) < 1e-6
