@@ -204,13 +204,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 
 
 // =============================================================================================
-// v2: 256x128x64 tile, 8 waves (4x2, each 64x64), ONE block per CU, 3-stage LDS-DMA ring with a
-// counted vmcnt (two K tiles in flight across the single barrier per K tile), grouped launch:
-// up to QFX_MAX_GROUPS independent problems (image/text streams, q/k/v) share one grid so the
-// small text-stream GEMMs ride along instead of running latency-bound on 72 tiles.
+// gemm256: 256x128x64 tiles, WARP-SPECIALISED and PERSISTENT.  One 640-thread block per CU:
+//   * waves 0..7  = compute (4x2, each 64x64 = 4x4 MFMA 16x16x32): ds_read_b128 + MFMA + epilogue only;
+//   * waves 8..9  = loaders: all LDS-DMA (global_load_lds_dwordx4) for the block, running up to two K tiles ahead
+//                   through a 3-stage ring and straight across output-tile boundaries.
+// One s_barrier per K tile joins the two roles ("tile f landed" + "everyone is done with tile f-1").  The compute
+// waves never wait on vmcnt, so their epilogue stores drain under the next tile's main loop, and the next tile's
+// first stages are already in LDS when the epilogue ends.  Measured (tools/gemm_lab/ws.hip vs abl.hip, warm,
+// paired): +12..21 % on the DiT shapes over the same tile with DMA issued from the compute waves.
+// Grid = whole rounds over <= 256 CUs (multiple of 8 so that bid % 8 stays the XCD); grouped launch: up to
+// QFX_MAX_GROUPS independent problems (image/text streams, q/k/v) share one tile list.
 constexpr int BM2 = 256;
 constexpr int STAGE_BYTES = (BM2 + BN) * BK * 2;  // 48 KiB
 constexpr int NSTAGE = 3;
+constexpr int NLD = 2;                            // loader waves
+constexpr int WS_THREADS = 512 + 64 * NLD;
+constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
+constexpr int QFX_NUM_CU = 256;                   // MI355X
 
 struct GroupedArgs {
   qfx_gemm_args g[QFX_MAX_GROUPS];
@@ -218,232 +228,265 @@ struct GroupedArgs {
   int n;
 };
 
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm256_kernel(const GroupedArgs ga) {
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES];
+// The argument block is read straight from the kernarg segment (constant address space, scalar loads): indexing the
+// by-value parameter with the run-time group id would make the compiler copy all of it to scratch.
+#define QFX_AS4 __attribute__((address_space(4)))
+typedef const QFX_AS4 GroupedArgs KGroupedArgs;
+typedef const QFX_AS4 qfx_gemm_args KArgs;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  int gi = 0;
+  gi = 0;
 #pragma unroll
   for (int i = 1; i < QFX_MAX_GROUPS; ++i)
     if (i < ga.n && swz >= ga.tile_start[i]) gi = i;
-  const qfx_gemm_args& p = ga.g[gi];
   const int lt = swz - ga.tile_start[gi];
   // supertile order: consecutive tile ids walk 8 M-tiles before the next N-tile, so the ~32 tiles an XCD runs at
   // a time form an 8(M) x 4(N) patch that shares A rows and B rows in that XCD's L2.
-  const int tiles_m = (p.M + BM2 - 1) / BM2, tiles_n = (p.N + BN - 1) / BN;
+  const int M = ga.g[gi].M, N = ga.g[gi].N;
+  const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + BN - 1) / BN;
   constexpr int GM = 8;
   const int per = GM * tiles_n, sg = lt / per, first = sg * GM;
   const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
   const int in = lt - sg * per;
-  const int m0 = (first + in % gsz) * BM2;
-  const int n0 = (in / gsz) * BN;
+  m0 = (first + in % gsz) * BM2;
+  n0 = (in / gsz) * BN;
+}
 
-  const int srow = lane >> 3;
-  const int schunk = lane & 7;
-  const bf16_t* pa[4];
-  const bf16_t* pb[2];
-  int a_row[4], b_row[2], sca[4], scb[2];
+template <int EPI>
+__global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArgs ga_by_value) {
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];  // 160 KiB
+  KGroupedArgs& ga = *(KGroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // == ga_by_value (sole explicit argument)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = ga.tile_start[QFX_MAX_GROUPS];
+
+  if (w >= 8) {
+    // ================================================================ loader waves
+    const int lw = w - 8;
+    constexpr int NA = 32 / NLD, NB = 16 / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
+    static_assert(NLD == 2 && NA + NB == 24, "vmcnt immediates below assume 24 pieces per K tile per loader wave");
+    const int srow = lane >> 3, schunk = lane & 7;
+    // source column incl. the bank swizzle chunk ^ ((row>>1)&7); with NLD == 2 it is the same for every piece
+    const int sc = (schunk ^ ((lw * 4 + (srow >> 1)) & 7)) * 8;
+    const bf16_t* pa[NA];
+    const bf16_t* pb[NB];
+    int ra[NA], rb[NB];
+    int ibid = blockIdx.x, it = 0, int1 = 0, intt = 0, ist = 0;
+    const bf16_t* iA2 = nullptr; const bf16_t* iB2 = nullptr;
+    int ilda2 = 0, ildb2 = 0;
+    auto setp = [&](int bid) {
+      int gi, m0, n0;
+      tile_coord(ga, nwg, bid, gi, m0, n0);
+      KArgs& p = ga.g[gi];
+      int1 = p.K1 / BK; intt = int1 + p.K2 / BK;
+      iA2 = p.A2; iB2 = p.B2; ilda2 = p.lda2; ildb2 = p.ldb2;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int lr = w * 32 + i * 8 + srow;
-    sca[i] = (schunk ^ ((lr >> 1) & 7)) * 8;
-    int gm = m0 + lr; gm = gm < p.M ? gm : p.M - 1;
-    a_row[i] = gm;
-    pa[i] = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1 + sca[i];
+      for (int i = 0; i < NA; ++i) {
+        int gm = m0 + (lw + i * NLD) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
+        ra[i] = gm;
+        pa[i] = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1 + sc;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int gn = n0 + (lw + i * NLD) * 8 + srow; gn = gn < p.N ? gn : p.N - 1;
+        rb[i] = gn;
+        pb[i] = p.B1 + (int64_t)gn * p.ldb1 + sc;
+      }
+    };
+    bool more = true;
+    auto issue = [&]() {
+      if (it == int1) {  // first K tile of the LoRA segment (A2 rows are never remapped)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) pa[i] = iA2 + (int64_t)ra[i] * ilda2 + sc;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) pb[i] = iB2 + (int64_t)rb[i] * ildb2 + sc;
+      }
+      char* sA = smem + ist * STAGE_BYTES;
+      char* sB = sA + BM2 * BK * 2;
+      const int koff = (it < int1 ? it : it - int1) * BK;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) glds16(pb[i] + koff, sB + (lw + i * NLD) * 1024);
+      ist = ist + 1 == NSTAGE ? 0 : ist + 1;
+      if (++it == intt) {
+        it = 0; ibid += gridDim.x; more = ibid < nwg;
+        if (more) setp(ibid);
+      }
+    };
+    setp(ibid);
+    int ahead = 0;  // K tiles issued and not yet handed over
+    issue(); ++ahead;
+    if (more) { issue(); ++ahead; }
+    for (int wbid = blockIdx.x; wbid < nwg; wbid += gridDim.x) {
+      int gi, m0, n0;
+      tile_coord(ga, nwg, wbid, gi, m0, n0);
+      const int ntw = ga.g[gi].K1 / BK + ga.g[gi].K2 / BK;
+      for (int t = 0; t < ntw; ++t) {
+        // the oldest K tile in flight must have landed; the one issued after it may still be in flight
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        --ahead;
+        if (more) { issue(); ++ahead; }   // into the stage every compute wave left before this barrier
+      }
+    }
+    return;
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lr = w * 16 + i * 8 + srow;
-    scb[i] = (schunk ^ ((lr >> 1) & 7)) * 8;
-    int gn = n0 + lr; gn = gn < p.N ? gn : p.N - 1;
-    b_row[i] = gn;
-    pb[i] = p.B1 + (int64_t)gn * p.ldb1 + scb[i];
-  }
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
+  // ================================================================== compute waves
+  const int wr = w >> 1, wc = w & 1;
   const int g = lane >> 4, li = lane & 15;
-
-  auto stage = [&](int t, int buf) {
-    if (t == nt1) {  // switch to the LoRA K segment (A2 rows are never remapped)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pa[i] = p.A2 + (int64_t)a_row[i] * p.lda2 + sca[i];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) pb[i] = p.B2 + (int64_t)b_row[i] * p.ldb2 + scb[i];
-    }
-    char* sA = smem + buf * STAGE_BYTES;
-    char* sB = sA + BM2 * BK * 2;
-    const int koff = (t < nt1 ? t : t - nt1) * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(pa[i] + koff, sA + (w * 32 + i * 8) * (BK * 2));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(pb[i] + koff, sB + (w * 16 + i * 8) * (BK * 2));
-  };
-
-  stage(0, 0);
-  if (nt > 1) stage(1, 1);
+  char* stg = smem + NSTAGE * STAGE_BYTES + w * STG_BYTES;
   int buf = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int nb = buf + 2; nb = nb >= NSTAGE ? nb - NSTAGE : nb;
-    const bool pre = t + 2 < nt;
-    if (pre && t + 2 == nt1) {  // switch the DMA source to the LoRA K segment (A2 rows are never remapped)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pa[i] = p.A2 + (int64_t)a_row[i] * p.lda2 + sca[i];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) pb[i] = p.B2 + (int64_t)b_row[i] * p.ldb2 + scb[i];
-    }
-    const int koff2 = ((t + 2) < nt1 ? (t + 2) : (t + 2) - nt1) * BK;
-    char* dA = smem + nb * STAGE_BYTES;
-    char* dB = dA + BM2 * BK * 2;
-    const char* sA = smem + buf * STAGE_BYTES;
-    const char* sB = sA + BM2 * BK * 2;
-    auto rdA = [&](int kk, int mi) {
-      const int row = wr * 64 + mi * 16 + li; const int chunk = kk * 4 + g;
-      return *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
-    };
-    auto rdB = [&](int kk, int ni) {
-      const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
-      return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
-    };
-    // software pipeline: the second k-step's fragments and the DMA of tile t+2 are issued between the MFMAs
-    // of the first k-step (sched_barrier pins the interleave); measured +8..12 % over compiler order.
-    bf16x8 a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-      a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
-      if (pre) {
-        glds16(pa[mi] + koff2, dA + (w * 32 + mi * 8) * (BK * 2));
-        if (mi < 2) glds16(pb[mi] + koff2, dB + (w * 16 + mi * 8) * (BK * 2));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-    if (nt2 > 0 && !p.seg2_plain && t == nt1 - 1) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + 4 * g;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr && n + 3 < p.N) {
-          const bf16x4 bb = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
-      }
-    }
-    buf = buf + 1 == NSTAGE ? 0 : buf + 1;
-  }
+  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    int gi, m0, n0;
+    tile_coord(ga, nwg, bid, gi, m0, n0);
+    KArgs& p = ga.g[gi];
+    const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
 
-  // ---- epilogue, stage 1: bf16(acc + bias) -- the nn.Linear output, first rounding point of every epilogue --
-  // goes to an LDS image of the C tile so that stage 2 can use full-row 16-byte global accesses
-  // (the MFMA layout would give 8-byte pieces scattered over 16 rows per store instruction).
-  constexpr int CROW = BN * 2 + 16;  // padded row stride (bytes)
-  const bool bias_pending = (p.bias != nullptr) && (nt2 == 0 || p.seg2_plain);
-  __syncthreads();
+    f32x4 acc[4][4];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int nl = wc * 64 + ni * 16 + 4 * g;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias_pending && n0 + nl + 3 < p.N) {
-      const bf16x4 bb = *(const bf16x4*)(p.bias + n0 + nl);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nt; ++t) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sA = smem + buf * STAGE_BYTES;
+      const char* sB = sA + BM2 * BK * 2;
+      auto rdA = [&](int kk, int mi) {
+        const int row = wr * 64 + mi * 16 + li; const int chunk = kk * 4 + g;
+        return *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+      };
+      auto rdB = [&](int kk, int ni) {
+        const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
+        return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+      };
+      // software pipeline: the second k-step's fragments are read between the MFMAs of the first k-step
+      bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+        a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+      if (nt2 > 0 && !p.seg2_plain && t == nt1 - 1) {
+        // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias != nullptr && n + 3 < p.N) {
+            const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
+          }
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
+        }
+      }
+      buf = buf + 1 == NSTAGE ? 0 : buf + 1;
     }
+
+    // ---- epilogue (no block barrier): per 16-row pass the wave stages bf16(acc + bias) -- the nn.Linear output, first
+    // rounding point of every epilogue -- in its private 2 KiB of LDS (8-byte unit u = ni*4+g of row li stored at
+    // u ^ 2*(li>>1): conflict-free writes, 16-byte pairs stay adjacent) and reads it back row-contiguous, so global
+    // accesses are full 128-byte row segments instead of 8-byte pieces scattered over 16 rows.
+    const bool bias_pending = (p.bias != nullptr) && (nt2 == 0 || p.seg2_plain);
+    float bv[4][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int ml = wr * 64 + mi * 16 + li;
-      u32x2 u;
-      u[0] = pack2bf(acc[mi][ni][0] + bv[0], acc[mi][ni][1] + bv[1]);
-      u[1] = pack2bf(acc[mi][ni][2] + bv[2], acc[mi][ni][3] + bv[3]);
-      *(u32x2*)(smem + ml * CROW + nl * 2) = u;
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[ni][r] = 0.f;
+      if (bias_pending && n + 3 < p.N) {
+        const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[ni][r] = bf2f((bf16_t)bb[r]);
+      }
     }
-  }
-  __syncthreads();
-  // ---- stage 2: thread -> (row tid/16 + 32 i, 16-byte chunk tid%16); a wave covers 4 full 256-byte rows
-  const int ch = tid & 15;
-  const int n = n0 + ch * 8;
-  if (n + 7 < p.N) {
+    const int ch = lane & 7;
+    const int n = n0 + wc * 64 + ch * 8;
+    const bool n_ok = n + 7 < p.N;
     float gt[8];
     int last_b = -1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ml = (tid >> 4) + 32 * i;
-      const int m = m0 + ml;
-      if (m >= p.M) continue;
-      const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
-      if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        *(u32x4*)(p.C + crow * p.ldc + n) = z;
-        if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
-        continue;
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        u32x2 u;
+        u[0] = pack2bf(acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]);
+        u[1] = pack2bf(acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]);
+        *(u32x2*)(stg + li * 128 + (((ni * 4 + g) ^ ((li >> 1) << 1)) << 3)) = u;
       }
-      const u32x4 yv = *(const u32x4*)(smem + ml * CROW + ch * 16);
-      float y[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { y[2 * q] = __uint_as_float(yv[q] << 16); y[2 * q + 1] = __uint_as_float(yv[q] & 0xffff0000u); }
-      if constexpr (EPI == QFX_EPI_NONE) {
-        *(u32x4*)(p.C + crow * p.ldc + n) = yv;
-      } else if constexpr (EPI == QFX_EPI_GELU) {
-        u32x4 o2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
-        *(u32x4*)(p.C + crow * p.ldc + n) = yv;
-        *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
-      } else if constexpr (EPI == QFX_EPI_GATE_RES) {
-        const int bidx = m / p.rows_per_batch;
-        if (bidx != last_b) {
-          const u32x4 gv = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { gt[2 * q] = __uint_as_float(gv[q] << 16); gt[2 * q + 1] = __uint_as_float(gv[q] & 0xffff0000u); }
-          last_b = bidx;
+      for (int j = 0; j < 2; ++j) {
+        const int row = (lane >> 3) + 8 * j;
+        const u32x4 yv = *(const u32x4*)(stg + row * 128 + ((ch ^ (row >> 1)) << 4));
+        const int m = m0 + wr * 64 + mi * 16 + row;
+        if (m >= p.M || !n_ok) continue;
+        const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+        if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          *(u32x4*)(p.C + crow * p.ldc + n) = z;
+          if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
+          continue;
         }
-        const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
-        u32x4 o;
+        float y[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float r0 = __uint_as_float(rv[q] << 16), r1 = __uint_as_float(rv[q] & 0xffff0000u);
-          o[q] = pack2bf(r0 + rbf(gt[2 * q] * y[2 * q]), r1 + rbf(gt[2 * q + 1] * y[2 * q + 1]));
-        }
-        *(u32x4*)(p.C + crow * p.ldc + n) = o;
-      } else {  // QFX_EPI_DGELU
-        const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
-        u32x4 o;
+        for (int q = 0; q < 4; ++q) { y[2 * q] = __uint_as_float(yv[q] << 16); y[2 * q + 1] = __uint_as_float(yv[q] & 0xffff0000u); }
+        if constexpr (EPI == QFX_EPI_NONE) {
+          *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+        } else if constexpr (EPI == QFX_EPI_GELU) {
+          u32x4 o2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float h0 = __uint_as_float(hv[q] << 16), h1 = __uint_as_float(hv[q] & 0xffff0000u);
-          o[q] = pack2bf(y[2 * q] * gelu_tanh_grad_f(h0), y[2 * q + 1] * gelu_tanh_grad_f(h1));
+          for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
+          *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+          *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+        } else if constexpr (EPI == QFX_EPI_GATE_RES) {
+          const int bidx = m / p.rows_per_batch;
+          if (bidx != last_b) {
+            const u32x4 gv = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { gt[2 * q] = __uint_as_float(gv[q] << 16); gt[2 * q + 1] = __uint_as_float(gv[q] & 0xffff0000u); }
+            last_b = bidx;
+          }
+          const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+          u32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float r0 = __uint_as_float(rv[q] << 16), r1 = __uint_as_float(rv[q] & 0xffff0000u);
+            o[q] = pack2bf(r0 + rbf(gt[2 * q] * y[2 * q]), r1 + rbf(gt[2 * q + 1] * y[2 * q + 1]));
+          }
+          *(u32x4*)(p.C + crow * p.ldc + n) = o;
+        } else {  // QFX_EPI_DGELU
+          const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+          u32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float h0 = __uint_as_float(hv[q] << 16), h1 = __uint_as_float(hv[q] & 0xffff0000u);
+            o[q] = pack2bf(y[2 * q] * gelu_tanh_grad_f(h0), y[2 * q + 1] * gelu_tanh_grad_f(h1));
+          }
+          *(u32x4*)(p.C + crow * p.ldc + n) = o;
         }
-        *(u32x4*)(p.C + crow * p.ldc + n) = o;
       }
     }
   }
@@ -488,11 +531,16 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
   for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
   ga.n = n;
   hipStream_t s = (hipStream_t)stream;
+  // balanced persistent grid: whole rounds over <= 256 CUs, multiple of 8 (one residue class per XCD)
+  const int rounds = (tiles + QFX_NUM_CU - 1) / QFX_NUM_CU;
+  int grid = (((tiles + rounds - 1) / rounds) + 7) & ~7;
+  if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
+  if (grid > tiles) grid = tiles;
   switch (groups[0].epi) {
-    case QFX_EPI_NONE: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_NONE>, dim3(tiles), dim3(512), 0, s, ga); break;
-    case QFX_EPI_GELU: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GELU>, dim3(tiles), dim3(512), 0, s, ga); break;
-    case QFX_EPI_GATE_RES: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GATE_RES>, dim3(tiles), dim3(512), 0, s, ga); break;
-    default: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_DGELU>, dim3(tiles), dim3(512), 0, s, ga); break;
+    case QFX_EPI_NONE: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_NONE>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    case QFX_EPI_GELU: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GELU>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    case QFX_EPI_GATE_RES: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GATE_RES>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    default: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_DGELU>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
   }
   QFX_CHECK_LAUNCH();
   return QFX_OK;

@@ -1,0 +1,230 @@
+// Warp-specialised GEMM lab (NOT product): 8 compute waves (4x2, 64x64 each) + NLD loader waves, persistent tiles,
+// 3-stage 256x128x64 LDS-DMA ring, wave-private LDS staging for a row-contiguous epilogue.  C = A B^T (bf16).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  bf2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
+  __builtin_amdgcn_global_load_lds((const AS1 void*)g, (AS3 void*)lds, 16, 0, 0);
+}
+constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
+constexpr int STAGE = (BM + BN) * BK * 2;
+
+#include <type_traits>
+template <int NLD, int EPI, int DEFER_EVERY = 2, int ROT = 0, int GM = 8>   // EPI 0: LDS-staged row stores, 1: none, 2: deferred into the next tile's k loop
+__global__ __launch_bounds__(512 + 64 * NLD, 1) void kws(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                          bf16_t* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 8 * 2048];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  const int nt = K / BK;
+  auto tile_of = [&](int bid, int& m0, int& n0) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int per = GM * tiles_n; const int grp_ = swz / per; const int first = grp_ * GM;
+    const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
+    const int in = swz - grp_ * per;
+    m0 = (first + in % gsz) * BM; n0 = (in / gsz) * BN;
+  };
+  const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+  if (w >= 8) {
+    // ------------------------------------------------ loader waves
+    const int lw = w - 8;
+    constexpr int NA = 32 / NLD, NB = 16 / NLD;
+    const int srow = lane >> 3, schunk = lane & 7;
+    const bf16_t* pa[NA]; const bf16_t* pb[NB];
+    int ibid = blockIdx.x, it = 0;
+    const int rot = ROT ? ((int)(blockIdx.x & 7) * nt) / 8 : 0;
+    auto setp = [&](int bid) {
+      int m0, n0; tile_of(bid, m0, n0);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int lr = (lw + i * NLD) * 8 + srow;
+        int gm = m0 + lr; gm = gm < M ? gm : M - 1;
+        pa[i] = A + (int64_t)gm * K + (schunk ^ ((lr >> 1) & 7)) * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int lr = (lw + i * NLD) * 8 + srow;
+        int gn = n0 + lr; gn = gn < N ? gn : N - 1;
+        pb[i] = B + (int64_t)gn * K + (schunk ^ ((lr >> 1) & 7)) * 8;
+      }
+    };
+    setp(ibid);
+    int ist = 0;   // stage of the next issue
+    auto issue = [&]() {
+      char* sA = smem + ist * STAGE; char* sB = sA + BM * 128;
+      int kt = it + rot; kt = kt >= nt ? kt - nt : kt;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) glds16(pa[i] + kt * BK, sA + (lw + i * NLD) * 1024);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) glds16(pb[i] + kt * BK, sB + (lw + i * NLD) * 1024);
+      ist = ist + 1 == NST ? 0 : ist + 1;
+      if (++it == nt) { it = 0; ibid += gridDim.x; if (ibid < nwg) setp(ibid); }
+    };
+    const int total = my_tiles * nt;
+    int issued = 0;
+    if (issued < total) { issue(); ++issued; }
+    if (issued < total) { issue(); ++issued; }
+    for (int f = 0; f < total; ++f) {
+      // k-tile f must have landed; at most the one issue after it may be in flight
+      if (issued > f + 1) { if constexpr (NA + NB == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else if constexpr (NA + NB == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (issued < total) { issue(); ++issued; }
+    }
+    return;
+  }
+
+  // -------------------------------------------------- compute waves
+  const int wr = w >> 1, wc = w & 1;
+  const int g = lane >> 4, li = lane & 15;
+  char* stg = smem + NST * STAGE + w * 2048;
+  int buf = 0;
+  u32x2 cp[4][4];
+  int next_pass = 4, pm0 = 0, pn0 = 0;
+  auto pass = [&](auto MI) {
+    constexpr int mi = decltype(MI)::value;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) *(u32x2*)(stg + li * 128 + (((ni * 4 + g) ^ ((li >> 1) << 1)) << 3)) = cp[mi][ni];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (lane >> 3) + 8 * j, c = lane & 7;
+      const u32x4 v = *(const u32x4*)(stg + row * 128 + ((c ^ (row >> 1)) << 4));
+      const int m = pm0 + wr * 64 + mi * 16 + row, n = pn0 + wc * 64 + c * 8;
+      if (m < M && n + 7 < N) *(u32x4*)(C + (int64_t)m * N + n) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto pass_rt = [&](int q) {
+    switch (q) {
+      case 0: pass(std::integral_constant<int, 0>{}); break;
+      case 1: pass(std::integral_constant<int, 1>{}); break;
+      case 2: pass(std::integral_constant<int, 2>{}); break;
+      default: pass(std::integral_constant<int, 3>{}); break;
+    }
+  };
+  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+    int m0, n0; tile_of(bid, m0, n0);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sA = smem + buf * STAGE; const char* sB = sA + BM * 128;
+      auto rdA = [&](int kk, int mi) {
+        const int row = wr * 64 + mi * 16 + li; const int chunk = kk * 4 + g;
+        return *(const bf16x8*)(sA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      };
+      auto rdB = [&](int kk, int ni) {
+        const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
+        return *(const bf16x8*)(sB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      };
+      bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+        a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+      // all LDS reads of this k-tile were consumed by the MFMAs above before the wave can reach the next barrier
+      buf = buf + 1 == NST ? 0 : buf + 1;
+      if constexpr (EPI == 2) {
+        if (next_pass < 4 && (t & (DEFER_EVERY - 1)) == DEFER_EVERY - 1) { pass_rt(next_pass); ++next_pass; }
+      }
+    }
+    if constexpr (EPI == 2) {
+      while (next_pass < 4) { pass_rt(next_pass); ++next_pass; }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          cp[mi][ni][0] = pack2bf(acc[mi][ni][0], acc[mi][ni][1]);
+          cp[mi][ni][1] = pack2bf(acc[mi][ni][2], acc[mi][ni][3]);
+        }
+      next_pass = 0; pm0 = m0; pn0 = n0;
+    }
+    if constexpr (EPI == 0) {
+      // wave-private staging: 16 rows x 64 cols per pass; unit(8 B) u = ni*4+g stored at u ^ (2*(li>>1))
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          u32x2 u;
+          u[0] = pack2bf(acc[mi][ni][0], acc[mi][ni][1]);
+          u[1] = pack2bf(acc[mi][ni][2], acc[mi][ni][3]);
+          *(u32x2*)(stg + li * 128 + (((ni * 4 + g) ^ ((li >> 1) << 1)) << 3)) = u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = (lane >> 3) + 8 * j, c = lane & 7;
+          const u32x4 v = *(const u32x4*)(stg + row * 128 + ((c ^ (row >> 1)) << 4));
+          const int m = m0 + wr * 64 + mi * 16 + row, n = n0 + wc * 64 + c * 8;
+          if (m < M && n + 7 < N) *(u32x4*)(C + (int64_t)m * N + n) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else if constexpr (EPI == 1) {
+      float s = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) s += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+      if (s == 123.456f) C[0] = 1;
+    }
+  }
+  if constexpr (EPI == 2) { while (next_pass < 4) { pass_rt(next_pass); ++next_pass; } }
+}
+
+extern "C" int lab_gemm(int var, const void* A, const void* B, void* C, int M, int N, int K, int GRID, void* stream) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B; bf16_t* c = (bf16_t*)C;
+  int grid = GRID;
+  if (GRID <= 0) { const int rounds = (tiles + 255) / 256; grid = (((tiles + rounds - 1) / rounds) + 7) & ~7; if (grid > 256) grid = 256; }
+  if (grid > tiles) grid = tiles;
+  switch (var) {
+    case 0: hipLaunchKernelGGL((kws<2, 0>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 1: hipLaunchKernelGGL((kws<4, 0>), dim3(grid), dim3(768), 0, s, a, b, c, M, N, K); break;
+    case 2: hipLaunchKernelGGL((kws<2, 1>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 3: hipLaunchKernelGGL((kws<4, 1>), dim3(grid), dim3(768), 0, s, a, b, c, M, N, K); break;
+    case 5: hipLaunchKernelGGL((kws<2, 2, 2>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 6: hipLaunchKernelGGL((kws<4, 2, 2>), dim3(grid), dim3(768), 0, s, a, b, c, M, N, K); break;
+    case 7: hipLaunchKernelGGL((kws<2, 2, 4>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 8: hipLaunchKernelGGL((kws<2, 2, 1>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 10: hipLaunchKernelGGL((kws<2, 0, 2, 1, 8>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 11: hipLaunchKernelGGL((kws<2, 0, 2, 0, 4>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 12: hipLaunchKernelGGL((kws<2, 0, 2, 1, 4>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 13: hipLaunchKernelGGL((kws<2, 0, 2, 0, 2>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 14: hipLaunchKernelGGL((kws<2, 0, 2, 0, 16>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 4: hipLaunchKernelGGL((kws<1, 0>), dim3(grid), dim3(576), 0, s, a, b, c, M, N, K); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
