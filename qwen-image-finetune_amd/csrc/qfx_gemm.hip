@@ -355,7 +355,29 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Rotated K loop: the second k-step of K tile t-1 is issued AFTER barrier t, under the first fragment reads of
+    // tile t, so the matrix pipe does not drain while the post-barrier ds_reads are in flight (+2..6 % in the lab).
+    auto round_base = [&]() {
+      // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr && n + 3 < p.N) {
+          const bf16x4 bb = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
+      }
+    };
+    const bool mid_round = nt2 > 0 && !p.seg2_plain;
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
     for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of tile t-1 has returned: its stage may be refilled
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const char* sA = smem + buf * STAGE_BYTES;
@@ -368,10 +390,17 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
         return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
       };
-      // software pipeline: the second k-step's fragments are read between the MFMAs of the first k-step
-      bf16x8 a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+        if (mid_round && t == nt1) round_base();
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
@@ -381,30 +410,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
         __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-      if (nt2 > 0 && !p.seg2_plain && t == nt1 - 1) {
-        // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int n = n0 + wc * 64 + ni * 16 + 4 * g;
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias != nullptr && n + 3 < p.N) {
-            const bf16x4 bb = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
-          }
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
-        }
-      }
       buf = buf + 1 == NSTAGE ? 0 : buf + 1;
     }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
 
     // ---- epilogue (no block barrier): per 16-row pass the wave stages bf16(acc + bias) -- the nn.Linear output, first
     // rounding point of every epilogue -- in its private 2 KiB of LDS (8-byte unit u = ni*4+g of row li stored at

@@ -21,7 +21,7 @@ constexpr int BM = 256, BN = 128, BK = 64, NST = 3;
 constexpr int STAGE = (BM + BN) * BK * 2;
 
 #include <type_traits>
-template <int NLD, int EPI, int DEFER_EVERY = 2, int ROT = 0, int GM = 8>   // EPI 0: LDS-staged row stores, 1: none, 2: deferred into the next tile's k loop
+template <int NLD, int EPI, int DEFER_EVERY = 2, int ROT = 0, int GM = 8, int ABLW = 0>   // EPI 0: LDS-staged row stores, 1: none, 2: deferred into the next tile's k loop
 __global__ __launch_bounds__(512 + 64 * NLD, 1) void kws(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                           bf16_t* __restrict__ C, int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE + 8 * 2048];
@@ -125,6 +125,46 @@ __global__ __launch_bounds__(512 + 64 * NLD, 1) void kws(const bf16_t* __restric
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (ABLW & 8) {
+      // rotated loop: the second k-step of tile t-1 runs AFTER barrier t, under the first fragment reads of tile t
+      bf16x8 a0[4], b0[4], a1[4], b1[4];
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sA = smem + buf * STAGE; const char* sB = sA + BM * 128;
+        auto rdA = [&](int kk, int mi) {
+          const int row = wr * 64 + mi * 16 + li; const int chunk = kk * 4 + g;
+          return *(const bf16x8*)(sA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        };
+        auto rdB = [&](int kk, int ni) {
+          const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
+          return *(const bf16x8*)(sB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+          a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+    } else
     for (int t = 0; t < nt; ++t) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -138,14 +178,17 @@ __global__ __launch_bounds__(512 + 64 * NLD, 1) void kws(const bf16_t* __restric
         return *(const bf16x8*)(sB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       };
       bf16x8 a0[4], b0[4], a1[4], b1[4];
+      if ((ABLW & 1) == 0 || (t == 0)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ABLW & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-        a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+        if ((ABLW & 1) == 0 || (t == 0)) { a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi); }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -223,6 +266,9 @@ extern "C" int lab_gemm(int var, const void* A, const void* B, void* C, int M, i
     case 12: hipLaunchKernelGGL((kws<2, 0, 2, 1, 4>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
     case 13: hipLaunchKernelGGL((kws<2, 0, 2, 0, 2>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
     case 14: hipLaunchKernelGGL((kws<2, 0, 2, 0, 16>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 20: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 1>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 21: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 4>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 22: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 8>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
     case 4: hipLaunchKernelGGL((kws<1, 0>), dim3(grid), dim3(576), 0, s, a, b, c, M, N, K); break;
     default: return -1;
   }
