@@ -22,7 +22,14 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
 }
 
 template <int DH> __device__ __forceinline__ int swz_row(int row) {
-  if constexpr (DH == 128) return row & 15; else return (row >> 1) & 7;
+  // DH == 128 (256-byte rows, 16 chunks).  f(r) = (m << 1) | h with h = (r>>3)&1, m = (r&7) ^ (h<<2) satisfies both
+  // access patterns on 64 banks:
+  //  * ds_read_b128 is serviced in 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}: rows A={0-3,12-15} at chunk c
+  //    together with rows B={4-11} at chunk c^1.  f(A) = {0..7}, f(B) = {8..15} are both closed under ^1, so the two
+  //    halves never share a 16-byte slot;
+  //  * the transpose read (8 aligned consecutive rows x 32 bytes per 32-lane group) needs f(r)>>1 distinct over r&7.
+  if constexpr (DH == 128) { const int h = (row >> 3) & 1; return ((((row & 7) ^ (h << 2)) << 1) | h); }
+  else return (row >> 1) & 7;
 }
 
 // 64 rows x DH tile of a token-major tensor (rows s0..s0+63 clamped to S-1) -> LDS [64][DH], swizzled.
@@ -449,14 +456,32 @@ __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
 }
 
 // =============================================================================================
-// dK, dV: block = 256 keys (8 waves x 32), loop over 64-query tiles (Q, dO row tiles + Q^T, dO^T column tiles).
-// 32 keys per wave halves the LDS fragment traffic per MFMA versus 16; the 8 waves share every staged query
-// tile; K fragments live in registers, V fragments are re-read from a resident LDS copy of the block's V rows.
+// Transposed fragment of a ROW-major [64][DH] tile through the hardware transpose read (ds_read_b64_tr_b16):
+// lane (g, li) receives X[q][16*df + li] for the 8 rows q = {32t+4g+j, 32t+16+4g+j}, j<4 -- the pi order of the packed
+// P / dS registers.  Source lane 16g + 4j' + m supplies the address of X[q0+j'][16*df+4m .. +3]; the instruction hands
+// lane (g, li) element li&3 of source lane 4j + (li>>2), j = 0..3 (mapping verified by qfx_debug_tr_read).
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+template <int DH>
+__device__ __forceinline__ bf16x8 read_trfrag(const char* tile, int df, int t, int g, int li) {
+  const int col = 16 * df + 4 * (li & 3);
+  const int chunk = col >> 3, off = (col & 7) * 2;
+  const int r1 = 32 * t + 4 * g + (li >> 2), r2 = r1 + 16;
+  const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(tile + r1 * (DH * 2) + ((chunk ^ swz_row<DH>(r1)) << 4) + off));
+  const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(tile + r2 * (DH * 2) + ((chunk ^ swz_row<DH>(r2)) << 4) + off));
+  return cat8(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi));
+}
+
+// =============================================================================================
+// dK, dV: block = 256 keys (8 waves x 32), loop over 64-query tiles of Q and dO (row-major, DOUBLE-BUFFERED by LDS-DMA:
+// tile it+1 streams in under the MFMAs of tile it, one barrier per tile).  The contractions over queries
+// (dV = P^T dO, dK = dS^T Q) read their A operands from the same row-major tiles with the transpose read, so no
+// transposed copies of Q / dO exist in HBM or LDS.  lse2 / dsum of the tile ride along by 4-byte LDS-DMA.
+// K fragments live in registers, V fragments are re-read from a resident LDS copy of the block's V rows.
 template <int DH>
 __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_args a) {
   constexpr int KC = DH / 32, DF = DH / 16, NW = 8;
   constexpr int TB = 64 * DH * 2;
-  __shared__ __attribute__((aligned(16))) char smem[8 * TB];   // [Q | dO | Q^T | dO^T | V(4 tiles of 64 keys)]
+  __shared__ __attribute__((aligned(16))) char smem[8 * TB + 1024];   // V(4 tiles of 64 keys) | 2 x [Q | dO] | 2 x [lse2 | dsum]
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -467,16 +492,32 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
   const bf16_t* Qb = a.Q + (int64_t)b * S * a.ldq + h * DH;
   const bf16_t* dOb = a.dO + (int64_t)b * S * a.lddo + h * DH;
   const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
-  const bf16_t* Qtb = a.Qt + ((int64_t)b * a.H + h) * DH * a.S_pad;
-  const bf16_t* dOtb = a.dOt + ((int64_t)b * a.H + h) * DH * a.S_pad;
   const float* lseb = a.lse2 + ((int64_t)b * a.H + h) * a.S_pad;
   const float* dsb = a.dsum + ((int64_t)b * a.H + h) * a.S_pad;
-  char* sQ = smem; char* sdO = smem + TB; char* sQt = smem + 2 * TB; char* sdOt = smem + 3 * TB;
-  char* sV = smem + 4 * TB;
+  char* sV = smem;
+  char* sStage = smem + 4 * TB;
+  char* sStat = smem + 8 * TB;
   const char* myV = sV + (w >> 1) * TB;    // 64-key tile holding this wave's 32 keys (fragments (w&1)*2 + {0,1})
 
+  // DMA sources as uniform base + 32-bit lane offset (rows past S clamp to S-1); nothing 64-bit stays live per lane
+  constexpr int CPR = DH / 8, RPI = 64 / CPR, RPW = 64 / NW, NIS = RPW / RPI;
+  auto stage = [&](int it, int buf) {
+    const int i0 = it * 64;
+    char* dQ_ = sStage + buf * 2 * TB;
+#pragma unroll
+    for (int i = 0; i < NIS; ++i) {
+      const int row = w * RPW + i * RPI + lane / CPR;
+      const int sc8 = ((lane % CPR) ^ swz_row<DH>(row)) * 8;
+      int sr = i0 + row; sr = sr < S ? sr : S - 1;
+      glds16(Qb + (unsigned)(sr * a.ldq + sc8), dQ_ + (w * RPW + i * RPI) * (DH * 2));
+      glds16(dOb + (unsigned)(sr * a.lddo + sc8), dQ_ + TB + (w * RPW + i * RPI) * (DH * 2));
+    }
+    if (w == 0) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(lseb + i0 + lane), (QFX_AS3 void*)(sStat + buf * 512), 4, 0, 0);
+    if (w == 1) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(dsb + i0 + lane), (QFX_AS3 void*)(sStat + buf * 512 + 256), 4, 0, 0);
+  };
 #pragma unroll
   for (int i = 0; i < 4; ++i) stage_rows_n<DH, NW>(sV + i * TB, Vb, a.ldv, kb + 64 * i, S, w, lane);
+  stage(0, 0);
 
   bf16x8 kf[2][KC];
   bool keyok[2];
@@ -500,61 +541,94 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
     for (int f = 0; f < 2; ++f) { dk[d][f] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d][f] = dk[d][f]; }
   const float c2 = a.scale * LOG2E;
 
+  // lane-constant LDS byte offsets (tile / fragment indices only add immediates): row fragments per k-chunk,
+  // transposed fragments per 16-wide d block
+  // koff(kk) = koff0 ^ (kk << 6) and toff(d) = toff0 ^ (d << 5): the chunk index enters the address only through an XOR
+  // with the row swizzle, so the k-chunk / d-block bits can be XOR-ed in afterwards (one VGPR each instead of 4 + 8).
+  const int koff0 = li * (DH * 2) + ((g ^ swz_row<DH>(li)) << 4);
+  const int tr1 = 4 * g + (li >> 2);   // + 32 t (+16): multiples of 16 leave the swizzle unchanged
+  const int toff0 = tr1 * (DH * 2) + ((((li & 3) >> 1) ^ swz_row<DH>(tr1)) << 4) + (li & 1) * 8;
+  auto koff = [&](int kk) { return koff0 ^ (kk << 6); };
+  auto toff = [&](int d) { return toff0 ^ (d << 5); };
+  const char* vbase = myV + (w & 1) * 2 * (16 * DH * 2);
+  auto trfrag = [&](const char* tile, int d, int t) {
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(tile + toff(d) + t * (32 * DH * 2)));
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(tile + toff(d) + t * (32 * DH * 2) + 16 * DH * 2));
+    return cat8(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi));
+  };
+
   const int ntiles = (S + 63) / 64;
   for (int it = 0; it < ntiles; ++it) {
     const int i0 = it * 64;
-    stage_rows_n<DH, NW>(sQ, Qb, a.ldq, i0, S, w, lane);
-    stage_rows_n<DH, NW>(sdO, dOb, a.lddo, i0, S, w, lane);
-    stage_cols_n<DH, NW>(sQt, Qtb, a.S_pad, i0, w, lane);
-    stage_cols_n<DH, NW>(sdOt, dOtb, a.S_pad, i0, w, lane);
-    __syncthreads();
+    const int buf = it & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile `it` (and of V) have landed
+    __syncthreads();                                    // everyone's have; everyone is done reading tile it-1
+    if (it + 1 < ntiles) stage(it + 1, buf ^ 1);
+    const char* sQ = sStage + buf * 2 * TB;
+    const char* sdO = sQ + TB;
+    const char* sL = sStat + buf * 512;
+    const bool tail = i0 + 64 > S;   // wave-uniform: only the last tile masks query rows
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      bf16x4 p4[2][2], d4[2][2];   // [key frag][q frag of this half]
+      u32x4 pbu[2], dsu[2];   // packed P / dS of this 32-query half per key fragment: directly the MFMA B operands
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
+        __builtin_amdgcn_sched_barrier(0);
         const int qfi = 2 * t + q2;
         f32x4 sa[2], da[2];
         sa[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sa[1] = sa[0]; da[0] = sa[0]; da[1] = sa[0];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          const bf16x8 qa = read_rowfrag<DH>(sQ, qfi, kk, g, li);
-          const bf16x8 oa = read_rowfrag<DH>(sdO, qfi, kk, g, li);
+          const bf16x8 qa = *(const bf16x8*)(sQ + koff(kk) + qfi * (16 * DH * 2));
+          const bf16x8 oa = *(const bf16x8*)(sdO + koff(kk) + qfi * (16 * DH * 2));
 #pragma unroll
           for (int f = 0; f < 2; ++f) {
             sa[f] = MFMA(qa, kf[f][kk], sa[f]);                                             // D[i=q][j=key]
-            da[f] = MFMA(oa, read_rowfrag<DH>(myV, (w & 1) * 2 + f, kk, g, li), da[f]);
+            da[f] = MFMA(oa, *(const bf16x8*)(vbase + koff(kk) + f * (16 * DH * 2)), da[f]);
           }
         }
-        const int qb = i0 + qfi * 16 + 4 * g;
-        const f32x4 l4 = *(const f32x4*)(lseb + qb);
-        const f32x4 s4 = *(const f32x4*)(dsb + qb);
+        const int ql = qfi * 16 + 4 * g;
+        const f32x4 l4 = *(const f32x4*)(sL + ql * 4);
+        const f32x4 s4 = *(const f32x4*)(sL + 256 + ql * 4);
+        if (tail) {
+          const int qb = i0 + ql;
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = (qb + r) < S;
+              const float p = ok ? fexp2(sa[f][r] * c2 + mk[f] - l4[r]) : 0.f;
+              da[f][r] = ok ? p * (da[f][r] - s4[r]) : 0.f;
+              sa[f][r] = p;
+            }
+        } else {
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = fexp2(sa[f][r] * c2 + (mk[f] - l4[r]));
+              da[f][r] = p * (da[f][r] - s4[r]);
+              sa[f][r] = p;
+            }
+        }
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = (qb + r) < S;
-            const float p = ok ? fexp2(sa[f][r] * c2 + mk[f] - l4[r]) : 0.f;
-            da[f][r] = ok ? p * (da[f][r] - s4[r]) : 0.f;
-            sa[f][r] = p;
-          }
-          p4[f][q2] = pack4(sa[f]);
-          d4[f][q2] = pack4(da[f]);
+          pbu[f][2 * q2] = pack2bf(sa[f][0], sa[f][1]); pbu[f][2 * q2 + 1] = pack2bf(sa[f][2], sa[f][3]);
+          dsu[f][2 * q2] = pack2bf(da[f][0], da[f][1]); dsu[f][2 * q2 + 1] = pack2bf(da[f][2], da[f][3]);
         }
       }
-      const bf16x8 pb0 = cat8(p4[0][0], p4[0][1]), pb1 = cat8(p4[1][0], p4[1][1]);
-      const bf16x8 ds0 = cat8(d4[0][0], d4[0][1]), ds1 = cat8(d4[1][0], d4[1][1]);
+      const bf16x8 pb0 = __builtin_bit_cast(bf16x8, pbu[0]), pb1 = __builtin_bit_cast(bf16x8, pbu[1]);
+      const bf16x8 ds0 = __builtin_bit_cast(bf16x8, dsu[0]), ds1 = __builtin_bit_cast(bf16x8, dsu[1]);
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        const bf16x8 ot = read_colfrag(sdOt, d, t, g, li);
-        const bf16x8 qt = read_colfrag(sQt, d, t, g, li);
+        const bf16x8 ot = trfrag(sdO, d, t);
+        const bf16x8 qt = trfrag(sQ, d, t);
         dv[d][0] = MFMA(ot, pb0, dv[d][0]);     // D[i=dv][j=key]
         dv[d][1] = MFMA(ot, pb1, dv[d][1]);
         dk[d][0] = MFMA(qt, ds0, dk[d][0]);
         dk[d][1] = MFMA(qt, ds1, dk[d][1]);
       }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -621,7 +695,7 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
 extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
-  if (!a->Q || !a->Qt || !a->K || !a->V || !a->dO || !a->dOt || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
+  if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
   dim3 grid((a->S + 255) / 256, a->H, a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, *a);
