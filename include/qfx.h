@@ -196,24 +196,26 @@ int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_
 
 /* ---- joint attention (non-causal flash attention, optional additive key mask) ---------------
  * Replaces torch.cat + F.scaled_dot_product_attention (transformer_qwenimage.py:324-337) and its backward.
- * Q,K,V: token-major [B,S,H,dh] views with row stride ld (elements); Kt,Vt,Qt,dOt: [B,H,dh,S_pad].
+ * Q,K,V: token-major [B,S,H,dh] views with row stride ld (elements).  Kt,Vt,Qt,dOt ([B,H,dh,S_pad]) are RESERVED: the
+ * kernels take their transposed MFMA operands from the row-major LDS tiles with ds_read_b64_tr_b16, so no transposed
+ * copy is read any more; the fields keep the struct layout stable and may be NULL.
  * O [B,S,H*dh] (row stride ldo). lse2 [B,H,S_pad] fp32 = log2-domain logsumexp. key_mask [B,S] fp32 additive or NULL.
  */
 typedef struct qfx_attn_args {
   const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ldq; int64_t ldk; int64_t ldv;
-  const uint16_t* Qt; const uint16_t* Kt; const uint16_t* Vt;   /* [B,H,dh,S_pad] */
+  const uint16_t* Qt; const uint16_t* Kt; const uint16_t* Vt;   /* reserved (unused), may be NULL */
   uint16_t* O; int64_t ldo;
   float* lse2; float* dsum;                                      /* [B,H,S_pad] */
-  const uint16_t* dO; int64_t lddo; const uint16_t* dOt;
+  const uint16_t* dO; int64_t lddo; const uint16_t* dOt;         /* dOt reserved (unused) */
   uint16_t* dQ; uint16_t* dK; uint16_t* dV; int64_t lddq; int64_t lddk; int64_t lddv;
   const float* key_mask;
   int32_t B; int32_t S; int32_t S_pad; int32_t H; int32_t dh; float scale;
 } qfx_attn_args;
 
-int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,Vt -> O,lse2 */
+int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,V -> O,lse2 */
 int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream);  /* dsum = rowsum(dO*O) */
-int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream);    /* needs Q,K,V,Kt,dO,lse2,dsum -> dQ */
-int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream);   /* needs Q,Qt,K,V,dO,dOt,lse2,dsum -> dK,dV */
+int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream);    /* needs Q,K,V,dO,lse2,dsum -> dQ */
+int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream);   /* needs Q,K,V,dO,lse2,dsum -> dK,dV */
 
 /* ---- flow-matching MSE criterion (src/qflux/losses/mse_loss.py:66-83 with weighting=1;
  * caller math of src/qflux/trainer/qwen_image_edit_trainer.py:839-847) --------------------------

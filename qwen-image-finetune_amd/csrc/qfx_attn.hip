@@ -16,6 +16,7 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;   // operand type of the transpose-read builtin
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
   __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)g, (QFX_AS3 void*)lds, 16, 0, 0);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
   const int S = a.S;
 
   const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
-  const bf16_t* Vtb = a.Vt + ((int64_t)b * a.H + h) * DH * a.S_pad;
+  const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
 
   bf16x8 qf[2][KC];
 #pragma unroll
@@ -138,26 +139,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
   const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
 
   // lane-constant LDS byte offsets of the fragment reads (tile/fragment index only adds an immediate)
-  int koff[KC], voff[4];
+  int koff[KC];
 #pragma unroll
   for (int kk = 0; kk < KC; ++kk) koff[kk] = li * (DH * 2) + (((kk * 4 + g) ^ swz_row<DH>(li)) << 4);
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int sw = (li >> 1) & 7, c1 = 4 * t + (g >> 1);
-    voff[2 * t] = li * 128 + ((c1 ^ sw) << 4) + 8 * (g & 1);
-    voff[2 * t + 1] = li * 128 + (((c1 + 2) ^ sw) << 4) + 8 * (g & 1);
-  }
+  // V^T fragments come from the ROW-major V tile through the transpose read (see read_trfrag): toff(d) = toff0 ^ (d << 5)
+  const int tr1 = 4 * g + (li >> 2);
+  const int toff0 = tr1 * (DH * 2) + ((((li & 3) >> 1) ^ swz_row<DH>(tr1)) << 4) + (li & 1) * 8;
   const int ntiles = (S + 63) / 64;
   stage_rows<DH>(smem, Kb, a.ldk, 0, S, w, lane);
-  stage_cols<DH>(smem + TB, Vtb, a.S_pad, 0, w, lane);
+  stage_rows<DH>(smem + TB, Vb, a.ldv, 0, S, w, lane);
   __syncthreads();
   for (int jt = 0; jt < ntiles; ++jt) {
     const char* sK = smem + (jt & 1) * 2 * TB;
-    const char* sVt = sK + TB;
+    const char* sV = sK + TB;
     if (jt + 1 < ntiles) {
       char* nK = smem + ((jt + 1) & 1) * 2 * TB;
       stage_rows<DH>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
-      stage_cols<DH>(nK + TB, Vtb, a.S_pad, (jt + 1) * 64, w, lane);
+      stage_rows<DH>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
     }
     const int j0 = jt * 64;
     f32x4 sacc[4][2];
@@ -237,8 +235,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
     for (int d = 0; d < DF; ++d)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x4 lo = *(const bf16x4*)(sVt + voff[2 * t] + d * 2048);
-        const bf16x4 hi = *(const bf16x4*)(sVt + voff[2 * t + 1] + d * 2048);
+        const int o = (toff0 ^ (d << 5)) + t * (32 * DH * 2);
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(sV + o)));
+        const bf16x4 hi = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(sV + o + 16 * DH * 2)));
         bf16x8 vfr;
         vfr[0] = lo[0]; vfr[1] = lo[1]; vfr[2] = lo[2]; vfr[3] = lo[3];
         vfr[4] = hi[0]; vfr[5] = hi[1]; vfr[6] = hi[2]; vfr[7] = hi[3];
@@ -301,7 +300,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args a) {
   constexpr int KC = DH / 32, DF = DH / 16;
   constexpr int TB = 64 * DH * 2;
-  __shared__ __attribute__((aligned(16))) char smem[3 * TB];
+  __shared__ __attribute__((aligned(16))) char smem[4 * TB];   // 2 x [K | V] row tiles (double-buffered LDS-DMA)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -310,8 +309,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
   const int S = a.S;
   const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
   const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
-  const bf16_t* Ktb = a.Kt + ((int64_t)b * a.H + h) * DH * a.S_pad;
-  char* sK = smem; char* sV = smem + TB; char* sKt = smem + 2 * TB;
+
+  // DMA sources as uniform base + 32-bit lane offset (rows past S clamp to S-1)
+  constexpr int CPR = DH / 8, RPI = 64 / CPR, NIS = 16 / RPI;
+  auto stage = [&](int jt, int buf) {
+    const int j0 = jt * 64;
+    char* dK_ = smem + buf * 2 * TB;
+#pragma unroll
+    for (int i = 0; i < NIS; ++i) {
+      const int row = w * 16 + i * RPI + lane / CPR;
+      const int sc8 = ((lane % CPR) ^ swz_row<DH>(row)) * 8;
+      int sr = j0 + row; sr = sr < S ? sr : S - 1;
+      glds16(Kb + (unsigned)(sr * a.ldk + sc8), dK_ + (w * 16 + i * RPI) * (DH * 2));
+      glds16(Vb + (unsigned)(sr * a.ldv + sc8), dK_ + TB + (w * 16 + i * RPI) * (DH * 2));
+    }
+  };
+  stage(0, 0);
 
   bf16x8 qf[2][KC], dof[2][KC];
   float lse[2], dsm[2];
@@ -331,24 +344,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
   const float c2 = a.scale * LOG2E;
   const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
 
-  // lane-constant LDS byte offsets of the fragment reads (tile/fragment index only adds an immediate)
-  int koff[KC], voff[4];
-#pragma unroll
-  for (int kk = 0; kk < KC; ++kk) koff[kk] = li * (DH * 2) + (((kk * 4 + g) ^ swz_row<DH>(li)) << 4);
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int sw = (li >> 1) & 7, c1 = 4 * t + (g >> 1);
-    voff[2 * t] = li * 128 + ((c1 ^ sw) << 4) + 8 * (g & 1);
-    voff[2 * t + 1] = li * 128 + (((c1 + 2) ^ sw) << 4) + 8 * (g & 1);
-  }
+  // lane-constant LDS byte offsets: koff(kk) = koff0 ^ (kk << 6), toff(d) = toff0 ^ (d << 5) (see the dK/dV kernel)
+  const int koff0 = li * (DH * 2) + ((g ^ swz_row<DH>(li)) << 4);
+  const int tr1 = 4 * g + (li >> 2);
+  const int toff0 = tr1 * (DH * 2) + ((((li & 3) >> 1) ^ swz_row<DH>(tr1)) << 4) + (li & 1) * 8;
+  auto koff = [&](int kk) { return koff0 ^ (kk << 6); };
+  auto trfrag = [&](const char* tile, int d, int t) {
+    const int o = (toff0 ^ (d << 5)) + t * (32 * DH * 2);
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(tile + o));
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(tile + o + 16 * DH * 2));
+    bf16x8 r;
+    const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+    r[0] = l4[0]; r[1] = l4[1]; r[2] = l4[2]; r[3] = l4[3]; r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
+    return r;
+  };
   const int ntiles = (S + 63) / 64;
   for (int jt = 0; jt < ntiles; ++jt) {
     const int j0 = jt * 64;
-    stage_rows<DH>(sK, Kb, a.ldk, j0, S, w, lane);
-    stage_rows<DH>(sV, Vb, a.ldv, j0, S, w, lane);
-    stage_cols<DH>(sKt, Ktb, a.S_pad, j0, w, lane);
-    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);   // wave-uniform
+    const int buf = jt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (jt + 1 < ntiles) stage(jt + 1, buf ^ 1);
+    const char* sK = smem + buf * 2 * TB;
+    const char* sV = sK + TB;
+    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);   // wave-uniform
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 sa[2][2], da[2][2];  // [kf local][qf]
@@ -358,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
         sa[k2][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sa[k2][1] = sa[k2][0]; da[k2][0] = sa[k2][0]; da[k2][1] = sa[k2][0];
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          const bf16x8 kfr = *(const bf16x8*)(sK + koff[kk] + kf * (16 * DH * 2));
-          const bf16x8 vfr = *(const bf16x8*)(sV + koff[kk] + kf * (16 * DH * 2));
+          const bf16x8 kfr = *(const bf16x8*)(sK + koff(kk) + kf * (16 * DH * 2));
+          const bf16x8 vfr = *(const bf16x8*)(sV + koff(kk) + kf * (16 * DH * 2));
           sa[k2][0] = MFMA(kfr, qf[0][kk], sa[k2][0]);
           sa[k2][1] = MFMA(kfr, qf[1][kk], sa[k2][1]);
           da[k2][0] = MFMA(vfr, dof[0][kk], da[k2][0]);
@@ -391,12 +410,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
       const bf16x8 ds1 = pack8(sa[0][1], sa[1][1]);
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        const bf16x8 ktf = colfrag_at(sKt + d * 2048, voff[2 * t], voff[2 * t + 1]);
+        const bf16x8 ktf = trfrag(sK, d, t);
         dq[d][0] = MFMA(ktf, ds0, dq[d][0]);
         dq[d][1] = MFMA(ktf, ds1, dq[d][1]);
       }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -460,7 +478,6 @@ __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
 // lane (g, li) receives X[q][16*df + li] for the 8 rows q = {32t+4g+j, 32t+16+4g+j}, j<4 -- the pi order of the packed
 // P / dS registers.  Source lane 16g + 4j' + m supplies the address of X[q0+j'][16*df+4m .. +3]; the instruction hands
 // lane (g, li) element li&3 of source lane 4j + (li>>2), j = 0..3 (mapping verified by qfx_debug_tr_read).
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
 template <int DH>
 __device__ __forceinline__ bf16x8 read_trfrag(const char* tile, int df, int t, int g, int li) {
   const int col = 16 * df + 4 * (li & 3);
@@ -659,7 +676,7 @@ int check_common(const qfx_attn_args* a) {
 extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
-  if (!a->Q || !a->K || !a->Vt || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldo % 4)) return QFX_EINVAL;
+  if (!a->Q || !a->K || !a->V || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return QFX_EINVAL;
   dim3 grid((a->S + 127) / 128, a->H, a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
@@ -683,7 +700,7 @@ extern "C" int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream) {
 extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
-  if (!a->Q || !a->K || !a->V || !a->Kt || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
+  if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
   dim3 grid((a->S + 127) / 128, a->H, a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);

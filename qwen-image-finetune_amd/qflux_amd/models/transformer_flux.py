@@ -430,14 +430,13 @@ class _FluxPlan(_QwenPlan):
         nq, nk = w["norms"]
         p.c(lib.qfx_qk_norm_rope_fwd, _ptr(bb["qkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
             B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
-        p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["VtA"]), B, S, S_pad, H, dh)
         a = L.AttnArgs()
         a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, 1.0 / math.sqrt(dh)
         a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
         a.ldq = a.ldk = a.ldv = 3 * D
-        a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["VtA"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
+        a.O, a.ldo, a.lse2 = _ptr(bb["ao"]), D, _ptr(bb["lse"])
         a.key_mask = _ptr(self.kmask)
-        a.Qt, a.Kt, a.dOt, a.dsum = _ptr(A["Qt"]), _ptr(A["Kt"]), _ptr(A["dOt"]), _ptr(A["dsum"])
+        a.dsum = _ptr(A["dsum"])
         a.dO, a.lddo = _ptr(A["dao"]), D
         dq2 = A["dqkv"].view(M, 3 * D)
         a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
@@ -513,9 +512,6 @@ class _FluxPlan(_QwenPlan):
         self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT[D:], K1=D, M=M, N=4 * D, C_=A["A2"], ldc=ldA2, epi=L.EPI_DGELU, aux=bb["h"],
                    ldaux=4 * D)
         q2 = bb["qkv"].view(M, 3 * D)
-        p.c(lib.qfx_transpose_heads, _ptr(dao2), D, _ptr(A["dOt"]), B, S, S_pad, H, dh)
-        p.c(lib.qfx_transpose_heads, _ptr(q2[:, 0:]), 3 * D, _ptr(A["Qt"]), B, S, S_pad, H, dh)
-        p.c(lib.qfx_transpose_heads, _ptr(q2[:, D:]), 3 * D, _ptr(A["Kt"]), B, S, S_pad, H, dh)
         p.c(lib.qfx_attn_bwd_prep, C.byref(a))
         p.c(lib.qfx_attn_bwd_dq, C.byref(a))
         p.c(lib.qfx_attn_bwd_dkv, C.byref(a))

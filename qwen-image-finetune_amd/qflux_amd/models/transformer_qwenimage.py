@@ -510,7 +510,6 @@ class _QwenPlan:
         buf, rows, B, S, D, H, dh, S_pad, A = self.buf, self.rows, self.B, self.S, self.D, self.H, self.dh, self.S_pad, self.A
         A["xm"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["g"] = {s: buf(rows[s], 4 * D) for s in ("img", "txt")}
-        A["VtA"] = buf(B, H, dh, S_pad)
         kext_max = 0
         rp_max = 0
         for w in blocks:   # LoRA scratch (pad columns stay zero forever)
@@ -532,7 +531,6 @@ class _QwenPlan:
         A["dh"] = {s: buf(rows[s], 4 * D) for s in ("img", "txt")}
         A["dxm"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["dao"] = buf(B, S, D, zero=True)
-        A["dOt"] = buf(B, H, dh, S_pad); A["Qt"] = buf(B, H, dh, S_pad); A["Kt"] = buf(B, H, dh, S_pad)
         A["dsum"] = buf(B, H, S_pad, dtype=F32, zero=True)
         A["dqkv"] = buf(B, S, 3 * D)
 
@@ -677,15 +675,14 @@ class _QwenPlan:
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_fwd, _ptr(qkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i),
                 B, S, T, H, dh, eps, norm_flags, self.rope_bs)
-            p.c(lib.qfx_transpose_heads, _ptr(q2[:, 2 * D:]), 3 * D, _ptr(A["VtA"]), B, S, S_pad, H, dh)
             a = L.AttnArgs()
             a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
             a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
             a.ldq = a.ldk = a.ldv = 3 * D
-            a.Vt, a.O, a.ldo, a.lse2 = _ptr(A["VtA"]), _ptr(bb["ao"]), D, _ptr(bb["lse"])
+            a.O, a.ldo, a.lse2 = _ptr(bb["ao"]), D, _ptr(bb["lse"])   # no transposed copies: the kernels use LDS transpose reads
             a.key_mask = _ptr(self.kmask)
             # backward fields (same struct reused by the backward program)
-            a.Qt, a.Kt, a.dOt, a.dsum = _ptr(A["Qt"]), _ptr(A["Kt"]), _ptr(A["dOt"]), _ptr(A["dsum"])
+            a.dsum = _ptr(A["dsum"])
             a.dO, a.lddo = _ptr(A["dao"]), D
             dq2 = A["dqkv"].view(B * S, 3 * D)
             a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
@@ -795,9 +792,6 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             # ---- attention backward
             q2 = bb["qkv"].view(B * S, 3 * D)
-            p.c(lib.qfx_transpose_heads, _ptr(dao2), D, _ptr(A["dOt"]), B, S, S_pad, H, dh)
-            p.c(lib.qfx_transpose_heads, _ptr(q2[:, 0:]), 3 * D, _ptr(A["Qt"]), B, S, S_pad, H, dh)
-            p.c(lib.qfx_transpose_heads, _ptr(q2[:, D:]), 3 * D, _ptr(A["Kt"]), B, S, S_pad, H, dh)
             p.c(lib.qfx_attn_bwd_prep, C.byref(a))
             p.c(lib.qfx_attn_bwd_dq, C.byref(a))
             p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
