@@ -94,6 +94,10 @@ typedef struct qfx_lora_down_args {
 } qfx_lora_down_args;
 
 int qfx_lora_down(const qfx_lora_down_args* args, void* stream);
+/* n <= QFX_MAX_BATCH independent problems of the same R in ONE launch (e.g. the q, k and v down projections of a block's
+ * backward): every separate launch of these one-round-trip kernels costs a dispatch gap plus its own latency floor. */
+#define QFX_MAX_BATCH 8
+int qfx_lora_down_batch(const qfx_lora_down_args* list, int32_t n, void* stream);
 
 /* ---- LoRA weight gradients (contraction over tokens, MFMA + LDS transpose reads) -------------
  * G[j,k] += out_scale * sum_m (Vt_hi+Vt_lo)[j,m] * X[m,k]   j<R, k<K ; Vt = transposed bf16 split of the fp32
@@ -111,6 +115,7 @@ typedef struct qfx_lora_grad_args {
 } qfx_lora_grad_args;
 
 int qfx_lora_grad(const qfx_lora_grad_args* args, void* stream);
+int qfx_lora_grad_batch(const qfx_lora_grad_args* list, int32_t n, void* stream);   /* same R for all; see qfx_lora_down_batch */
 
 /* ---- LoRA operand packing (after every optimizer step) ---------------------------------------
  * From fp32 A[r,K], B[N,r] and scale s = lora_alpha/r build (Rp = r rounded up to 16):

@@ -10,14 +10,27 @@ namespace {
 // interleave the K/32 MFMA steps (adjacent waves read adjacent 64 B of each row), two steps in flight
 // per wave, LDS reduce at the end.  Outputs: U fp32, the packed bf16 K-extension image for the GEMM,
 // and the transposed hi/lo image Ut[R][M] that the weight-gradient kernel contracts over tokens.
+// Batched launches: up to QFX_MAX_BATCH independent problems of the same rank share one grid (these kernels are one
+// memory round trip long, so every separate launch costs ~2 us of dispatch gap plus its own latency floor).  The
+// argument block is read from the kernarg segment (scalar loads); indexing the by-value copy would go through scratch.
+#define QFX_AS4 __attribute__((address_space(4)))
+struct DownBatch { qfx_lora_down_args a[QFX_MAX_BATCH]; int start[QFX_MAX_BATCH + 1]; int n; };
+struct GradBatch { qfx_lora_grad_args a[QFX_MAX_BATCH]; int start[QFX_MAX_BATCH + 1]; int n; };
+
 template <int NF>
-__global__ __launch_bounds__(512) void lora_down_kernel(const qfx_lora_down_args p) {
+__global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by_value) {
   constexpr int NW = 8;
   __shared__ float red[NW][NF * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int m0 = blockIdx.x * 16;
+  const QFX_AS4 DownBatch& kb = *(const QFX_AS4 DownBatch*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < QFX_MAX_BATCH; ++i)
+    if (i < kb.n && (int)blockIdx.x >= kb.start[i]) pi = i;
+  const QFX_AS4 qfx_lora_down_args& p = kb.a[pi];
+  const int m0 = ((int)blockIdx.x - kb.start[pi]) * 16;
 
   int mr = m0 + li;
   mr = mr < p.M ? mr : p.M - 1;
@@ -33,30 +46,37 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const qfx_lora_down_args
 #pragma unroll
   for (int j = 0; j < NF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // The kernel is a latency chain, not a bandwidth stream (152 blocks, ~12 k-steps per wave): ALL X fragments of a
+  // 12-step chunk are requested up front (one HBM latency per chunk instead of one per step pair); the weight
+  // fragments are L2 hits and are double-buffered one step ahead of the MFMAs.
   const int nks = p.K / 32;
-  int ks = w;
-  for (; ks + NW < nks; ks += 2 * NW) {
-    const int k0 = ks * 32, k1 = (ks + NW) * 32;
-    const bf16x8 x0 = *(const bf16x8*)(xrow + k0);
-    const bf16x8 x1 = *(const bf16x8*)(xrow + k1);
+  constexpr int CHK = 12;
+  for (int base = w; base < nks; base += NW * CHK) {
+    bf16x8 xs[CHK];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const bf16x8 h0 = *(const bf16x8*)(wh[nf] + k0), l0 = *(const bf16x8*)(wl[nf] + k0);
-      const bf16x8 h1 = *(const bf16x8*)(wh[nf] + k1), l1 = *(const bf16x8*)(wl[nf] + k1);
-      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, h0, acc[nf], 0, 0, 0);
-      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, l0, acc[nf], 0, 0, 0);
-      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, h1, acc[nf], 0, 0, 0);
-      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, l1, acc[nf], 0, 0, 0);
+    for (int i = 0; i < CHK; ++i) {
+      const int ks = base + i * NW;
+      xs[i] = ks < nks ? *(const bf16x8*)(xrow + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
-  }
-  for (; ks < nks; ks += NW) {
-    const int k0 = ks * 32;
-    const bf16x8 x0 = *(const bf16x8*)(xrow + k0);
+    bf16x8 hcur[NF], lcur[NF], hnext[NF], lnext[NF];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const bf16x8 h0 = *(const bf16x8*)(wh[nf] + k0), l0 = *(const bf16x8*)(wl[nf] + k0);
-      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, h0, acc[nf], 0, 0, 0);
-      acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, l0, acc[nf], 0, 0, 0);
+    for (int nf = 0; nf < NF; ++nf) { hcur[nf] = *(const bf16x8*)(wh[nf] + base * 32); lcur[nf] = *(const bf16x8*)(wl[nf] + base * 32); }
+#pragma unroll
+    for (int i = 0; i < CHK; ++i) {
+      const int ksn = base + (i + 1) * NW;
+      if (i + 1 < CHK && ksn < nks) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) { hnext[nf] = *(const bf16x8*)(wh[nf] + ksn * 32); lnext[nf] = *(const bf16x8*)(wl[nf] + ksn * 32); }
+      }
+      if (base + i * NW < nks) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i], hcur[nf], acc[nf], 0, 0, 0);
+          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i], lcur[nf], acc[nf], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) { hcur[nf] = hnext[nf]; lcur[nf] = lnext[nf]; }
     }
   }
 #pragma unroll
@@ -98,14 +118,21 @@ typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
 constexpr int GX_ROWB = 288;  // padded LDS row stride (bytes) of the [32 tokens][128 cols] tile
 
 template <int NF>
-__global__ __launch_bounds__(256) void lora_grad_kernel(const qfx_lora_grad_args p) {
+__global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by_value) {
   constexpr int CH = 128;  // tokens per block
   __shared__ __attribute__((aligned(16))) char sX[2][32 * GX_ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
+  const QFX_AS4 GradBatch& kb = *(const QFX_AS4 GradBatch*)__builtin_amdgcn_kernarg_segment_ptr();
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < QFX_MAX_BATCH; ++i)
+    if (i < kb.n && (int)blockIdx.y >= kb.start[i]) pi = i;
+  const QFX_AS4 qfx_lora_grad_args& p = kb.a[pi];
   const int k0 = blockIdx.x * 128;
-  const int mb = blockIdx.y * CH;
+  if (k0 >= p.K) return;   // grid.x is sized for the widest problem of the batch
+  const int mb = ((int)blockIdx.y - kb.start[pi]) * CH;
   const int nsteps = ((p.M - mb < CH ? p.M - mb : CH) + 31) / 32;
 
   // staging: thread -> (token row tid/16 + 16*it, 16-byte chunk tid%16)
@@ -113,55 +140,67 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const qfx_lora_grad_args
   int kc = k0 + sch * 8;
   const bool kok = kc < p.K;
   kc = kok ? kc : 0;
-  u32x4 st[2];
-  auto gload = [&](int step) {
+  // 4 steps of 32 tokens per block: all of the block's X rows are requested up front (one HBM latency per block instead
+  // of one per step); the LDS tile is double-buffered.
+  constexpr int NST = CH / 32;
+  u32x4 st[NST][2];
+#pragma unroll
+  for (int step = 0; step < NST; ++step)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       int m = mb + step * 32 + it * 16 + srow;
       m = m < p.M ? m : p.M - 1;
       const bf16_t* src = p.X + remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + kc;
-      st[it] = *(const u32x4*)src;
+      st[step][it] = *(const u32x4*)src;
     }
-  };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int step) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) *(u32x4*)(&sX[buf][(it * 16 + srow) * GX_ROWB + sch * 16]) = st[it];
+    for (int it = 0; it < 2; ++it) *(u32x4*)(&sX[step & 1][(it * 16 + srow) * GX_ROWB + sch * 16]) = st[step][it];
   };
 
   f32x4 acc[NF][2];
 #pragma unroll
   for (int i = 0; i < NF; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
 
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) gload(s + 1);
-    const char* tile = sX[s & 1];
-    const int mtok = mb + s * 32 + 8 * g;   // tokens mtok..mtok+7 are this lane group's k-slots
-    bf16x8 b[2];
-#pragma unroll
-    for (int cf = 0; cf < 2; ++cf) {
-      const int colb = (w * 32 + cf * 16 + 4 * (li & 3)) * 2;
-      const char* a0 = tile + (8 * g + (li >> 2)) * GX_ROWB + colb;
-      const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0));
-      const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0 + 4 * GX_ROWB));
-      const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-      b[cf][0] = l4[0]; b[cf][1] = l4[1]; b[cf][2] = l4[2]; b[cf][3] = l4[3];
-      b[cf][4] = h4[0]; b[cf][5] = h4[1]; b[cf][6] = h4[2]; b[cf][7] = h4[3];
-    }
+  // rank-side fragments (L2 hits) are fetched one step ahead of the MFMAs that use them
+  bf16x8 ah[2][NF], al[2][NF];
+  auto vload = [&](int step, int slot) {
+    const int mtok = mb + step * 32 + 8 * g;   // tokens mtok..mtok+7 are this lane group's k-slots
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int64_t ro = (int64_t)(nf * 16 + li) * p.ldvt + mtok;
-      const bf16x8 ah = *(const bf16x8*)(p.Vt_hi + ro);
-      const bf16x8 al = *(const bf16x8*)(p.Vt_lo + ro);
+      ah[slot][nf] = *(const bf16x8*)(p.Vt_hi + ro);
+      al[slot][nf] = *(const bf16x8*)(p.Vt_lo + ro);
+    }
+  };
+  vload(0, 0);
+  swrite(0);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NST; ++s) {
+    if (s + 1 < NST && s + 1 < nsteps) vload(s + 1, (s + 1) & 1);
+    if (s < nsteps) {
+      const char* tile = sX[s & 1];
+      bf16x8 b[2];
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf) {
-        acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[cf], acc[nf][cf], 0, 0, 0);
-        acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[cf], acc[nf][cf], 0, 0, 0);
+        const int colb = (w * 32 + cf * 16 + 4 * (li & 3)) * 2;
+        const char* a0 = tile + (8 * g + (li >> 2)) * GX_ROWB + colb;
+        const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0));
+        const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0 + 4 * GX_ROWB));
+        const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+        b[cf][0] = l4[0]; b[cf][1] = l4[1]; b[cf][2] = l4[2]; b[cf][3] = l4[3];
+        b[cf][4] = h4[0]; b[cf][5] = h4[1]; b[cf][6] = h4[2]; b[cf][7] = h4[3];
       }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) {
+          acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][nf], b[cf], acc[nf][cf], 0, 0, 0);
+          acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][nf], b[cf], acc[nf][cf], 0, 0, 0);
+        }
     }
-    if (s + 1 < nsteps) swrite((s + 1) & 1);
+    if (s + 1 < NST) swrite(s + 1);
     __syncthreads();
   }
   // D[i = rank 4g+r][j = col li]
@@ -230,20 +269,82 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const qfx_lora_pack_args
 
 }  // namespace
 
-extern "C" int qfx_lora_down(const qfx_lora_down_args* a, void* stream) {
-  if (!a || !a->X || !a->W_hi || !a->W_lo) return QFX_EINVAL;
+namespace {
+int check_down(const qfx_lora_down_args* a) {
+  if (!a->X || !a->W_hi || !a->W_lo) return QFX_EINVAL;
   if (a->M <= 0 || a->K <= 0 || (a->K % 32) || (a->ldx % 8) || (a->ldw % 8) || (a->R % 16) || a->R <= 0) return QFX_EINVAL;
   if (a->ext && (a->group_R <= 0 || (a->R % a->group_R))) return QFX_EINVAL;
   if (a->Ut_hi && (!a->Ut_lo || a->ld_ut < a->M)) return QFX_EINVAL;
   if (a->rows_per_batch <= 0) return QFX_EINVAL;
+  return QFX_OK;
+}
+int check_grad(const qfx_lora_grad_args* a) {
+  if (!a->Vt_hi || !a->Vt_lo || !a->X || !a->G) return QFX_EINVAL;
+  if (a->M <= 0 || a->K <= 0 || (a->K % 8) || (a->ldx % 8) || a->R <= 0 || (a->R % 16) || a->rows_per_batch <= 0) return QFX_EINVAL;
+  if ((a->ldvt % 8) || a->ldvt < ((a->M + 31) / 32) * 32) return QFX_EINVAL;  /* rows must be zero-padded to a multiple of 32 tokens */
+  if (a->group_R <= 0 || (a->group_R % 16) || (a->R % a->group_R) || a->R / a->group_R > 3) return QFX_EINVAL;
+  if (a->R / a->group_R > 1 && !a->G1) return QFX_EINVAL;
+  if (a->R / a->group_R > 2 && !a->G2) return QFX_EINVAL;
+  return QFX_OK;
+}
+}  // namespace
+
+extern "C" int qfx_lora_down_batch(const qfx_lora_down_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > QFX_MAX_BATCH) return QFX_EINVAL;
+  DownBatch b;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = check_down(&list[i]);
+    if (rc) return rc;
+    if (list[i].R != list[0].R) return QFX_EINVAL;   /* one MFMA fragment count per launch */
+    b.a[i] = list[i];
+    b.start[i] = blocks;
+    blocks += (list[i].M + 15) / 16;
+  }
+  for (int i = n; i <= QFX_MAX_BATCH; ++i) b.start[i] = blocks;
+  b.n = n;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((a->M + 15) / 16), block(512);
-  switch (a->R / 16) {
-    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, block, 0, s, *a); break;
-    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, block, 0, s, *a); break;
-    case 3: hipLaunchKernelGGL(lora_down_kernel<3>, grid, block, 0, s, *a); break;
-    case 4: hipLaunchKernelGGL(lora_down_kernel<4>, grid, block, 0, s, *a); break;
-    case 6: hipLaunchKernelGGL(lora_down_kernel<6>, grid, block, 0, s, *a); break;
+  dim3 grid(blocks), block(512);
+  switch (list[0].R / 16) {
+    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, block, 0, s, b); break;
+    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, block, 0, s, b); break;
+    case 3: hipLaunchKernelGGL(lora_down_kernel<3>, grid, block, 0, s, b); break;
+    case 4: hipLaunchKernelGGL(lora_down_kernel<4>, grid, block, 0, s, b); break;
+    case 6: hipLaunchKernelGGL(lora_down_kernel<6>, grid, block, 0, s, b); break;
+    default: return QFX_EUNSUPPORTED;
+  }
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_lora_down(const qfx_lora_down_args* a, void* stream) {
+  if (!a) return QFX_EINVAL;
+  return qfx_lora_down_batch(a, 1, stream);
+}
+
+extern "C" int qfx_lora_grad_batch(const qfx_lora_grad_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > QFX_MAX_BATCH) return QFX_EINVAL;
+  GradBatch b;
+  int chunks = 0, kmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = check_grad(&list[i]);
+    if (rc) return rc;
+    if (list[i].R != list[0].R) return QFX_EINVAL;
+    b.a[i] = list[i];
+    b.start[i] = chunks;
+    chunks += (list[i].M + 127) / 128;
+    kmax = list[i].K > kmax ? list[i].K : kmax;
+  }
+  for (int i = n; i <= QFX_MAX_BATCH; ++i) b.start[i] = chunks;
+  b.n = n;
+  dim3 grid((kmax + 127) / 128, chunks);
+  hipStream_t s = (hipStream_t)stream;
+  switch (list[0].R / 16) {
+    case 1: hipLaunchKernelGGL(lora_grad_kernel<1>, grid, dim3(256), 0, s, b); break;
+    case 2: hipLaunchKernelGGL(lora_grad_kernel<2>, grid, dim3(256), 0, s, b); break;
+    case 3: hipLaunchKernelGGL(lora_grad_kernel<3>, grid, dim3(256), 0, s, b); break;
+    case 4: hipLaunchKernelGGL(lora_grad_kernel<4>, grid, dim3(256), 0, s, b); break;
+    case 6: hipLaunchKernelGGL(lora_grad_kernel<6>, grid, dim3(256), 0, s, b); break;
     default: return QFX_EUNSUPPORTED;
   }
   QFX_CHECK_LAUNCH();
@@ -251,24 +352,8 @@ extern "C" int qfx_lora_down(const qfx_lora_down_args* a, void* stream) {
 }
 
 extern "C" int qfx_lora_grad(const qfx_lora_grad_args* a, void* stream) {
-  if (!a || !a->Vt_hi || !a->Vt_lo || !a->X || !a->G) return QFX_EINVAL;
-  if (a->M <= 0 || a->K <= 0 || (a->K % 8) || (a->ldx % 8) || a->R <= 0 || (a->R % 16) || a->rows_per_batch <= 0) return QFX_EINVAL;
-  if ((a->ldvt % 8) || a->ldvt < ((a->M + 31) / 32) * 32) return QFX_EINVAL;  /* rows must be zero-padded to a multiple of 32 tokens */
-  if (a->group_R <= 0 || (a->group_R % 16) || (a->R % a->group_R) || a->R / a->group_R > 3) return QFX_EINVAL;
-  if (a->R / a->group_R > 1 && !a->G1) return QFX_EINVAL;
-  if (a->R / a->group_R > 2 && !a->G2) return QFX_EINVAL;
-  dim3 grid((a->K + 127) / 128, (a->M + 127) / 128);
-  hipStream_t s = (hipStream_t)stream;
-  switch (a->R / 16) {
-    case 1: hipLaunchKernelGGL(lora_grad_kernel<1>, grid, dim3(256), 0, s, *a); break;
-    case 2: hipLaunchKernelGGL(lora_grad_kernel<2>, grid, dim3(256), 0, s, *a); break;
-    case 3: hipLaunchKernelGGL(lora_grad_kernel<3>, grid, dim3(256), 0, s, *a); break;
-    case 4: hipLaunchKernelGGL(lora_grad_kernel<4>, grid, dim3(256), 0, s, *a); break;
-    case 6: hipLaunchKernelGGL(lora_grad_kernel<6>, grid, dim3(256), 0, s, *a); break;
-    default: return QFX_EUNSUPPORTED;
-  }
-  QFX_CHECK_LAUNCH();
-  return QFX_OK;
+  if (!a) return QFX_EINVAL;
+  return qfx_lora_grad_batch(a, 1, stream);
 }
 
 extern "C" int qfx_lora_pack(const qfx_lora_pack_args* descs, int32_t n, int32_t max_dim, void* stream) {

@@ -75,6 +75,7 @@ class AttnArgs(C.Structure):
     ]
 
 
+MAX_BATCH = 8          # QFX_MAX_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/qfx.h declares
@@ -83,7 +84,9 @@ SYMBOLS = {
     "qfx_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "qfx_gemm_grouped": (C.c_int, [C.POINTER(GemmArgs), _i32, _vp]),
     "qfx_lora_down": (C.c_int, [C.POINTER(LoraDownArgs), _vp]),
+    "qfx_lora_down_batch": (C.c_int, [C.POINTER(LoraDownArgs), C.c_int32, _vp]),
     "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),
+    "qfx_lora_grad_batch": (C.c_int, [C.POINTER(LoraGradArgs), C.c_int32, _vp]),
     "qfx_lora_pack": (C.c_int, [_vp, _i32, _i32, _vp]),
     "qfx_ln_modulate_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f, _vp]),
     "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),

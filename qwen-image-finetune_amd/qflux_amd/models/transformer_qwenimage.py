@@ -522,6 +522,8 @@ class _QwenPlan:
         if self.has_lora:
             A["ext3"] = {s: buf(rows[s], 3 * kext_max, zero=True) for s in ("img", "txt")}
             A["ext1"] = {s: buf(rows[s], kext_max, zero=True) for s in ("img", "txt")}
+            A["VtO"] = {s: (buf(rp_max, _ceil(rows[s], 128), zero=True), buf(rp_max, _ceil(rows[s], 128), zero=True))
+                        for s in ("img", "txt")}
             A["Vt"] = {s: (buf(3 * rp_max, _ceil(rows[s], 128), zero=True), buf(3 * rp_max, _ceil(rows[s], 128), zero=True))
                        for s in ("img", "txt")}   # v^T hi/lo scratch (pad columns stay zero)
         A["dX"] = {s: [buf(rows[s], D), buf(rows[s], D)] for s in ("img", "txt")}
@@ -574,7 +576,7 @@ class _QwenPlan:
         prog.c(lib.qfx_gemm_grouped, arr, len(groups))
 
     def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
-              group_stride=0, rpb=None, x_map=(0, 0)):
+              group_stride=0, rpb=None, x_map=(0, 0), defer=None):
         a = L.LoraDownArgs()
         a.X, a.ldx, a.M, a.K = _ptr(X), ldx, M, K
         a.W_hi, a.W_lo, a.ldw, a.R = _ptr(W_hi), _ptr(W_lo), ldw, R
@@ -586,10 +588,28 @@ class _QwenPlan:
         a.group_stride = group_stride
         a.rows_per_batch = M if rpb is None else rpb
         a.x_batch_rows, a.x_row_off = x_map
+        if defer is not None:
+            defer.append(a)
+            return
         prog.keep.append(a)
         prog.c(lib.qfx_lora_down, C.byref(a))
 
-    def _grad(self, prog, *, Vt, R, r_valid, X, ldx, M, K, G, g_sr, g_sc, group_R=None, rpb=None, x_map=(0, 0), out_scale=1.0):
+    @staticmethod
+    def _flush_batch(prog, pending, struct, fn):
+        """Emit deferred skinny-kernel problems as batched launches: same R per launch, at most QFX_MAX_BATCH each."""
+        by_r = {}
+        for a in pending:
+            by_r.setdefault(a.R, []).append(a)
+        for _, lst in by_r.items():
+            for i in range(0, len(lst), L.MAX_BATCH):
+                chunk = lst[i:i + L.MAX_BATCH]
+                arr = (struct * len(chunk))(*chunk)
+                prog.keep.append(arr)
+                prog.c(fn, arr, len(chunk))
+        pending.clear()
+
+    def _grad(self, prog, *, Vt, R, r_valid, X, ldx, M, K, G, g_sr, g_sc, group_R=None, rpb=None, x_map=(0, 0), out_scale=1.0,
+              defer=None):
         a = L.LoraGradArgs()
         Gs = G if isinstance(G, (tuple, list)) else (G,)
         a.Vt_hi, a.Vt_lo, a.ldvt, a.R, a.r_valid = _ptr(Vt[0]), _ptr(Vt[1]), Vt[0].stride(0), R, r_valid
@@ -602,6 +622,9 @@ class _QwenPlan:
         a.rows_per_batch = M if rpb is None else rpb
         a.x_batch_rows, a.x_row_off = x_map
         a.out_scale = out_scale
+        if defer is not None:
+            defer.append(a)
+            return
         prog.keep.append(a)
         prog.c(lib.qfx_lora_grad, C.byref(a))
 
@@ -758,6 +781,9 @@ class _QwenPlan:
         dq2 = A["dqkv"].view(B * S, 3 * D)
         STREAMS = (("img", 0), ("txt", 1))
         i = 0 if first else 1
+        # LoRA weight gradients are leaves: every qfx_lora_grad of the block is deferred to ONE batched launch per rank at the
+        # end of the block (their X operands -- dyg1, ao, dqkv, xm1 -- stay intact until the next block's backward starts)
+        gl = []
         if True:
             ao2 = bb["ao"].view(B * S, D)
             live = [(s, sidx) for s, sidx in STREAMS if not (last and s == "txt")]
@@ -779,13 +805,13 @@ class _QwenPlan:
                 kw = {}
                 if lw.lora is not None:
                     lo = lw.lora
-                    Vt = (A["Vt"][s][0][:lo.Rp], A["Vt"][s][1][:lo.Rp])
+                    Vt = (A["VtO"][s][0][:lo.Rp], A["VtO"][s][1][:lo.Rp])
                     self._down(p, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0),
                                R=lo.Rp, Ut=Vt, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0))
                     self._grad(p, Vt=bb["Uo." + s], R=lo.Rp, r_valid=lo.r, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N,
-                               G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale)
+                               G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale, defer=gl)
                     self._grad(p, Vt=Vt, R=lo.Rp, r_valid=lo.r, X=ao2, ldx=D, M=rows[s], K=lw.K, G=lo.gA,
-                               g_sr=lw.K, g_sc=1, rpb=rpb[s], x_map=(S, off[s]))
+                               g_sr=lw.K, g_sc=1, rpb=rpb[s], x_map=(S, off[s]), defer=gl)
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
                 groups.append(self._gargs(A1=A["dyg1"][s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
                                           c_map=(S, off[s]), **kw))
@@ -800,6 +826,7 @@ class _QwenPlan:
                 _ptr(nk_i), B, S, T, H, dh, eps, norm_flags, self.rope_bs)
             # ---- q/k/v projection backward (+ LoRA), both streams in one launch
             groups = []
+            dl = []   # the q/k/v down projections of both streams: one batched launch
             for s, sidx in STREAMS:
                 grp = w[s + ".qkv_lora"]
                 kw = {}
@@ -816,23 +843,25 @@ class _QwenPlan:
                         sl = slice(sec * Rp, (sec + 1) * Rp)
                         self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=rows[s], K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo,
                                    ldw=lo.Bt_hi.stride(0), R=Rp, Ut=(Vth[sl], Vtl[sl]), ext=e3[:, sec * Kext:],
-                                   ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]))
+                                   ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]), defer=dl)
                         self._grad(p, Vt=(Uth[sl], Utl[sl]), R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D,
-                                   M=rows[s], K=D, G=lo.gB, g_sr=1, g_sc=lo.r, rpb=rpb[s], x_map=(S, off[s]), out_scale=lo.scale)
+                                   M=rows[s], K=D, G=lo.gB, g_sr=1, g_sc=lo.r, rpb=rpb[s], x_map=(S, off[s]), out_scale=lo.scale,
+                                   defer=gl)
                     los = [w[s + ".qkv"][sec].lora for sec in range(3)]
                     if all(l is not None for l in los):   # one pass over xm1 for dA of q, k and v
                         self._grad(p, Vt=(Vth[:3 * Rp], Vtl[:3 * Rp]), R=3 * Rp, r_valid=los[0].r, group_R=Rp, X=bb["xm1." + s],
-                                   ldx=D, M=rows[s], K=D, G=[l.gA for l in los], g_sr=D, g_sc=1)
+                                   ldx=D, M=rows[s], K=D, G=[l.gA for l in los], g_sr=D, g_sc=1, defer=gl)
                     else:
                         for sec, lo in enumerate(los):
                             if lo is not None:
                                 sl = slice(sec * Rp, (sec + 1) * Rp)
                                 self._grad(p, Vt=(Vth[sl], Vtl[sl]), R=Rp, r_valid=lo.r, X=bb["xm1." + s], ldx=D, M=rows[s],
-                                           K=D, G=lo.gA, g_sr=D, g_sc=1)
+                                           K=D, G=lo.gA, g_sr=D, g_sc=1, defer=gl)
                     kw = dict(A2=e3, lda2=e3.stride(0), B2=grp["WeT"], ldb2=grp["WeT"].stride(0), K2=3 * Kext)
                 if i > 0:   # nothing upstream of block 0 needs a gradient (frozen embedders, inputs without grad)
                     groups.append(self._gargs(A1=dq2, lda1=3 * D, B1=w[s + ".qkvT"], K1=3 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D,
                                               rpb=rpb[s], a_map=(S, off[s]), **kw))
+            self._flush_batch(p, dl, L.LoraDownArgs, lib.qfx_lora_down_batch)
             if i > 0:
                 self._gemm_group(p, groups)
                 for s, sidx in STREAMS:
@@ -841,6 +870,7 @@ class _QwenPlan:
                     p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(x_in[s]), _ptr(mods[s][:, D:2 * D]), 6 * D, _ptr(dres),
                         _ptr(gp), (gp.stride(0) if gp is not None else 0), _ptr(out_dx[s]), _ptr(A["dyg2"][s] if gp is not None else None),
                         rows[s], D, rpb[s], eps, _ptr(self.rmask[s]))
+        self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
 
     # ------------------------------------------------------------------ execution
     def run_forward(self, hidden_states, encoder_hidden_states, timestep):
