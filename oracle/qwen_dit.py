@@ -429,3 +429,21 @@ def qwen_compute_loss(dit: nn.Module, emb: dict, noise: torch.Tensor, u: torch.T
     target = noise - x0
     loss = mse_loss(pred, target, weighting)
     return (loss, pred) if return_pred else loss
+
+
+def mask_edit_loss(model_pred, target, edit_mask=None, fg=2.0, bg=1.0):
+    """MaskEditLoss.forward, reduction='mean', weighting=None (src/qflux/losses/edit_mask_loss.py:45-86)."""
+    el = (model_pred.float() - target.float()) ** 2
+    B, T, _ = model_pred.shape
+    m = torch.ones((B, T), dtype=torch.float32, device=model_pred.device) if edit_mask is None else edit_mask.float()
+    w = (m * fg + (1 - m) * bg).unsqueeze(-1)
+    return torch.mean((el * w).reshape(B, -1), 1).mean()
+
+
+def map_mask_to_latent(image_mask):
+    """src/qflux/losses/edit_mask_loss.py:7-36: 8x8 average pool, 2x2 patch maximum, flatten."""
+    B, H, W = image_mask.shape
+    lh, lw = H // 8, W // 8
+    m = torch.nn.functional.avg_pool2d(image_mask.float().unsqueeze(1), kernel_size=8, stride=8).squeeze(1)
+    p = m.reshape(B, lh // 2, 2, lw // 2, 2).permute(0, 1, 3, 2, 4).contiguous().view(B, lh // 2, lw // 2, 4)
+    return p.max(dim=-1)[0].view(B, (lh // 2) * (lw // 2))

@@ -34,9 +34,24 @@ def flowmatch_tables(num_train_timesteps: int = 1000, shift: float = 1.0):
     return sig * num_train_timesteps, sig
 
 
+def map_mask_to_latent(image_mask: torch.Tensor) -> torch.Tensor:
+    """[B,H,W] pixel-space edit mask -> [B, (H/16)(W/16)] packed-latent token mask: 8x8 average pool (VAE stride), then
+    the maximum over each 2x2 packing patch (src/qflux/losses/edit_mask_loss.py:7-36).  Host-side plumbing."""
+    B, H, W = image_mask.shape
+    lh, lw = H // 8, W // 8
+    m = torch.nn.functional.avg_pool2d(image_mask.float().unsqueeze(1), kernel_size=8, stride=8).squeeze(1)
+    m = m.reshape(B, lh // 2, 2, lw // 2, 2).permute(0, 1, 3, 2, 4).reshape(B, lh // 2, lw // 2, 4)
+    return m.max(dim=-1)[0].reshape(B, (lh // 2) * (lw // 2))
+
+
 class QwenLoraTrainStep:
     def __init__(self, dit, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
-                 weight_dtype=BF, process_group=None):
+                 weight_dtype=BF, process_group=None, criterion="mse", forground_weight=2.0, background_weight=1.0):
+        """criterion: "mse" = MseLoss (losses/mse_loss.py:46-83); "mask_edit" = MaskEditLoss(forground_weight,
+        background_weight) (losses/edit_mask_loss.py:39-90), fed by embeddings["edit_mask"] [B,S_t] (all-ones when absent)."""
+        if criterion not in ("mse", "mask_edit"):
+            raise ValueError(f"unknown criterion {criterion!r}")
+        self.criterion, self.fg, self.bg = criterion, float(forground_weight), float(background_weight)
         self.dit = dit
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -81,7 +96,14 @@ class QwenLoraTrainStep:
                         return_dict=False)[0]
         pred = pred[:, :S_t]
         el = (pred.float() - target.float()) ** 2            # MseLoss with weighting = 1 (mse_loss.py:71-81)
+        if self.criterion == "mask_edit":                      # MaskEditLoss, reduction="mean" (edit_mask_loss.py:62-86)
+            el = el * self._token_weights(embeddings, target.shape[0], S_t, el.device).unsqueeze(-1)
         return torch.mean(el.reshape(target.shape[0], -1), dim=1).mean()
+
+    def _token_weights(self, embeddings, B, S_t, dev):
+        m = embeddings.get("edit_mask")
+        m = torch.ones(B, S_t) if m is None else m.float()
+        return (m * self.fg + (1.0 - m) * self.bg).to(dev).contiguous()
 
     # ------------------------------------------------------------------ fused path
     def forward_backward(self, embeddings, noise=None, u=None, grad_scale=1.0):
@@ -91,7 +113,12 @@ class QwenLoraTrainStep:
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
         dit.lora_store  # make sure the flat buffers / grads are attached
         pred = plan.run_forward(packed, pe, t_in)
-        loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
+        if self.criterion == "mask_edit":
+            B = packed.shape[0]
+            tw = self._token_weights(embeddings, B, S_t, pred.device)
+            loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
+        else:
+            loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
         plan.run_backward(dpred)
         return loss
 

@@ -435,6 +435,34 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("multi-res reference check FAILED:", repr(e))
         raise
+    # ---------------- criteria: the reference's OWN loss classes (importable without diffusers) ----------------
+    for m_ in ("qflux.losses",):
+        if m_ not in sys.modules:
+            pk = types.ModuleType(m_); pk.__path__ = [os.path.join(REF, "src", "qflux", "losses")]; sys.modules[m_] = pk
+    mse_mod = importlib.import_module("qflux.losses.mse_loss")
+    em_mod = importlib.import_module("qflux.losses.edit_mask_loss")
+    am_mod = importlib.import_module("qflux.losses.attention_mask_loss")
+    g = torch.Generator().manual_seed(77)
+    pr = torch.randn(2, 12, 8, generator=g); tg = torch.randn(2, 12, 8, generator=g)
+    em = (torch.rand(2, 12, generator=g) > 0.5).float()
+    am = torch.ones(2, 12, dtype=torch.bool); am[0, 9:] = False
+    pix = (torch.rand(2, 64, 96, generator=g) > 0.7).float()
+    out = {"pred": pr, "target": tg, "edit_mask": em, "attention_mask": am.to(torch.uint8), "pixel_mask": pix,
+           "mse": mse_mod.MseLoss()(model_pred=pr, target=tg).reshape(1),
+           "mask_edit_2_1": em_mod.MaskEditLoss(2.0, 1.0)(model_pred=pr, target=tg, edit_mask=em).reshape(1),
+           "mask_edit_none": em_mod.MaskEditLoss(2.0, 1.0)(model_pred=pr, target=tg, edit_mask=None).reshape(1),
+           "latent_mask": em_mod.map_mask_to_latent(pix)}
+    AM = am_mod.AttentionMaskMseLoss
+    try:
+        out["attn_mask_mse"] = AM()(model_pred=pr, target=tg, attention_mask=am, edit_mask=None).reshape(1)
+    except TypeError:
+        out["attn_mask_mse"] = AM(reduction="mean")(model_pred=pr, target=tg, attention_mask=am, edit_mask=None).reshape(1)
+    assert abs(O.mask_edit_loss(pr, tg, em).item() - out["mask_edit_2_1"].item()) < 1e-6
+    assert torch.equal(O.map_mask_to_latent(pix), out["latent_mask"])
+    assert abs(FO.attention_mask_mse_loss(pr, tg, am).item() - out["attn_mask_mse"].item()) < 1e-6
+    assert abs(O.mse_loss(pr, tg).item() - out["mse"].item()) < 1e-6
+    save_file({k: v.contiguous().clone() for k, v in out.items()}, os.path.join(HERE, "losses.safetensors"))
+    print("criteria: oracle == reference MseLoss / MaskEditLoss / AttentionMaskMseLoss / map_mask_to_latent")
     print("wrote golden vectors to", HERE)
 
 

@@ -36,3 +36,13 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.qfx_attn_fwd(C.byref(a), None) == -1
     with pytest.raises(_lib.QfxError):
         _lib.check(-1, "x")
+
+
+def test_map_mask_to_latent_host_helper_matches_reference_vectors():
+    """Host-side plumbing of the edit-mask criterion (no GPU needed): pixel mask -> packed-latent token mask."""
+    import os
+    import torch
+    from safetensors.torch import load_file
+    from qflux_amd.trainer import map_mask_to_latent
+    t = load_file(os.path.join(os.path.dirname(__file__), "golden", "losses.safetensors"))
+    assert torch.equal(map_mask_to_latent(t["pixel_mask"]), t["latent_mask"])

@@ -101,3 +101,33 @@ def test_zero_grad_set_to_none_is_survived():
         g.append(hip.lora_parameters()[0].grad.clone())
         opt.zero_grad()  # set_to_none=True
     assert torch.allclose(g[0], g[1], rtol=1e-3, atol=1e-6)  # no stale accumulation, grads re-attached
+
+
+def test_mask_edit_criterion_step_matches_oracle():
+    """MaskEditLoss(2,1) (edit_mask_loss.py:45-90) through the fused step (token-weighted criterion kernel) and the autograd
+    path vs the oracle criterion applied to the oracle's prediction; LoRA grads compared too."""
+    from common import TINY
+    from parity_util import build_pair, tiny_embeddings
+    from oracle import qwen_dit as O
+    from qflux_amd.trainer import QwenLoraTrainStep
+    oracle, hip = build_pair(dict(TINY), device=DEV)
+    emb, noise, u = tiny_embeddings()
+    g = torch.Generator().manual_seed(9)
+    emb = dict(emb, edit_mask=(torch.rand(emb["image_latents"].shape[:2], generator=g) > 0.5).float())
+    BF = torch.bfloat16
+    _, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+    target = noise.to(BF) - emb["image_latents"].to(BF)
+    lo = O.mask_edit_loss(pred_o, target, emb["edit_mask"], 2.0, 1.0)
+    lo.backward()
+    step = QwenLoraTrainStep(hip, criterion="mask_edit", forground_weight=2.0, background_weight=1.0)
+    lh = step.forward_backward(emb, noise, u)
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    worst = 0.0
+    for n, p in hip.named_parameters():
+        if "lora" in n and og.get(n) is not None and og[n].abs().max() > 0:
+            worst = max(worst, ((p.grad.cpu() - og[n]).abs().max() / og[n].abs().max()).item())
+    la = step.compute_loss(emb, noise, u)
+    print("mask_edit loss oracle/hip/autograd", lo.item(), lh.item(), la.item(), "grad worst", worst)
+    assert abs(lh.item() - lo.item()) / abs(lo.item()) < 5e-3
+    assert abs(la.item() - lo.item()) / abs(lo.item()) < 5e-3
+    assert worst < 5e-2

@@ -152,3 +152,16 @@ def test_attention_mask_mse_loss_semantics():
     want = sum(((p[b, :n] - q[b, :n]) ** 2).mean(dim=1).sum() for b, n in ((0, 3), (1, 5))) / 8
     got = FO.attention_mask_mse_loss(p, q, mk)
     assert abs(got.item() - want.item()) < 1e-6
+
+
+def test_criteria_match_reference_loss_classes(golden_dir):
+    """Vectors produced by the reference's own MseLoss / MaskEditLoss / AttentionMaskMseLoss / map_mask_to_latent."""
+    from oracle import flux_dit as FO
+    from oracle import qwen_dit as O
+    t = load_file(os.path.join(golden_dir, "losses.safetensors"))
+    pr, tg, em, am = t["pred"], t["target"], t["edit_mask"], t["attention_mask"].bool()
+    assert abs(O.mse_loss(pr, tg).item() - t["mse"].item()) < 1e-6
+    assert abs(O.mask_edit_loss(pr, tg, em, 2.0, 1.0).item() - t["mask_edit_2_1"].item()) < 1e-6
+    assert abs(O.mask_edit_loss(pr, tg, None, 2.0, 1.0).item() - t["mask_edit_none"].item()) < 1e-6
+    assert abs(FO.attention_mask_mse_loss(pr, tg, am).item() - t["attn_mask_mse"].item()) < 1e-6
+    assert torch.equal(O.map_mask_to_latent(t["pixel_mask"]), t["latent_mask"])
