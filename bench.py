@@ -55,6 +55,21 @@ def gemm_flops_of(prog):
     return tot, n
 
 
+def gemm_bytes_of(*progs):
+    """Algorithmic HBM bytes of the GEMM launches: every operand and output touched once (bf16), aux/bias included."""
+    from qflux_amd import _lib as L
+    tot = 0
+    for prog in progs:
+        for g in prog.keep:
+            gs = [g] if isinstance(g, L.GemmArgs) else (list(g) if isinstance(g, C.Array) and len(g) and isinstance(g[0], L.GemmArgs) else [])
+            for x in gs:
+                k = x.K1 + x.K2
+                outs = 2 if x.epi == L.EPI_GELU else 1
+                aux = 1 if x.epi in (L.EPI_GATE_RES, L.EPI_DGELU) else 0
+                tot += 2 * (x.M * k + x.N * k + (outs + aux) * x.M * x.N)
+    return tot
+
+
 def run_profiled(prog, fn_target):
     """Replay a program with a HIP event pair around every launch of `fn_target`; returns summed ms and count."""
     st_obj = torch.cuda.current_stream()
@@ -196,6 +211,16 @@ def main():
     cfgd = dit.config
     fwd_fl, bwd_fl = algorithmic_flops(cfgd.num_layers, dit.inner_dim, 2 * S_t, T, Jd, cfgd.in_channels, dit.proj_out.out_features,
                                        args.rank, 4)
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the committed
+    # rocprofv3 passes (profiles/r01_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
+    # FETCH_SIZE x2 gfx950 correction) give bytes per launch of the same kernel on the same workload.
+    traffic = None
+    try:
+        if B == 1 and args.layers == 60 and args.res == 512 and args.rank == 16:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+                traffic = json.load(fh)["kernels"]["gemm256_kernel"]["traffic_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        traffic = None
     out = {
         "metric": "train images/sec, Qwen-Image-Edit LoRA r=16 bf16 512^2, cached-embed",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +235,9 @@ def main():
                    "loss": float(loss.item())},
         "roofline": {"bound": "mfma", "kernel": "gemm256_kernel / gemm_kernel (qfx_gemm_grouped + qfx_gemm_bf16, all epilogue variants)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                     "traffic": None, "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
+                     "traffic": traffic, "traffic_unit": "bytes per launch, L2 fabric side incl. Infinity-Cache hits (committed PMC pass)",
+                     "algorithmic_bytes_per_launch": int(gemm_bytes_of(plan.fwd, plan.bwd) / n_launch),
+                     "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                      "gemm_share_of_step": round(gemm_ms / ms_per_step, 3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

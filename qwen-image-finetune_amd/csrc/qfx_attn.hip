@@ -104,6 +104,20 @@ __device__ __forceinline__ bf16x8 colfrag_at(const char* lds, int o1, int o2) {
   return r;
 }
 
+// 1-D grid -> (seq block, head, batch) with an XCD-aware bijection: hardware dispatches workgroup i to XCD i % 8, so the
+// virtual id walks each XCD through a CONTIGUOUS range of (batch, head, block) triples: all blocks of one head run on
+// one XCD and its K/V (or Q/dO) tiles are fetched into one L2 instead of eight (PMC: fabric-side fetch per launch was
+// 6x the tensor bytes with the plain blockIdx.x-fastest order).
+__device__ __forceinline__ void attn_block_coord(int nx, int H, int& xb, int& h, int& b) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  xb = v % nx;
+  const int hb = v / nx;
+  h = hb % H;
+  b = hb / H;
+}
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 // =============================================================================================
@@ -116,8 +130,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  int xb, h, b;
+  attn_block_coord((a.S + 127) / 128, a.H, xb, h, b);
+  const int q0 = xb * 128 + w * 32;
   const int S = a.S;
 
   const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
@@ -304,8 +319,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + w * 32;
+  int xb, h, b;
+  attn_block_coord((a.S + 127) / 128, a.H, xb, h, b);
+  const int q0 = xb * 128 + w * 32;
   const int S = a.S;
   const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
   const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
@@ -502,8 +518,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int kb = blockIdx.x * 256;
+  int xb, h, b;
+  attn_block_coord((a.S + 255) / 256, a.H, xb, h, b);
+  const int kb = xb * 256;
   const int key0 = kb + w * 32;
   const int S = a.S;
   const bf16_t* Qb = a.Q + (int64_t)b * S * a.ldq + h * DH;
@@ -677,7 +694,7 @@ extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return QFX_EINVAL;
-  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  dim3 grid(((a->S + 127) / 128) * a->H * a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   QFX_CHECK_LAUNCH();
@@ -702,7 +719,7 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
-  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  dim3 grid(((a->S + 127) / 128) * a->H * a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   QFX_CHECK_LAUNCH();
@@ -714,7 +731,7 @@ extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
-  dim3 grid((a->S + 255) / 256, a->H, a->B);
+  dim3 grid(((a->S + 255) / 256) * a->H * a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(512), 0, (hipStream_t)stream, *a);
   QFX_CHECK_LAUNCH();
