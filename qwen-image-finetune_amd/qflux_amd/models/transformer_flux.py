@@ -476,6 +476,7 @@ class _FluxPlan(_QwenPlan):
                 nxt = cur ^ 1
                 self._emit_single_bwd(p, P["singles"][i], A["sblk"][i], self.sattn_args[i], A["smods"][i], A["J"][i],
                                       dJ_out=A["dJ"][cur], dJ_in=A["dJ"][nxt], i=i, Ld=Ld)
+                p.mark(f"single_transformer_blocks.{i}.")
                 cur = nxt
             if Ld == 0:
                 return
@@ -492,6 +493,7 @@ class _FluxPlan(_QwenPlan):
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][dcur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
                                   gate_prev=gate_prev, last=(i + 1 == Ld and Ls == 0), first=(i == 0), norm_flags=self.NORM_FLAGS)
+            p.mark(f"transformer_blocks.{i}.")
             dcur = nxt
 
     def _emit_single_bwd(self, p, w, bb, a, mod, x, dJ_out, dJ_in, i, Ld):

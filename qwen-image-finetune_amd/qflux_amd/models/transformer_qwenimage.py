@@ -119,6 +119,7 @@ class _Prog:
     def __init__(self):
         self.calls = []
         self.keep = []
+        self.marks = []   # (call index, parameter-name prefix): every LoRA gradient under `prefix` is final after calls[:index]
 
     def c(self, fn, *args):
         self.calls.append((fn, args))
@@ -126,9 +127,12 @@ class _Prog:
     def py(self, fn):
         self.calls.append((None, fn))
 
-    def run(self):
+    def mark(self, prefix: str):
+        self.marks.append((len(self.calls), prefix))
+
+    def run(self, start: int = 0, end: int | None = None):
         st = torch.cuda.current_stream().cuda_stream
-        for fn, args in self.calls:
+        for fn, args in self.calls[start:end]:
             if fn is None:
                 args()
             else:
@@ -768,6 +772,7 @@ class _QwenPlan:
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
                                   gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0), norm_flags=0)
+            p.mark(f"transformer_blocks.{i}.")
             cur = nxt
 
     def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags):
@@ -882,10 +887,20 @@ class _QwenPlan:
         self.fwd.run()
         return A["out"].view(self.B, self.S_i, -1)
 
-    def run_backward(self, dpred):
+    def run_backward(self, dpred, on_segment=None):
+        """on_segment(prefixes): called after each marked segment of the backward program with the parameter-name prefixes
+        whose LoRA gradients just became final (data-parallel bucketed all-reduce hooks in here)."""
         self.A["dpred"].view(self.B, self.S_i, -1).copy_(dpred)
         self.model._lora.ensure_grads()
-        self.bwd.run()
+        if on_segment is None:
+            self.bwd.run()
+            return
+        pos = 0
+        for idx, prefix in self.bwd.marks:
+            self.bwd.run(pos, idx)
+            pos = idx
+            on_segment(prefix)
+        self.bwd.run(pos, None)
 
 
 class _QwenDiTFn(torch.autograd.Function):

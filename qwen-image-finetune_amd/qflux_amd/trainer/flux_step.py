@@ -53,7 +53,7 @@ class FluxKontextTrainStep(QwenLoraTrainStep):
         dit.lora_store
         pred = plan.run_forward((packed, pooled, guidance), pe, t)
         loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
-        plan.run_backward(dpred)
+        plan.run_backward(dpred, on_segment=self._bucket_hook() if self.world > 1 else None)
         return loss
 
     def train_step(self, embeddings, noise=None, t=None):
@@ -132,7 +132,7 @@ def _forward_backward_multires(self, samples, txt, grad_scale=1.0):
     pred = plan.run_forward((b["inp"], b["pooled"], b["guidance"]), b["pe"], b["timestep"])
     loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, b["target"], b["tok_w"].contiguous(), b["n_t_max"], 1.0 / (b["n_valid"] + 1e-12),
                                                  gscale=grad_scale)
-    plan.run_backward(dpred)
+    plan.run_backward(dpred, on_segment=self._bucket_hook() if self.world > 1 else None)
     return loss
 
 

@@ -46,7 +46,8 @@ def map_mask_to_latent(image_mask: torch.Tensor) -> torch.Tensor:
 
 class QwenLoraTrainStep:
     def __init__(self, dit, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
-                 weight_dtype=BF, process_group=None, criterion="mse", forground_weight=2.0, background_weight=1.0):
+                 weight_dtype=BF, process_group=None, criterion="mse", forground_weight=2.0, background_weight=1.0,
+                 bucket_mb=24.0):
         """criterion: "mse" = MseLoss (losses/mse_loss.py:46-83); "mask_edit" = MaskEditLoss(forground_weight,
         background_weight) (losses/edit_mask_loss.py:39-90), fed by embeddings["edit_mask"] [B,S_t] (all-ones when absent)."""
         if criterion not in ("mse", "mask_edit"):
@@ -62,6 +63,11 @@ class QwenLoraTrainStep:
         self.global_step = 0
         self._m = self._v = None
         self._gnorm = None
+        # data-parallel exchange overlapped with the backward: the flat gradient is all-reduced in buckets of whole DiT
+        # blocks as soon as their backward segment has been enqueued (the gradient of block i is final when its segment ends)
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self._pending = []
+        self._reduced = False
 
     # ------------------------------------------------------------------ sampling (CPU RNG like the reference)
     def sample_timesteps(self, batch_size, u=None):
@@ -119,13 +125,51 @@ class QwenLoraTrainStep:
             loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
         else:
             loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
-        plan.run_backward(dpred)
+        plan.run_backward(dpred, on_segment=self._bucket_hook() if self.world > 1 else None)
         return loss
 
+    # ------------------------------------------------------------------ bucketed all-reduce behind the backward
+    def _bucket_hook(self):
+        st = self.dit.lora_store
+        ents = st.entries
+        todo = set(range(len(ents)))
+        acc = []          # entry indices final but not yet reduced
+        self._pending, self._reduced = [], False
+
+        def flush(force=False):
+            nbytes = sum(((ents[i][3] + 63) // 64 * 64) * 4 for i in acc)
+            if not acc or (not force and nbytes < self.bucket_bytes):
+                return
+            for lo, hi in _contiguous_runs(sorted(acc), ents):
+                self._pending.append(dist.all_reduce(st.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            acc.clear()
+
+        def hook(prefix):
+            done = [i for i in todo if ents[i][0].startswith(prefix)]
+            todo.difference_update(done)
+            acc.extend(done)
+            flush()
+
+        def finish():
+            acc.extend(sorted(todo))   # adapters outside the marked blocks, if any
+            todo.clear()
+            flush(force=True)
+
+        self._finish_buckets = finish
+        return hook
+
     def allreduce_grads(self):
+        """Returns the factor the optimizer applies to the summed gradient (1/world)."""
         if self.world > 1:
-            g = self.dit.lora_store.gflat
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            fin = getattr(self, "_finish_buckets", None)
+            if fin is not None:
+                fin()
+                self._finish_buckets = None
+                for w in self._pending:
+                    w.wait()
+                self._pending = []
+            else:   # no bucketed backward ran (drop-in autograd path): one all-reduce of the whole flat buffer
+                dist.all_reduce(self.dit.lora_store.gflat, op=dist.ReduceOp.SUM, group=self.group)
             return 1.0 / self.world
         return 1.0
 
@@ -160,6 +204,19 @@ class QwenLoraTrainStep:
             dist.all_gather(out, loss, group=self.group)
             return torch.stack(out).mean()
         return loss
+
+
+def _contiguous_runs(idx, ents):
+    """Entry indices -> [lo, hi) element ranges of the flat buffer, merged where adjacent (64-element padded slots)."""
+    runs = []
+    for i in idx:
+        lo = ents[i][2]
+        hi = lo + (ents[i][3] + 63) // 64 * 64
+        if runs and runs[-1][1] == lo:
+            runs[-1][1] = hi
+        else:
+            runs.append([lo, hi])
+    return [(a, b) for a, b in runs]
 
 
 def init_distributed_from_env():

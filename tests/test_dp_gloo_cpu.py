@@ -73,3 +73,80 @@ def test_flat_lora_grad_allreduce_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _worker_buckets(rank, world, port, q):
+    """Bucketed exchange: segments of a (fake) backward program finalise the gradients of whole blocks; the hook
+    all-reduces contiguous ranges of the flat buffer asynchronously; allreduce_grads() drains them."""
+    sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qflux_amd.modules import LoraStore, QfxLinear, QfxLoraLinear
+    from qflux_amd.trainer import QwenLoraTrainStep
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_q = QfxLoraLinear(QfxLinear(8, 8), 4, 8, "ad")
+            self.to_k = QfxLoraLinear(QfxLinear(8, 8), 4, 8, "ad")
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.transformer_blocks = nn.ModuleList([Blk() for _ in range(5)])
+            self.extra = QfxLoraLinear(QfxLinear(8, 8), 4, 8, "ad")   # an adapter outside the marked blocks
+            self._store = LoraStore(self)
+            self._store.rebuild("cpu")
+
+        @property
+        def lora_store(self):
+            return self._store
+
+        device = torch.device("cpu")
+
+    toy = Toy()
+    st = toy.lora_store
+    # tiny bucket size: every block flushes on its own -> several async all-reduces in flight
+    step = QwenLoraTrainStep(toy, bucket_mb=1e-4)
+    hook = step._bucket_hook()
+    calls = []
+    for i in range(4, -1, -1):   # backward order: last block first
+        for n, p in toy.named_parameters():
+            if n.startswith(f"transformer_blocks.{i}.") and "lora_" in n:
+                p.grad.fill_(float((rank + 1) * (i + 1)))
+        hook(f"transformer_blocks.{i}.")
+        calls.append(len(step._pending))
+    for n, p in toy.named_parameters():
+        if n.startswith("extra.") and "lora_" in n:
+            p.grad.fill_(float(10 * (rank + 1)))
+    scale = step.allreduce_grads()
+    tot = sum(range(1, world + 1))
+    ok = abs(scale - 1.0 / world) < 1e-12 and calls == sorted(calls) and calls[-1] >= 5 and not step._pending
+    for n, p in toy.named_parameters():
+        if "lora_" not in n:
+            continue
+        if n.startswith("extra."):
+            ok = ok and bool(p.grad.eq(10.0 * tot).all())
+        else:
+            i = int(n.split(".")[1])
+            ok = ok and bool(p.grad.eq(float(tot * (i + 1))).all())
+    # a second step without a bucketed backward falls back to the single all-reduce
+    st.gflat.fill_(float(rank + 1))
+    step.allreduce_grads()
+    ok = ok and bool(st.gflat.eq(float(tot)).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_behind_backward_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_buckets, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res
