@@ -113,13 +113,15 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
 // token-major X tile goes through LDS and comes back as MFMA B fragments with ds_read_b64_tr_b16
 // (gfx950 hardware transpose read): within a 16-lane group, lane s supplies 8 bytes
 // {row 8g+4h+(s>>2), cols 4(s&3)..+3} and receives {rows 8g+4h+0..3, col s}.
-// grid = (K/128, token chunks of 128); block = 4 waves x 32 columns; fp32 atomics into G.
+// grid = (K/128, token chunks of GRAD_CH); block = 4 waves x 32 columns; fp32 atomics into G.
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
 constexpr int GX_ROWB = 288;  // padded LDS row stride (bytes) of the [32 tokens][128 cols] tile
 
+constexpr int GRAD_CH = 512;   // tokens per block: 4x fewer device-scope fp32 atomics per output element than 128 (the atomics
+                               // of the M/CH partial sums, not the 15 MB stream, bounded the 128-token version)
 template <int NF>
 __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by_value) {
-  constexpr int CH = 128;  // tokens per block
+  constexpr int CH = GRAD_CH;
   __shared__ __attribute__((aligned(16))) char sX[2][32 * GX_ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,31 +135,26 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
   const int k0 = blockIdx.x * 128;
   if (k0 >= p.K) return;   // grid.x is sized for the widest problem of the batch
   const int mb = ((int)blockIdx.y - kb.start[pi]) * CH;
-  const int nsteps = ((p.M - mb < CH ? p.M - mb : CH) + 31) / 32;
+  const int nsteps = ((p.M - mb < CH ? p.M - mb : CH) + 31) / 32;   // 32 tokens per step
+  const int nquads = (nsteps + 3) / 4;
 
   // staging: thread -> (token row tid/16 + 16*it, 16-byte chunk tid%16)
   const int srow = tid >> 4, sch = tid & 15;
   int kc = k0 + sch * 8;
-  const bool kok = kc < p.K;
-  kc = kok ? kc : 0;
-  // 4 steps of 32 tokens per block: all of the block's X rows are requested up front (one HBM latency per block instead
-  // of one per step); the LDS tile is double-buffered.
-  constexpr int NST = CH / 32;
-  u32x4 st[NST][2];
+  kc = kc < p.K ? kc : 0;
+  // X rows are requested a whole quad (4 steps = 128 tokens) ahead of their use; the LDS tile is double-buffered.
+  u32x4 st[4][2], stn[4][2];
+  auto gload = [&](int quad, u32x4 (&dst)[4][2]) {
 #pragma unroll
-  for (int step = 0; step < NST; ++step)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      int m = mb + step * 32 + it * 16 + srow;
-      m = m < p.M ? m : p.M - 1;
-      const bf16_t* src = p.X + remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + kc;
-      st[step][it] = *(const u32x4*)src;
-    }
-  auto swrite = [&](int step) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) *(u32x4*)(&sX[step & 1][(it * 16 + srow) * GX_ROWB + sch * 16]) = st[step][it];
+      for (int it = 0; it < 2; ++it) {
+        int m = mb + (quad * 4 + j) * 32 + it * 16 + srow;
+        m = m < p.M ? m : p.M - 1;
+        const bf16_t* src = p.X + remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + kc;
+        dst[j][it] = *(const u32x4*)src;
+      }
   };
-
   f32x4 acc[NF][2];
 #pragma unroll
   for (int i = 0; i < NF; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
@@ -173,35 +170,43 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
       al[slot][nf] = *(const bf16x8*)(p.Vt_lo + ro);
     }
   };
+  gload(0, st);
   vload(0, 0);
-  swrite(0);
-  __syncthreads();
+  int buf = 0;
+  for (int q = 0; q < nquads; ++q) {
+    if (q + 1 < nquads) gload(q + 1, stn);
 #pragma unroll
-  for (int s = 0; s < NST; ++s) {
-    if (s + 1 < NST && s + 1 < nsteps) vload(s + 1, (s + 1) & 1);
-    if (s < nsteps) {
-      const char* tile = sX[s & 1];
-      bf16x8 b[2];
+    for (int j = 0; j < 4; ++j) {
+      const int s = q * 4 + j;
+      if (s < nsteps) {   // block-uniform
 #pragma unroll
-      for (int cf = 0; cf < 2; ++cf) {
-        const int colb = (w * 32 + cf * 16 + 4 * (li & 3)) * 2;
-        const char* a0 = tile + (8 * g + (li >> 2)) * GX_ROWB + colb;
-        const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0));
-        const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0 + 4 * GX_ROWB));
-        const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-        b[cf][0] = l4[0]; b[cf][1] = l4[1]; b[cf][2] = l4[2]; b[cf][3] = l4[3];
-        b[cf][4] = h4[0]; b[cf][5] = h4[1]; b[cf][6] = h4[2]; b[cf][7] = h4[3];
-      }
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
+        for (int it = 0; it < 2; ++it) *(u32x4*)(&sX[buf][(it * 16 + srow) * GX_ROWB + sch * 16]) = st[j][it];
+        __syncthreads();   // tile s visible; every wave is past its reads of tile s-2 (same buffer)
+        if (s + 1 < nsteps) vload(s + 1, (j + 1) & 1);
+        const char* tile = sX[buf];
+        bf16x8 b[2];
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf) {
-          acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][nf], b[cf], acc[nf][cf], 0, 0, 0);
-          acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][nf], b[cf], acc[nf][cf], 0, 0, 0);
+          const int colb = (w * 32 + cf * 16 + 4 * (li & 3)) * 2;
+          const char* a0 = tile + (8 * g + (li >> 2)) * GX_ROWB + colb;
+          const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0));
+          const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(a0 + 4 * GX_ROWB));
+          const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+          b[cf][0] = l4[0]; b[cf][1] = l4[1]; b[cf][2] = l4[2]; b[cf][3] = l4[3];
+          b[cf][4] = h4[0]; b[cf][5] = h4[1]; b[cf][6] = h4[2]; b[cf][7] = h4[3];
         }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int cf = 0; cf < 2; ++cf) {
+            acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j & 1][nf], b[cf], acc[nf][cf], 0, 0, 0);
+            acc[nf][cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j & 1][nf], b[cf], acc[nf][cf], 0, 0, 0);
+          }
+        buf ^= 1;
+      }
     }
-    if (s + 1 < NST) swrite(s + 1);
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st[j][0] = stn[j][0]; st[j][1] = stn[j][1]; }
   }
   // D[i = rank 4g+r][j = col li]
 #pragma unroll
@@ -332,7 +337,7 @@ extern "C" int qfx_lora_grad_batch(const qfx_lora_grad_args* list, int32_t n, vo
     if (list[i].R != list[0].R) return QFX_EINVAL;
     b.a[i] = list[i];
     b.start[i] = chunks;
-    chunks += (list[i].M + 127) / 128;
+    chunks += (list[i].M + GRAD_CH - 1) / GRAD_CH;
     kmax = list[i].K > kmax ? list[i].K : kmax;
   }
   for (int i = n; i <= QFX_MAX_BATCH; ++i) b.start[i] = chunks;

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(512 + 64 * NLD, 1) void kws(const bf16_t* __restric
     setp(ibid);
     int ist = 0;   // stage of the next issue
     auto issue = [&]() {
+      if constexpr (ABLW & 16) { ist = ist + 1 == NST ? 0 : ist + 1; if (++it == nt) { it = 0; ibid += gridDim.x; } return; }
       char* sA = smem + ist * STAGE; char* sB = sA + BM * 128;
       int kt = it + rot; kt = kt >= nt ? kt - nt : kt;
 #pragma unroll
@@ -269,6 +270,9 @@ extern "C" int lab_gemm(int var, const void* A, const void* B, void* C, int M, i
     case 20: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 1>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
     case 21: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 4>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
     case 22: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 8>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 23: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 16>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 24: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 17>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
+    case 25: hipLaunchKernelGGL((kws<2, 0, 2, 0, 8, 24>), dim3(grid), dim3(640), 0, s, a, b, c, M, N, K); break;
     case 4: hipLaunchKernelGGL((kws<1, 0>), dim3(grid), dim3(576), 0, s, a, b, c, M, N, K); break;
     default: return -1;
   }
