@@ -220,13 +220,18 @@ def _contiguous_runs(idx, ents):
 
 
 def init_distributed_from_env():
-    """One process per GPU; backend "nccl" is RCCL on ROCm.  Returns (rank, local_rank, world)."""
+    """One process per GPU; backend "nccl" is RCCL on ROCm.  Returns (rank, local_rank, world).
+    Test hooks: QFX_DIST_BACKEND=gloo and QFX_SHARE_GPU=1 let several ranks share device 0 (RCCL refuses duplicate devices), so
+    the multi-rank code path can be exercised on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("QFX_SHARE_GPU") == "1":
+        local = 0
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)   # before the process group: RCCL binds to the current device
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        backend = os.environ.get("QFX_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world

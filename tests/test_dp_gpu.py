@@ -68,3 +68,22 @@ def test_two_ranks_one_gpu_stay_identical_and_match_manual_average():
     rel = ((f0 - ref).abs().max() / ref.abs().max()).item()
     print("2-rank vs manual average: rel", rel, "losses", res[0][2], res[1][2])
     assert rel < 1e-5    # fp32 atomics order differs, nothing else
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """The driver's N>1 launch line (torch.distributed.run, one process per rank) on the bench itself, 2 DiT blocks, both ranks
+    on device 0 over gloo: barrier / max-over-ranks timing / single JSON line from rank 0 / whole-job images per second."""
+    import json
+    import subprocess
+    env = dict(os.environ, QFX_DIST_BACKEND="gloo", QFX_SHARE_GPU="1")
+    port = 34500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2",
+           "--res", "256"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    assert abs(r["value"] - 2 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3
+    assert "cpu_baseline" not in r    # rank 0 at N=1 only

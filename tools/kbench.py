@@ -97,7 +97,9 @@ def main():
     t = timeit(lambda: ops.lora_down(xx, wh, wl, U=U, ext=ext, group_R=16, group_stride=64))
     res["lora_down_R48"] = dict(us=t * 1e6, gbps=M * K * 2 / t / 1e9)
     G = torch.zeros(R, K, device=DEV)
-    t = timeit(lambda: ops.lora_grad(U, xx, G, K, 1))
+    Mp = (M + 127) // 128 * 128
+    Vt = (torch.randn(R, Mp, device=DEV).to(BF), torch.randn(R, Mp, device=DEV).to(BF))
+    t = timeit(lambda: ops.lora_grad(Vt, xx, G, K, 1, M=M))
     res["lora_grad_R48"] = dict(us=t * 1e6, gbps=M * K * 2 / t / 1e9)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "kbench.json"), "w") as f:
