@@ -447,3 +447,35 @@ def map_mask_to_latent(image_mask):
     m = torch.nn.functional.avg_pool2d(image_mask.float().unsqueeze(1), kernel_size=8, stride=8).squeeze(1)
     p = m.reshape(B, lh // 2, 2, lw // 2, 2).permute(0, 1, 3, 2, 4).contiguous().view(B, lh // 2, lw // 2, 4)
     return p.max(dim=-1)[0].view(B, (lh // 2) * (lw // 2))
+
+
+def qwen_sample(dit: nn.Module, emb: dict, dtype: torch.dtype):
+    """QwenImageEditTrainer.sampling_from_embeddings (qwen_image_edit_trainer.py:1116-1289) with the initial latents injected;
+    scheduler = restated FlowMatchEulerDiscreteScheduler (dynamic exponential shift; base_trainer.py:1009-1043)."""
+    import math
+    steps, cfg = int(emb["num_inference_steps"]), float(emb.get("true_cfg_scale", 1.0))
+    do_cfg = cfg > 1 and emb.get("negative_prompt_embeds") is not None
+    ctrl, pe, mask = emb["control_latents"].to(dtype), emb["prompt_embeds"].to(dtype), emb["prompt_embeds_mask"]
+    latents = emb["latents"].to(dtype)
+    n = latents.shape[1]
+    sig = torch.linspace(1.0, 1.0 / steps, steps, dtype=torch.float64)
+    m = (1.15 - 0.5) / (4096 - 256)
+    mu = n * m + (0.5 - m * 256)
+    sig = (math.exp(mu) / (math.exp(mu) + (1.0 / sig - 1.0))).to(torch.float32)
+    ts = sig * 1000
+    sig = torch.cat([sig, torch.zeros(1)])
+    with torch.no_grad():
+        for i, t in enumerate(ts):
+            x = torch.cat([latents, ctrl], dim=1)
+            tt = t.expand(latents.shape[0]).to(dtype) / 1000
+            pred = dit(hidden_states=x, timestep=tt, guidance=None, encoder_hidden_states_mask=mask, encoder_hidden_states=pe,
+                       img_shapes=emb["img_shapes"], txt_seq_lens=mask.sum(dim=1).tolist(), return_dict=False)[0][:, :n]
+            if do_cfg:
+                nm = emb["negative_prompt_embeds_mask"]
+                neg = dit(hidden_states=x, timestep=tt, guidance=None, encoder_hidden_states_mask=nm,
+                          encoder_hidden_states=emb["negative_prompt_embeds"].to(dtype), img_shapes=emb["img_shapes"],
+                          txt_seq_lens=nm.sum(dim=1).tolist(), return_dict=False)[0][:, :n]
+                comb = neg + cfg * (pred - neg)
+                pred = comb * (torch.norm(pred, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
+            latents = (latents.to(torch.float32) + (float(sig[i + 1]) - float(sig[i])) * pred.to(torch.float32)).to(pred.dtype)
+    return latents

@@ -12,6 +12,7 @@ Numerics follow the reference's bf16 eager graph at every rounding point (see cs
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 
@@ -413,6 +414,12 @@ class QwenImageTransformer2DModel(nn.Module):
             L.check(rc, "qfx_lora_pack")
 
     # ------------------------------------------------------------------ forward
+    @contextlib.contextmanager
+    def cache_context(self, name: str):
+        """diffusers CacheMixin.cache_context("cond"|"uncond") (qwen_image_edit_trainer.py:1237,1255): no feature caches exist
+        here, the context is accepted for call-site compatibility."""
+        yield
+
     def forward(self, hidden_states, encoder_hidden_states=None, encoder_hidden_states_mask=None, timestep=None,
                 img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None, return_dict=True):
         if encoder_hidden_states is None:

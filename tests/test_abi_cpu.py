@@ -46,3 +46,18 @@ def test_map_mask_to_latent_host_helper_matches_reference_vectors():
     from qflux_amd.trainer import map_mask_to_latent
     t = load_file(os.path.join(os.path.dirname(__file__), "golden", "losses.safetensors"))
     assert torch.equal(map_mask_to_latent(t["pixel_mask"]), t["latent_mask"])
+
+
+def test_sampling_schedule_host_logic():
+    """FlowMatchEulerSchedule (host side of the sampling loop): shifted sigmas are decreasing in (0,1], end with 0, the Euler step
+    reproduces x + (s_next - s) v, calculate_shift interpolates linearly (custom_flowmatch_scheduler.py:20-30)."""
+    import torch
+    from qflux_amd.sampling import FlowMatchEulerSchedule, calculate_shift
+    assert abs(calculate_shift(256) - 0.5) < 1e-12 and abs(calculate_shift(4096) - 1.15) < 1e-12
+    sch = FlowMatchEulerSchedule()
+    ts = sch.set_timesteps(8, 1024)
+    assert ts.shape == (8,) and sch.sigmas.shape == (9,) and sch.sigmas[-1] == 0
+    assert torch.all(sch.sigmas[:-1] > 0) and torch.all(sch.sigmas[:-1] <= 1) and torch.all(sch.sigmas[1:] < sch.sigmas[:-1])
+    assert abs(float(sch.sigmas[0]) - 1.0) < 1e-6     # t=1 is a fixed point of the time shift
+    x, v = torch.randn(2, 3, 4), torch.randn(2, 3, 4)
+    assert torch.allclose(sch.step(v, 0.7, 0.4, x), x + (0.4 - 0.7) * v, atol=1e-6)
