@@ -154,3 +154,39 @@ def test_sampling_loop_matches_oracle():
     assert out.shape == ref.shape and rel < 3e-2
     # the sampler leaves no gradient behind and the training step still works afterwards
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for n, p in hip.named_parameters() if "lora" in n)
+
+
+def test_cache_loader_feeds_the_fused_step(tmp_path):
+    """Disk cache (reference layout) -> pinned staging -> side-stream upload -> fused train_step; losses equal the same step fed
+    from host tensors."""
+    from common import TINY
+    from parity_util import build_pair
+    from qflux_amd.data import CachedEmbeddingDataset, PrefetchLoader, convert_img_shapes_to_latent_space, write_cache_sample
+    from qflux_amd.trainer import QwenLoraTrainStep
+    g = torch.Generator().manual_seed(3)
+    for i in range(4):
+        write_cache_sample(tmp_path, f"{i:032x}", dict(image_latents=torch.randn(24, 64, generator=g), control_latents=torch.randn(24, 64, generator=g),
+                                                      prompt_embeds=torch.randn(5, 512, generator=g) * 4, prompt_embeds_mask=torch.ones(5)),
+                           img_shapes=[(3, 64, 96), (3, 64, 96)])
+    ds = CachedEmbeddingDataset(str(tmp_path))
+    _, hip = build_pair(dict(TINY), device=DEV)
+    step = QwenLoraTrainStep(hip, lr=1e-3)
+    noise = torch.randn(2, 24, 64, generator=g)
+    u = torch.tensor([0.3, 0.8])
+    losses = []
+    for b in PrefetchLoader(ds, batch_size=2, device=DEV, shuffle=False):
+        assert b["image_latents"].is_cuda and b["image_latents"].dtype == torch.float16
+        emb = dict(image_latents=b["image_latents"], control_latents=b["control_latents"], prompt_embeds=b["prompt_embeds"],
+                   prompt_embeds_mask=b["prompt_embeds_mask"].long(), img_shapes=convert_img_shapes_to_latent_space(b["img_shapes"]))
+        losses.append(step.train_step(emb, noise=noise, u=u).item())
+    _, hip2 = build_pair(dict(TINY), device=DEV)
+    step2 = QwenLoraTrainStep(hip2, lr=1e-3)
+    want = []
+    for i0 in (0, 2):
+        items = [ds[i0], ds[i0 + 1]]
+        emb = dict(image_latents=torch.stack([it["image_latents"] for it in items]), control_latents=torch.stack([it["control_latents"] for it in items]),
+                   prompt_embeds=torch.stack([it["prompt_embeds"] for it in items]), prompt_embeds_mask=torch.ones(2, 5, dtype=torch.int64),
+                   img_shapes=[[(1, 4, 6), (1, 4, 6)]] * 2)
+        want.append(step2.train_step(emb, noise=noise, u=u).item())
+    print("losses via loader", losses, "direct", want)
+    assert len(losses) == 2 and all(abs(a - b) < 1e-6 * max(1.0, abs(b)) for a, b in zip(losses, want))
