@@ -145,7 +145,7 @@ def main():
     rank, local, world = init_distributed_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234)          # identical frozen trunk on every rank (data-parallel replicas)
 
     with torch.device(dev):
         dit = QwenImageTransformer2DModel(num_layers=args.layers)
@@ -168,6 +168,7 @@ def main():
     S_t = side * side
     T = 384
     Jd = dit.config.joint_attention_dim
+    torch.manual_seed(1234 + rank)   # rank-local synthetic micro-batch (main.py:58 seed + rank)
     emb = dict(image_latents=torch.randn(B, S_t, 64).half().to(dev), control_latents=torch.randn(B, S_t, 64).half().to(dev),
                prompt_embeds=(torch.randn(B, T, Jd) * 4).half().to(dev), prompt_embeds_mask=None,
                img_shapes=[[(1, side, side), (1, side, side)]] * B)

@@ -148,6 +148,21 @@ int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* s
                         uint16_t* dx, uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch,
                         float eps, const float* row_mask, void* stream);
 /* row_mask (optional, [rows]): rows with mask 0 get dx = dyg = 0 (backward of the padded-token zeroing). */
+
+/* Batched forms: n <= QFX_MAX_LN_BATCH problems in ONE launch (the image and the text stream of a block: the 384-row text
+ * problem otherwise pays a dispatch gap and a memory round trip of its own).  Every problem but the last needs rows % 4 == 0. */
+#define QFX_MAX_LN_BATCH 4
+typedef struct qfx_ln_fwd_args {
+  const uint16_t* x; const uint16_t* shift; const uint16_t* scale; int64_t mod_bstride; uint16_t* y;
+  int32_t rows; int32_t D; int32_t rows_per_batch; float eps;
+} qfx_ln_fwd_args;
+typedef struct qfx_ln_bwd_args {
+  const uint16_t* dy; const uint16_t* x; const uint16_t* scale; int64_t mod_bstride;
+  const uint16_t* dres; const uint16_t* gate; int64_t gate_bstride; uint16_t* dx; uint16_t* dyg;
+  const float* row_mask; int32_t rows; int32_t D; int32_t rows_per_batch; float eps;
+} qfx_ln_bwd_args;
+int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n, void* stream);
+int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n, void* stream);
 /* dyg = bf16(gate[b] * dx) only (used where no LayerNorm precedes). */
 int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg,
                  int32_t rows, int32_t D, int32_t rows_per_batch, void* stream);

@@ -26,11 +26,24 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
 }
 
 // ---------------------------------------------------------------- LayerNorm + modulate, forward
-__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ shift,
-                                                         const bf16_t* __restrict__ scale, int64_t mod_bstride,
-                                                         bf16_t* __restrict__ y, int rows, int D, int rpb, float eps) {
+// Batched: up to QFX_MAX_LN_BATCH problems (e.g. the image and the text stream of a block) share one launch; a wave owns
+// one row of one problem.  The tiny text-stream problems otherwise pay a full dispatch gap + memory round trip each.
+struct LnFwdBatch { qfx_ln_fwd_args a[QFX_MAX_LN_BATCH]; int n; };
+struct LnBwdBatch { qfx_ln_bwd_args a[QFX_MAX_LN_BATCH]; int n; };
+
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < QFX_MAX_LN_BATCH; ++i)
+    if (pi == i && i + 1 < bt.n && row >= bt.a[i].rows) { row -= bt.a[i].rows; pi = i + 1; }
+  const bf16_t* __restrict__ x; const bf16_t* __restrict__ shift; const bf16_t* __restrict__ scale; bf16_t* __restrict__ y;
+  int64_t mod_bstride; int rows, D, rpb; float eps;
+  {
+    const qfx_ln_fwd_args& q = pi == 0 ? bt.a[0] : (pi == 1 ? bt.a[1] : (pi == 2 ? bt.a[2] : bt.a[3]));
+    x = q.x; shift = q.shift; scale = q.scale; y = q.y; mod_bstride = q.mod_bstride; rows = q.rows; D = q.D; rpb = q.rows_per_batch; eps = q.eps;
+  }
   if (row >= rows) return;
   const int b = row / rpb;
   const bf16_t* xr = x + (int64_t)row * D;
@@ -75,14 +88,21 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------- LayerNorm + modulate, backward
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
-                                                         const bf16_t* __restrict__ scale, int64_t mod_bstride,
-                                                         const bf16_t* __restrict__ dres, const bf16_t* __restrict__ gate,
-                                                         int64_t gate_bstride, bf16_t* __restrict__ dx,
-                                                         bf16_t* __restrict__ dyg, int rows, int D, int rpb, float eps,
-                                                         const float* __restrict__ row_mask) {
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int pi = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < QFX_MAX_LN_BATCH; ++i)
+    if (pi == i && i + 1 < bt.n && row >= bt.a[i].rows) { row -= bt.a[i].rows; pi = i + 1; }
+  const bf16_t* __restrict__ dy; const bf16_t* __restrict__ x; const bf16_t* __restrict__ scale; const bf16_t* __restrict__ dres;
+  const bf16_t* __restrict__ gate; bf16_t* __restrict__ dx; bf16_t* __restrict__ dyg; const float* __restrict__ row_mask;
+  int64_t mod_bstride, gate_bstride; int rows, D, rpb; float eps;
+  {
+    const qfx_ln_bwd_args& q = pi == 0 ? bt.a[0] : (pi == 1 ? bt.a[1] : (pi == 2 ? bt.a[2] : bt.a[3]));
+    dy = q.dy; x = q.x; scale = q.scale; dres = q.dres; gate = q.gate; dx = q.dx; dyg = q.dyg; row_mask = q.row_mask;
+    mod_bstride = q.mod_bstride; gate_bstride = q.gate_bstride; rows = q.rows; D = q.D; rpb = q.rows_per_batch; eps = q.eps;
+  }
   if (row >= rows) return;
   const int b = row / rpb;
   const int64_t ro = (int64_t)row * D;
@@ -548,12 +568,51 @@ extern "C" int qfx_flowmatch_prepare(const uint16_t* x0, const uint16_t* noise, 
   return QFX_OK;
 }
 
+extern "C" int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > QFX_MAX_LN_BATCH) return QFX_EINVAL;
+  LnFwdBatch bt;
+  int rows = 0;
+  for (int i = 0; i < n; ++i) {
+    const qfx_ln_fwd_args& a = list[i];
+    if (!a.x || !a.shift || !a.scale || !a.y || a.rows <= 0 || a.D <= 0 || (a.D % 8) || a.D > MAXP * 512 || a.rows_per_batch <= 0 ||
+        (a.mod_bstride % 8))
+      return QFX_EINVAL;
+    bt.a[i] = a;
+    rows += (a.rows + 3) / 4 * 4;     // problems start on a block boundary (4 rows per block)
+    if (i + 1 < n && (a.rows % 4)) return QFX_EINVAL;   /* only the last problem may have a ragged row count */
+  }
+  for (int i = n; i < QFX_MAX_LN_BATCH; ++i) bt.a[i] = list[0];
+  bt.n = n;
+  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
 extern "C" int qfx_ln_modulate_fwd(const uint16_t* x, const uint16_t* shift, const uint16_t* scale, int64_t mod_bstride,
                                    uint16_t* y, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, void* stream) {
-  if (!x || !shift || !scale || !y || rows <= 0 || D <= 0 || (D % 8) || D > MAXP * 512 || rows_per_batch <= 0 || (mod_bstride % 8))
-    return QFX_EINVAL;
-  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, shift, scale,
-                     mod_bstride, y, rows, D, rows_per_batch, eps);
+  qfx_ln_fwd_args a;
+  a.x = x; a.shift = shift; a.scale = scale; a.mod_bstride = mod_bstride; a.y = y; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch;
+  a.eps = eps;
+  return qfx_ln_modulate_fwd_batch(&a, 1, stream);
+}
+
+extern "C" int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > QFX_MAX_LN_BATCH) return QFX_EINVAL;
+  LnBwdBatch bt;
+  int rows = 0;
+  for (int i = 0; i < n; ++i) {
+    const qfx_ln_bwd_args& a = list[i];
+    if (!a.dy || !a.x || !a.scale || !a.dx || a.rows <= 0 || a.D <= 0 || (a.D % 8) || a.D > MAXP * 512 || a.rows_per_batch <= 0 ||
+        (a.mod_bstride % 8))
+      return QFX_EINVAL;
+    if (a.dyg && (!a.gate || (a.gate_bstride % 8))) return QFX_EINVAL;
+    bt.a[i] = a;
+    rows += (a.rows + 3) / 4 * 4;
+    if (i + 1 < n && (a.rows % 4)) return QFX_EINVAL;
+  }
+  for (int i = n; i < QFX_MAX_LN_BATCH; ++i) bt.a[i] = list[0];
+  bt.n = n;
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
@@ -562,13 +621,10 @@ extern "C" int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const 
                                    const uint16_t* dres, const uint16_t* gate, int64_t gate_bstride, uint16_t* dx,
                                    uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, const float* row_mask,
                                    void* stream) {
-  if (!dy || !x || !scale || !dx || rows <= 0 || D <= 0 || (D % 8) || D > MAXP * 512 || rows_per_batch <= 0 || (mod_bstride % 8))
-    return QFX_EINVAL;
-  if (dyg && (!gate || (gate_bstride % 8))) return QFX_EINVAL;
-  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, scale,
-                     mod_bstride, dres, gate, gate_bstride, dx, dyg, rows, D, rows_per_batch, eps, row_mask);
-  QFX_CHECK_LAUNCH();
-  return QFX_OK;
+  qfx_ln_bwd_args a;
+  a.dy = dy; a.x = x; a.scale = scale; a.mod_bstride = mod_bstride; a.dres = dres; a.gate = gate; a.gate_bstride = gate_bstride;
+  a.dx = dx; a.dyg = dyg; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch; a.eps = eps; a.row_mask = row_mask;
+  return qfx_ln_modulate_bwd_batch(&a, 1, stream);
 }
 
 extern "C" int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg, int32_t rows,

@@ -51,6 +51,17 @@ class LoraGradArgs(C.Structure):
     ]
 
 
+class LnFwdArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("shift", C.c_void_p), ("scale", C.c_void_p), ("mod_bstride", C.c_int64), ("y", C.c_void_p),
+                ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("scale", C.c_void_p), ("mod_bstride", C.c_int64),
+                ("dres", C.c_void_p), ("gate", C.c_void_p), ("gate_bstride", C.c_int64), ("dx", C.c_void_p), ("dyg", C.c_void_p),
+                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
+
+
 class LoraPackArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("r", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("scale", C.c_float),
@@ -76,6 +87,7 @@ class AttnArgs(C.Structure):
 
 
 MAX_BATCH = 8          # QFX_MAX_BATCH
+MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/qfx.h declares
@@ -90,6 +102,8 @@ SYMBOLS = {
     "qfx_lora_pack": (C.c_int, [_vp, _i32, _i32, _vp]),
     "qfx_ln_modulate_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f, _vp]),
     "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
+    "qfx_ln_modulate_fwd_batch": (C.c_int, [C.POINTER(LnFwdArgs), C.c_int32, _vp]),
+    "qfx_ln_modulate_bwd_batch": (C.c_int, [C.POINTER(LnBwdArgs), C.c_int32, _vp]),
     "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "qfx_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -606,6 +606,37 @@ class _QwenPlan:
         prog.c(lib.qfx_lora_down, C.byref(a))
 
     @staticmethod
+    def _ln_fwd_args(x, shift, scale, mod_bs, y, rows, D, rpb, eps):
+        a = L.LnFwdArgs()
+        a.x, a.shift, a.scale, a.mod_bstride, a.y = _ptr(x), _ptr(shift), _ptr(scale), mod_bs, _ptr(y)
+        a.rows, a.D, a.rows_per_batch, a.eps = rows, D, rpb, eps
+        return a
+
+    @staticmethod
+    def _ln_bwd_args(dy, x, scale, mod_bs, dres, gate, gate_bs, dx, dyg, rows, D, rpb, eps, row_mask):
+        a = L.LnBwdArgs()
+        a.dy, a.x, a.scale, a.mod_bstride = _ptr(dy), _ptr(x), _ptr(scale), mod_bs
+        a.dres, a.gate, a.gate_bstride, a.dx, a.dyg = _ptr(dres), _ptr(gate), gate_bs, _ptr(dx), _ptr(dyg)
+        a.row_mask, a.rows, a.D, a.rows_per_batch, a.eps = _ptr(row_mask), rows, D, rpb, eps
+        return a
+
+    @staticmethod
+    def _flush_ln(prog, pending, struct, fn):
+        """One launch for the LayerNorm problems of both streams (ragged row counts go last: only the last problem of a batch
+        may have rows % 4 != 0)."""
+        pend = sorted(pending, key=lambda a: (a.rows % 4 != 0))
+        while pend:
+            chunk = []
+            while pend and len(chunk) < L.MAX_LN_BATCH:
+                chunk.append(pend.pop(0))
+                if chunk[-1].rows % 4:
+                    break
+            arr = (struct * len(chunk))(*chunk)
+            prog.keep.append(arr)
+            prog.c(fn, arr, len(chunk))
+        pending.clear()
+
+    @staticmethod
     def _flush_batch(prog, pending, struct, fn):
         """Emit deferred skinny-kernel problems as batched launches: same R per launch, at most QFX_MAX_BATCH each."""
         by_r = {}
@@ -687,12 +718,17 @@ class _QwenPlan:
             ao2 = bb["ao"].view(B * S, D)
             # ---- LN1 + modulate, LoRA down-projections, then ONE grouped launch for the 6 q/k/v projections
             groups = []
+            lnl = []
+            for s, sidx in STREAMS:
+                mod = mods[s]
+                xm1 = bb["xm1." + s] if w[s + ".qkv_lora"] is not None else A["xm"][s]
+                lnl.append(self._ln_fwd_args(x_in[s], mod[:, 0:D], mod[:, D:2 * D], 6 * D, xm1, rows[s], D, rpb[s], eps))
+            self._flush_ln(p, lnl, L.LnFwdArgs, lib.qfx_ln_modulate_fwd_batch)
             for s, sidx in STREAMS:
                 mod = mods[s]
                 x = x_in[s]
                 grp = w[s + ".qkv_lora"]
                 xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
-                p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 6 * D, _ptr(xm1), rows[s], D, rpb[s], eps)
                 if grp is not None:
                     self._down(p, X=xm1, ldx=D, M=rows[s], K=D, W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
                                Ut=bb["Uqkv." + s], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
@@ -739,10 +775,11 @@ class _QwenPlan:
                                           rpb=rpb[s], a_map=(S, off[s]), **kw))
             self._gemm_group(p, groups)
             groups = []
+            lnl = [self._ln_fwd_args(bb["x1"][s], mods[s][:, 3 * D:4 * D], mods[s][:, 4 * D:5 * D], 6 * D, A["xm"][s], rows[s], D, rpb[s], eps)
+                   for s, sidx in live]
+            self._flush_ln(p, lnl, L.LnFwdArgs, lib.qfx_ln_modulate_fwd_batch)
             for s, sidx in live:
                 mod = mods[s]
-                p.c(lib.qfx_ln_modulate_fwd, _ptr(bb["x1"][s]), _ptr(mod[:, 3 * D:4 * D]), _ptr(mod[:, 4 * D:5 * D]), 6 * D,
-                    _ptr(A["xm"][s]), rows[s], D, rpb[s], eps)
                 f1 = w[s + ".fc1"]
                 groups.append(self._gargs(A1=A["xm"][s], lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D,
                                           bias=f1.b, epi=L.EPI_GELU, C2=A["g"][s], ldc2=4 * D))
@@ -808,10 +845,11 @@ class _QwenPlan:
             self._gemm_group(p, [self._gargs(A1=A["dh"][s], lda1=4 * D, B1=w[s + ".fc1"].WT, K1=4 * D, M=rows[s], N=D,
                                              C_=A["dxm"][s], ldc=D) for s, _ in live])
             groups = []
+            lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
+                                     A["dx1"][s], A["dyg1"][s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
+            self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
             for s, sidx in live:
                 mod = mods[s]
-                p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(bb["x1"][s]), _ptr(mod[:, 4 * D:5 * D]), 6 * D,
-                    _ptr(dx2[s]), _ptr(mod[:, 2 * D:3 * D]), 6 * D, _ptr(A["dx1"][s]), _ptr(A["dyg1"][s]), rows[s], D, rpb[s], eps, None)
                 # attention out-projection backward (+ LoRA)
                 lw = w[s + ".o"]
                 kw = {}
@@ -876,12 +914,14 @@ class _QwenPlan:
             self._flush_batch(p, dl, L.LoraDownArgs, lib.qfx_lora_down_batch)
             if i > 0:
                 self._gemm_group(p, groups)
+                lnl = []
                 for s, sidx in STREAMS:
                     dres = None if (last and s == "txt") else A["dx1"][s]
                     gp = gate_prev[s] if gate_prev is not None else None
-                    p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm"][s]), _ptr(x_in[s]), _ptr(mods[s][:, D:2 * D]), 6 * D, _ptr(dres),
-                        _ptr(gp), (gp.stride(0) if gp is not None else 0), _ptr(out_dx[s]), _ptr(A["dyg2"][s] if gp is not None else None),
-                        rows[s], D, rpb[s], eps, _ptr(self.rmask[s]))
+                    lnl.append(self._ln_bwd_args(A["dxm"][s], x_in[s], mods[s][:, D:2 * D], 6 * D, dres, gp,
+                                                 (gp.stride(0) if gp is not None else 0), out_dx[s],
+                                                 A["dyg2"][s] if gp is not None else None, rows[s], D, rpb[s], eps, self.rmask[s]))
+                self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
         self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
 
     # ------------------------------------------------------------------ execution
