@@ -175,10 +175,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
     const int j0 = jt * 64;
     f32x4 sacc[4][2];
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      sacc[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sacc[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kf = 0; kf < 4; ++kf) { sacc[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sacc[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // k-chunk outer, key fragment inner: 8 independent accumulators between two MFMAs of the same chain
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk) {
+    for (int kk = 0; kk < KC; ++kk) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) {
         const bf16x8 kfr = *(const bf16x8*)(sK + koff[kk] + kf * (16 * DH * 2));
         sacc[kf][0] = MFMA(kfr, qf[0][kk], sacc[kf][0]);
         sacc[kf][1] = MFMA(kfr, qf[1][kk], sacc[kf][1]);
@@ -247,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
         for (int r = 0; r < 4; ++r) { oacc[d][0][r] *= alpha[0]; oacc[d][1][r] *= alpha[1]; }
     }
 #pragma unroll
-    for (int d = 0; d < DF; ++d)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int d = 0; d < DF; ++d) {
         const int o = (toff0 ^ (d << 5)) + t * (32 * DH * 2);
         const bf16x4 lo = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(sV + o)));
         const bf16x4 hi = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(sV + o + 16 * DH * 2)));
