@@ -112,8 +112,10 @@ class QwenLoraTrainStep:
         return (m * self.fg + (1.0 - m) * self.bg).to(dev).contiguous()
 
     # ------------------------------------------------------------------ fused path
-    def forward_backward(self, embeddings, noise=None, u=None, grad_scale=1.0):
-        """loss (device fp32 scalar); LoRA grads accumulated into the flat gradient buffer."""
+    def forward_backward(self, embeddings, noise=None, u=None, grad_scale=1.0, sync=True):
+        """loss (device fp32 scalar); LoRA grads ACCUMULATE into the flat gradient buffer.
+        sync=False = accelerator.accumulate()/no_sync micro-step (base_trainer.py:518): no gradient exchange is started; pass
+        sync=True on the last micro-step of the window (the buckets then carry the accumulated sums)."""
         packed, target, pe, t_in, S_t = self._prepare(embeddings, noise, u)
         dit = self.dit
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
@@ -125,7 +127,7 @@ class QwenLoraTrainStep:
             loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
         else:
             loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
-        plan.run_backward(dpred, on_segment=self._bucket_hook() if self.world > 1 else None)
+        plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
         return loss
 
     # ------------------------------------------------------------------ bucketed all-reduce behind the backward
@@ -189,13 +191,68 @@ class QwenLoraTrainStep:
     def zero_grad(self):
         self.dit.lora_store.gflat.zero_()
 
-    def train_step(self, embeddings, noise=None, u=None):
-        """One full optimisation step; returns the (device) loss."""
-        loss = self.forward_backward(embeddings, noise, u)
-        scale = self.allreduce_grads()
+    # ------------------------------------------------------------------ optimizer / resume state (base_trainer.py:827-875,944-1002)
+    def state_dict(self):
+        """torch.optim.AdamW-style state: {"state": {i: {"step","exp_avg","exp_avg_sq"}}, "param_groups": [...]} with one entry
+        per LoRA parameter in named_parameters() order (what accelerate's optimizer.bin holds for the reference)."""
+        st = self.dit.lora_store
+        state = {}
+        for i, (_, p, off, k) in enumerate(st.entries):
+            if self._m is None:
+                break
+            state[i] = {"step": torch.tensor(float(self.global_step)), "exp_avg": self._m[off:off + k].view(p.shape).detach().cpu().clone(),
+                        "exp_avg_sq": self._v[off:off + k].view(p.shape).detach().cpu().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "params": list(range(len(st.entries)))}
+        return {"state": state, "param_groups": [group], "global_step": self.global_step}
+
+    def load_state_dict(self, sd):
+        st = self.dit.lora_store
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self._m = torch.zeros_like(st.pflat); self._v = torch.zeros_like(st.pflat)
+        self._gnorm = torch.zeros((), dtype=torch.float32, device=st.pflat.device)
+        step = sd.get("global_step", 0)
+        for i, (_, p, off, k) in enumerate(st.entries):
+            e = sd["state"].get(i)
+            if e is None:
+                continue
+            self._m[off:off + k].copy_(e["exp_avg"].reshape(-1).to(self._m.device))
+            self._v[off:off + k].copy_(e["exp_avg_sq"].reshape(-1).to(self._v.device))
+            step = max(step, int(float(e["step"])))
+        self.global_step = int(step)
+
+    def save_checkpoint(self, save_dir, extra_state=None):
+        """checkpoint-<e>-<step> folder of the reference (base_trainer.py:827-875): pytorch_lora_weights.safetensors (diffusers
+        key style) + optimizer.bin + state.json."""
+        import json
+        os.makedirs(save_dir, exist_ok=True)
+        self.dit.save_lora_weights(save_dir)
+        torch.save(self.state_dict(), os.path.join(save_dir, "optimizer.bin"))
+        with open(os.path.join(save_dir, "state.json"), "w") as f:
+            json.dump(dict({"global_step": self.global_step, "lr": self.lr}, **(extra_state or {})), f, indent=2)
+
+    def load_checkpoint(self, save_dir, adapter_name=None):
+        """adapter_name: inject/overwrite that adapter from the saved weights first (None = the adapter is already in place)."""
+        import json
+        if adapter_name is not None:
+            self.dit.load_lora_adapter(save_dir, adapter_name=adapter_name)
+        self.load_state_dict(torch.load(os.path.join(save_dir, "optimizer.bin"), map_location="cpu", weights_only=False))
+        with open(os.path.join(save_dir, "state.json")) as f:
+            return json.load(f)
+
+    def train_step(self, embeddings, noise=None, u=None, micro_batches=None):
+        """One full optimisation step; returns the (device) loss.  micro_batches: optional list of further embedding dicts
+        accumulated before the step (gradient_accumulation_steps = 1 + len(micro_batches); mean over micro-steps)."""
+        extra = list(micro_batches or [])
+        k = 1 + len(extra)
+        loss = self.forward_backward(embeddings, noise, u, sync=not extra)
+        for j, mb in enumerate(extra):
+            loss = loss + self.forward_backward(mb, sync=(j == len(extra) - 1))
+        scale = self.allreduce_grads() / k
         self.optimizer_step(grad_scale=scale)
         self.zero_grad()
-        return loss
+        return loss / k if k > 1 else loss
 
     def gather_loss(self, loss):
         """accelerator.gather(loss).mean() (base_trainer.py:539)."""
@@ -204,6 +261,32 @@ class QwenLoraTrainStep:
             dist.all_gather(out, loss, group=self.group)
             return torch.stack(out).mean()
         return loss
+
+
+def get_scheduler(name: str, num_warmup_steps: int = 0, num_training_steps: int | None = None, num_cycles: float = 0.5):
+    """lr multiplier(step) of diffusers.optimization.get_scheduler for the schedules the reference's configs use
+    (base_trainer.py:900-916): constant, constant_with_warmup, linear, cosine.  Use: step.lr = base_lr * f(global_step)."""
+    import math
+
+    def warm(s):
+        return float(s) / float(max(1, num_warmup_steps)) if s < num_warmup_steps else None
+
+    if name == "constant":
+        return lambda s: 1.0
+    if name == "constant_with_warmup":
+        return lambda s: (warm(s) if warm(s) is not None else 1.0)
+    if name == "linear":
+        return lambda s: (warm(s) if warm(s) is not None else
+                          max(0.0, float(num_training_steps - s) / float(max(1, num_training_steps - num_warmup_steps))))
+    if name == "cosine":
+        def f(s):
+            w = warm(s)
+            if w is not None:
+                return w
+            prog = float(s - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * prog)))
+        return f
+    raise ValueError(f"unsupported lr scheduler {name!r}")
 
 
 def _contiguous_runs(idx, ents):

@@ -61,3 +61,15 @@ def test_sampling_schedule_host_logic():
     assert abs(float(sch.sigmas[0]) - 1.0) < 1e-6     # t=1 is a fixed point of the time shift
     x, v = torch.randn(2, 3, 4), torch.randn(2, 3, 4)
     assert torch.allclose(sch.step(v, 0.7, 0.4, x), x + (0.4 - 0.7) * v, atol=1e-6)
+
+
+def test_lr_schedules_host_logic():
+    """get_scheduler multipliers (diffusers.optimization semantics used at base_trainer.py:900-916)."""
+    from qflux_amd.trainer import get_scheduler
+    c = get_scheduler("constant_with_warmup", num_warmup_steps=4)
+    assert [c(s) for s in (0, 2, 4, 100)] == [0.0, 0.5, 1.0, 1.0]
+    lin = get_scheduler("linear", 2, 10)
+    assert abs(lin(1) - 0.5) < 1e-12 and abs(lin(6) - 0.5) < 1e-12 and lin(10) == 0.0
+    cos = get_scheduler("cosine", 0, 10)
+    assert abs(cos(0) - 1.0) < 1e-12 and abs(cos(5) - 0.5) < 1e-12 and abs(cos(10)) < 1e-12
+    assert get_scheduler("constant")(7) == 1.0
