@@ -176,13 +176,25 @@ def joint_attention(attn: OracleAttention, img: torch.Tensor, txt: torch.Tensor,
     tq, tk, tv = (t.unflatten(-1, (H, -1)) for t in (tq, tk, tv))
     iq, ik = attn.norm_q(iq), attn.norm_k(ik)
     tq, tk = attn.norm_added_q(tq), attn.norm_added_k(tk)
-    if rope is not None:
+    if rope is not None and not isinstance(rope, list):
         img_f, txt_f = rope
         iq, ik = apply_rope_complex(iq, img_f), apply_rope_complex(ik, img_f)
         tq, tk = apply_rope_complex(tq, txt_f), apply_rope_complex(tk, txt_f)
     q = torch.cat([tq, iq], dim=1)  # order [text, image]  (:324-326)
     k = torch.cat([tk, ik], dim=1)
     v = torch.cat([tv, iv], dim=1)
+    if isinstance(rope, list):
+        # QwenDoubleStreamAttnProcessorPerSample._apply_rope_per_sample (transformer_qwen_custom.py:175-228): per sample the
+        # text table covers joint rows [0, txt_len_b) and the image table the rows RIGHT AFTER them, [txt_len_b, txt_len_b +
+        # seq_img_b) -- measured from the sample's own text length, not from the padded one; all other rows stay unrotated.
+        qo, ko = q.clone(), k.clone()
+        for b, (img_f, txt_f) in enumerate(rope):
+            st, si = txt_f.shape[0], img_f.shape[0]
+            qo[b:b + 1, :st] = apply_rope_complex(q[b:b + 1, :st], txt_f)
+            ko[b:b + 1, :st] = apply_rope_complex(k[b:b + 1, :st], txt_f)
+            qo[b:b + 1, st:st + si] = apply_rope_complex(q[b:b + 1, st:st + si], img_f)
+            ko[b:b + 1, st:st + si] = apply_rope_complex(k[b:b + 1, st:st + si], img_f)
+        q, k = qo, ko
     am = None
     if key_mask is not None:
         am = key_mask[:, None, None, :].to(q.dtype)
@@ -331,7 +343,10 @@ class OracleQwenDiT(nn.Module):
 
     def forward(self, hidden_states, encoder_hidden_states=None, encoder_hidden_states_mask=None,
                 timestep=None, img_shapes=None, txt_seq_lens=None, guidance=None,
-                attention_kwargs=None, return_dict=False, key_mask=None):
+                attention_kwargs=None, return_dict=False, key_mask=None, attention_mask=None):
+        batched = isinstance(img_shapes, list) and len(img_shapes) > 0 and isinstance(img_shapes[0], list)
+        if attention_mask is not None or (batched and not all(sh == img_shapes[0] for sh in img_shapes)):
+            return self.forward_custom(hidden_states, encoder_hidden_states, timestep, img_shapes, txt_seq_lens, attention_mask)
         hidden_states = self.img_in(hidden_states)
         timestep = timestep.to(hidden_states.dtype)  # (:623-624) sigma rounded to the model dtype
         encoder_hidden_states = self.txt_in(self.txt_norm(encoder_hidden_states))
@@ -344,6 +359,47 @@ class OracleQwenDiT(nn.Module):
             encoder_hidden_states, hidden_states = block(hidden_states, encoder_hidden_states, temb, rope, key_mask)
         hidden_states = self.norm_out(hidden_states, temb)
         return (self.proj_out(hidden_states),)
+
+
+def _forward_custom(self, hidden_states, encoder_hidden_states, timestep, img_shapes, txt_seq_lens, attention_mask):
+    """QwenImageTransformer2DModel.forward of transformer_qwen_custom.py:384-573 (non-checkpointed path): per-sample RoPE when
+    the samples' shape lists differ, boolean [B, T+S_max] padding mask -> additive key mask, padded text rows zeroed once
+    after txt_in, padded image rows zeroed after img_in, after EVERY block and in the output."""
+    hidden_states = self.img_in(hidden_states)
+    timestep = timestep.to(hidden_states.dtype)
+    encoder_hidden_states = self.txt_in(self.txt_norm(encoder_hidden_states))
+    temb = self.time_text_embed(timestep, hidden_states)
+    batched = isinstance(img_shapes, list) and len(img_shapes) > 0 and isinstance(img_shapes[0], list)
+    if batched:
+        B = len(img_shapes)
+        lens = txt_seq_lens if isinstance(txt_seq_lens, list) else [txt_seq_lens] * B
+        if all(sh == img_shapes[0] for sh in img_shapes):
+            vid_f, txt_f = qwen_rope_tables(img_shapes[0], max(lens), self.axes_dims_rope)
+            rope = (vid_f, txt_f)
+        else:
+            rope = [qwen_rope_tables(img_shapes[b], lens[b], self.axes_dims_rope) for b in range(B)]
+    else:
+        rope = qwen_rope_tables(img_shapes, max(txt_seq_lens) if isinstance(txt_seq_lens, list) else txt_seq_lens, self.axes_dims_rope)
+    key_mask = None
+    img_mask = None
+    if attention_mask is not None:
+        mask = attention_mask if attention_mask.dtype == torch.bool else attention_mask > 0
+        T, S_i = encoder_hidden_states.shape[1], hidden_states.shape[1]
+        img_mask = mask[:, T:T + S_i]
+        encoder_hidden_states = encoder_hidden_states.masked_fill(~mask[:, :T].unsqueeze(-1), 0)
+        hidden_states = hidden_states.masked_fill(~img_mask.unsqueeze(-1), 0)
+        key_mask = torch.zeros(mask.shape, dtype=hidden_states.dtype).masked_fill(~mask, float("-inf"))
+    for block in self.transformer_blocks:
+        encoder_hidden_states, hidden_states = block(hidden_states, encoder_hidden_states, temb, rope, key_mask)
+        if img_mask is not None and not img_mask.all():
+            hidden_states = hidden_states * img_mask.unsqueeze(-1)
+    out = self.proj_out(self.norm_out(hidden_states, temb))
+    if img_mask is not None:
+        out = out.masked_fill(~img_mask.unsqueeze(-1), 0)
+    return (out,)
+
+
+OracleQwenDiT.forward_custom = _forward_custom
 
 
 # ----------------------------------------------------------------------------

@@ -421,12 +421,26 @@ class QwenImageTransformer2DModel(nn.Module):
         yield
 
     def forward(self, hidden_states, encoder_hidden_states=None, encoder_hidden_states_mask=None, timestep=None,
-                img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None, return_dict=True):
+                img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None, return_dict=True, attention_mask=None):
+        """attention_mask: optional bool [B, T+S_max] padding mask of the multi-resolution model (transformer_qwen_custom.py:384-396);
+        with it, or with per-sample img_shapes that differ, the masked / per-sample-RoPE launch program runs."""
         if encoder_hidden_states is None:
             raise ValueError("QwenImageTransformer2DModel requires encoder_hidden_states (text stream)")
         if guidance is not None:
             raise NotImplementedError("guidance embeddings are not part of the Qwen-Image-Edit training path")
-        plan = self.get_plan(hidden_states.shape[0], hidden_states.shape[1], encoder_hidden_states.shape[1], img_shapes, txt_seq_lens)
+        B, S_i, T = hidden_states.shape[0], hidden_states.shape[1], encoder_hidden_states.shape[1]
+        batched = isinstance(img_shapes, list) and len(img_shapes) > 0 and isinstance(img_shapes[0], list)
+        ragged = batched and not all(sh == img_shapes[0] for sh in img_shapes)
+        if attention_mask is not None or ragged:
+            if attention_mask is not None:
+                if attention_mask.dim() != 2:
+                    raise ValueError("attention_mask must have shape (batch, total_sequence_length).")
+                if attention_mask.shape[1] < T + S_i:
+                    raise ValueError(f"attention_mask length {attention_mask.shape[1]} is smaller than expected sequence length {T + S_i}.")
+            plan = self.get_plan_multires(B, S_i, T, img_shapes, txt_seq_lens, attention_mask)
+            out = _QwenDiTFn.apply(self, plan, hidden_states, encoder_hidden_states, timestep, *self.lora_parameters())
+            return (out,) if not return_dict else _Cfg(sample=out)
+        plan = self.get_plan(B, S_i, T, img_shapes, txt_seq_lens)
         out = _QwenDiTFn.apply(self, plan, hidden_states, encoder_hidden_states, timestep, *self.lora_parameters())
         if not return_dict:
             return (out,)
@@ -445,12 +459,24 @@ class QwenImageTransformer2DModel(nn.Module):
             self._plans[key] = _QwenPlan(self, B, S_i, T, shapes)
         return self._plans[key]
 
+    def get_plan_multires(self, B, S_i, T, img_shapes, txt_seq_lens, attention_mask):
+        """One plan per padded shape (B, S_max, T); the per-batch contents (per-sample RoPE, key mask, row masks) are refreshed
+        on every call."""
+        self._prepare()
+        self._prepare_lora()
+        key = ("multires", B, S_i, T, self._version)
+        if key not in self._plans:
+            self._plans[key] = _QwenPlan(self, B, S_i, T, None, multires=True)
+        plan = self._plans[key]
+        plan.set_multires(img_shapes, txt_seq_lens, attention_mask)
+        return plan
+
 
 # ----------------------------------------------------------------------------------------------
 class _QwenPlan:
     """Launch programs (forward, backward) + persistent arena for one shape signature."""
 
-    def __init__(self, model, B: int, S_i: int, T: int, shapes):
+    def __init__(self, model, B: int, S_i: int, T: int, shapes, multires: bool = False):
         self._setup(model, B, S_i, T)
         cfg = model.config
         D, S = self.D, self.S
@@ -459,9 +485,23 @@ class _QwenPlan:
         Lyr = cfg.num_layers
         Cin, Cout, Jd = cfg.in_channels, model.proj_out.out_features, cfg.joint_attention_dim
         P = model._prepared
-        self.rope = qwen_joint_rope(shapes, T, cfg.axes_dims_rope).to(model.device)
-        assert self.rope.shape == (S, self.dh // 2, 2)
         A = self.A
+        self.multires = multires
+        self.rm_txt0 = None
+        if multires:
+            # per-batch contents, filled by set_multires(): per-sample RoPE (identity on unrotated rows), additive key mask,
+            # row masks of the padded image tokens (every block) and of the padded text tokens (once, after txt_in)
+            A["rope_b"] = buf(B, S, self.dh // 2, 2, dtype=F32)
+            A["kmask"] = buf(B, S, dtype=F32, zero=True)
+            A["rm_img"] = buf(B * S_i, dtype=F32)
+            A["rm_txt0"] = buf(B * T, dtype=F32)
+            self.rope, self.rope_bs = A["rope_b"], S * (self.dh // 2) * 2
+            self.kmask = A["kmask"]
+            self.rmask = {"img": A["rm_img"], "txt": None, "joint": None}
+            self.rm_txt0 = A["rm_txt0"]
+        else:
+            self.rope = qwen_joint_rope(shapes, T, cfg.axes_dims_rope).to(model.device)
+            assert self.rope.shape == (S, self.dh // 2, 2)
         A["in_img"] = buf(B * S_i, Cin); A["in_txt"] = buf(B * T, Jd); A["t"] = buf(B, dtype=F32)
         A["tproj"] = buf(B, 256); A["t1"] = buf(1, B, D); A["temb"] = buf(1, B, D)
         A["txt_n"] = buf(B * T, Jd)
@@ -688,10 +728,10 @@ class _QwenPlan:
         p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
         p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["norm_out_Wp"]), _ptr(P["norm_out_bp"]), 1, 2 * D, 1, _ptr(A["mod_out"]))
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["img_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
-                   C_=A["X"]["img"][0], ldc=D, bias=P["img_in"].b)
+                   C_=A["X"]["img"][0], ldc=D, bias=P["img_in"].b, row_mask=self.rmask["img"])
         p.c(lib.qfx_rmsnorm_fwd, _ptr(A["in_txt"]), _ptr(model.txt_norm.weight.data), _ptr(A["txt_n"]), rows["txt"], Jd, eps)
         self._gemm(p, A1=A["txt_n"], lda1=Jd, B1=P["txt_in"].W, K1=Jd, M=rows["txt"], N=D, C_=A["X"]["txt"][0], ldc=D,
-                   bias=P["txt_in"].b)
+                   bias=P["txt_in"].b, row_mask=self.rm_txt0)
         self.attn_args = []
         for i in range(Lyr):
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
@@ -701,7 +741,8 @@ class _QwenPlan:
         p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
             rows["img"], D, rpb["img"], eps)
         po = P["proj_out"]
-        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b)
+        self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b,
+                   row_mask=self.rmask["img"])
 
     def _emit_double_fwd(self, p, w, bb, mods, x_in, x_out, last, norm_flags):
         """One double-stream block (reference: transformer_qwenimage.py:425-494; FLUX: transformer_flux.py:467-523).
@@ -803,7 +844,8 @@ class _QwenPlan:
         eps = 1e-6
         po = P["proj_out"]
         # tail: proj_out dX, norm_out LN backward (+ gate2 of the last block folded in)
-        self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D)
+        self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D,
+                   row_mask=self.rmask["img"])   # backward of the output masked_fill: no gradient enters through padded rows
         mo = A["mod_out"][0]
         modL = A["mods"][2 * (Lyr - 1)]
         cur = 0
@@ -923,6 +965,44 @@ class _QwenPlan:
                                                  A["dyg2"][s] if gp is not None else None, rows[s], D, rpb[s], eps, self.rmask[s]))
                 self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
         self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
+
+    def set_multires(self, img_shapes, txt_seq_lens, attention_mask):
+        """Per-batch tables of the multi-resolution path (host-side plumbing of transformer_qwen_custom.py:72-150,175-228,
+        444-512).  Per sample the joint table [text rows | image rows] starts at joint row 0, i.e. the image rows follow the
+        sample's OWN text length (the reference's placement); every other row keeps the identity rotation."""
+        cfg = self.model.config
+        B, S, T, S_i = self.B, self.S, self.T, self.S_i
+        dev = self.model.device
+        batched = isinstance(img_shapes, list) and len(img_shapes) > 0 and isinstance(img_shapes[0], list)
+        per = [normalize_img_shapes(sh) for sh in img_shapes] if batched else [normalize_img_shapes(img_shapes)] * B
+        lens = list(txt_seq_lens) if isinstance(txt_seq_lens, (list, tuple)) else [int(txt_seq_lens)] * B
+        rope = torch.zeros(B, S, self.dh // 2, 2)
+        rope[..., 0] = 1.0
+        if all(sh == per[0] for sh in per):      # shared RoPE: first sample's shapes, max text length (custom forward :462-470)
+            tbl = qwen_joint_rope(per[0], max(lens), cfg.axes_dims_rope)
+            if max(lens) != T:
+                raise ValueError("max(txt_seq_lens) must equal the text sequence length (reference RoPE broadcast)")
+            rope[:, : tbl.shape[0]] = tbl
+        else:
+            for b in range(B):
+                tbl = qwen_joint_rope(per[b], int(lens[b]), cfg.axes_dims_rope)
+                if tbl.shape[0] > S:
+                    raise ValueError(f"sample {b}: text + image tokens ({tbl.shape[0]}) exceed the padded joint length {S}")
+                rope[b, : tbl.shape[0]] = tbl
+        km = torch.zeros(B, S)
+        rm_i = torch.ones(B, S_i)
+        rm_t = torch.ones(B, T)
+        if attention_mask is not None:
+            m = attention_mask if attention_mask.dtype == torch.bool else attention_mask > 0
+            m = m[:, :S].cpu()
+            km.masked_fill_(~m, float("-inf"))
+            rm_i = m[:, T:].float()
+            rm_t = m[:, :T].float()
+        A = self.A
+        A["rope_b"].copy_(rope.to(dev, non_blocking=True))
+        A["kmask"].copy_(km.to(dev, non_blocking=True))
+        A["rm_img"].copy_(rm_i.reshape(-1).to(dev, non_blocking=True))
+        A["rm_txt0"].copy_(rm_t.reshape(-1).to(dev, non_blocking=True))
 
     # ------------------------------------------------------------------ execution
     def run_forward(self, hidden_states, encoder_hidden_states, timestep):

@@ -435,6 +435,43 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("multi-res reference check FAILED:", repr(e))
         raise
+    # ---------------- Qwen multi-resolution: reference transformer_qwen_custom.py vs oracle ----------------
+    qc = importlib.import_module("qflux.models.transformer_qwen_custom")
+    import contextlib, io
+    cmq = qc.QwenImageTransformer2DModel(**TINY).eval()
+    fill_weights(cmq, seed=1)
+    oq = O.OracleQwenDiT(**TINY)
+    oq.load_state_dict(cmq.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(43)
+    B, T = 2, 6
+    shapes_b = [[(1, 4, 6), (1, 4, 6)], [(1, 4, 6), (1, 3, 5)]]      # per-sample shape lists (target + control)
+    lens = [sum(f * h * w for f, h, w in sh) for sh in shapes_b]     # 48, 39
+    txt_lens = [6, 4]                                                # ragged text too (exercises the placement quirk)
+    S_max = max(lens)
+    x = torch.zeros(B, S_max, 64)
+    full = torch.zeros(B, T + S_max, dtype=torch.bool)
+    for b in range(B):
+        x[b, : lens[b]] = torch.randn(lens[b], 64, generator=g)
+        full[b, : txt_lens[b]] = True
+        full[b, T: T + lens[b]] = True
+    pe = torch.randn(B, T, TINY["joint_attention_dim"], generator=g)
+    tt = torch.tensor([0.7109, 0.1611])
+    xr = x.clone().requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):      # the reference's forward_batched prints debug lines
+        outq = cmq(hidden_states=xr, encoder_hidden_states=pe, encoder_hidden_states_mask=None, timestep=tt, img_shapes=shapes_b,
+                   txt_seq_lens=txt_lens, return_dict=False, attention_mask=full)[0]
+    tgt = torch.randn(outq.shape, generator=g)
+    (gxr,) = torch.autograd.grad(((outq - tgt) ** 2).mean(), [xr])
+    xo = x.clone().requires_grad_(True)
+    oo = oq(hidden_states=xo, encoder_hidden_states=pe, timestep=tt, img_shapes=shapes_b, txt_seq_lens=txt_lens, attention_mask=full)[0]
+    (gxo,) = torch.autograd.grad(((oo - tgt) ** 2).mean(), [xo])
+    print("qwen multi-res oracle vs reference custom model: fwd %.3e gx %.3e; padded output max %.1e" % (
+        (oo - outq).abs().max().item(), (gxo - gxr).abs().max().item(), outq[1, lens[1]:].abs().max().item()))
+    assert (oo - outq).abs().max() < 1e-5 and (gxo - gxr).abs().max() < 1e-6
+    save_file({"in.hidden_states": x, "in.encoder_hidden_states": pe, "in.timestep": tt, "in.attention_mask": full.to(torch.uint8),
+               "in.target": tgt, "in.shapes": torch.tensor([[list(t_) for t_ in sh] for sh in shapes_b]), "in.txt_lens": torch.tensor(txt_lens),
+               "out.sample": outq.detach().contiguous(), "grad.hidden_states": gxr.contiguous(), "w.checksum": weight_checksum(cmq)},
+              os.path.join(HERE, "qwen_tiny_multires.safetensors"), metadata={"cfg": repr(TINY), "weights": "common.fill_weights seed 1"})
     # ---------------- criteria: the reference's OWN loss classes (importable without diffusers) ----------------
     for m_ in ("qflux.losses",):
         if m_ not in sys.modules:

@@ -165,3 +165,25 @@ def test_criteria_match_reference_loss_classes(golden_dir):
     assert abs(O.mask_edit_loss(pr, tg, None, 2.0, 1.0).item() - t["mask_edit_none"].item()) < 1e-6
     assert abs(FO.attention_mask_mse_loss(pr, tg, am).item() - t["attn_mask_mse"].item()) < 1e-6
     assert torch.equal(O.map_mask_to_latent(t["pixel_mask"]), t["latent_mask"])
+
+
+def test_qwen_multires_matches_reference_custom_vectors(golden_dir):
+    """Ragged right-padded batch (per-sample shape lists AND ragged text lengths) through the oracle vs vectors from the
+    reference's transformer_qwen_custom.py: per-sample RoPE placement, additive key mask, padded rows zeroed."""
+    from oracle import qwen_dit as O
+    t = load_file(os.path.join(golden_dir, "qwen_tiny_multires.safetensors"))
+    m = O.OracleQwenDiT(**TINY)
+    fill_weights(m, seed=1)
+    assert torch.equal(weight_checksum(m), t["w.checksum"])
+    shapes = [[tuple(int(v) for v in s) for s in sh] for sh in t["in.shapes"].tolist()]
+    lens = [int(v) for v in t["in.txt_lens"]]
+    full = t["in.attention_mask"].bool()
+    x = t["in.hidden_states"].clone().requires_grad_(True)
+    out = m(hidden_states=x, encoder_hidden_states=t["in.encoder_hidden_states"], timestep=t["in.timestep"], img_shapes=shapes,
+            txt_seq_lens=lens, attention_mask=full)[0]
+    assert (out - t["out.sample"]).abs().max() < 1e-5
+    T = t["in.encoder_hidden_states"].shape[1]
+    pad = ~full[:, T:]
+    assert pad.any() and out[pad].abs().max() == 0
+    (gx,) = torch.autograd.grad(((out - t["in.target"]) ** 2).mean(), [x])
+    assert (gx - t["grad.hidden_states"]).abs().max() < 1e-6
