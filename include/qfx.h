@@ -233,8 +233,8 @@ typedef struct qfx_attn_args {
 } qfx_attn_args;
 
 int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,V -> O,lse2 */
-int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream);  /* dsum = rowsum(dO*O) */
-int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream);    /* needs Q,K,V,dO,lse2,dsum -> dQ */
+int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream);  /* dsum = rowsum(dO*O); optional: qfx_attn_bwd_dq computes and writes it too */
+int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream);    /* needs Q,K,V,O,dO,lse2 -> dQ and dsum (= rowsum(dO*O), consumed by qfx_attn_bwd_dkv: launch dq first) */
 int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream);   /* needs Q,K,V,dO,lse2,dsum -> dK,dV */
 
 /* ---- flow-matching MSE criterion (src/qflux/losses/mse_loss.py:66-83 with weighting=1;

@@ -1,8 +1,8 @@
 // qfx_attn.hip -- joint [text|image] non-causal flash attention for gfx950, forward + backward.
 //
-// MFMA 16x16x32 bf16 everywhere; every operand is read K-contiguous from row-major LDS tiles:
-// the transposed views an attention backward needs (Q^T, K^T, V^T, dO^T as [B,H,dh,S_pad]) are
-// materialised once per block by qfx_transpose_heads (HBM is plentiful, LDS transposes are not).
+// MFMA 16x16x32 bf16 everywhere.  Every tile lives in LDS ROW-major ([tokens][dh], LDS-DMA, double-buffered); operands that
+// contract over dh are read with ds_read_b128, operands that contract over TOKENS (V^T for PV, K^T for dQ, Q^T / dO^T for
+// dK / dV) come from the same tiles through the gfx950 transpose read ds_read_b64_tr_b16 -- no transposed copy exists in HBM.
 // Scores are computed "swapped" (S^T = K Q^T, i.e. D[i=key][j=query]) so that a lane owns ONE
 // query column: softmax statistics are lane-local plus two cross-lane steps, and the bf16-packed
 // P registers are directly the B operand of the PV MFMA under the key permutation
@@ -50,41 +50,8 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* base, int64_
   }
 }
 
-// DH rows x 64 tile of a [.., DH, S_pad] tensor (columns s0..s0+63) -> LDS [DH][64], swizzled.
-// base points at element [b, h, 0, 0].
-template <int DH>
-__device__ __forceinline__ void stage_cols(char* lds, const bf16_t* base, int64_t S_pad, int s0, int w, int lane) {
-  constexpr int NI = DH / 32;  // 8 rows per wave-instruction, DH/4 rows per wave
-  const int rr = lane >> 3, c = lane & 7;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int row = w * (DH / 4) + i * 8 + rr;
-    const int sc = c ^ ((row >> 1) & 7);
-    glds16(base + (int64_t)row * S_pad + s0 + sc * 8, lds + (w * (DH / 4) + i * 8) * 128);
-  }
-}
 
-// fragment (16 rows x 32 k) of a [64][DH] tile: lane (g, li) gets row rf*16+li, k = kk*32 + 8g..+7
-template <int DH>
-__device__ __forceinline__ bf16x8 read_rowfrag(const char* lds, int rf, int kk, int g, int li) {
-  const int row = rf * 16 + li;
-  const int chunk = kk * 4 + g;
-  return *(const bf16x8*)(lds + row * (DH * 2) + ((chunk ^ swz_row<DH>(row)) << 4));
-}
 
-// fragment of a [DH][64] tile under the pi permutation: row df*16+li, cols {32t+4g..+3, 32t+16+4g..+3}
-__device__ __forceinline__ bf16x8 read_colfrag(const char* lds, int df, int t, int g, int li) {
-  const int row = df * 16 + li;
-  const int sw = (row >> 1) & 7;
-  const int c1 = 4 * t + (g >> 1), c2 = c1 + 2;
-  const int off = 8 * (g & 1);
-  const bf16x4 lo = *(const bf16x4*)(lds + row * 128 + ((c1 ^ sw) << 4) + off);
-  const bf16x4 hi = *(const bf16x4*)(lds + row * 128 + ((c2 ^ sw) << 4) + off);
-  bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
-}
 
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   bf16x8 r;
@@ -95,14 +62,6 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs <= 0 here)
 
-__device__ __forceinline__ bf16x8 colfrag_at(const char* lds, int o1, int o2) {
-  const bf16x4 lo = *(const bf16x4*)(lds + o1);
-  const bf16x4 hi = *(const bf16x4*)(lds + o2);
-  bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
-}
 
 // 1-D grid -> (seq block, head, batch) with an XCD-aware bijection: hardware dispatches workgroup i to XCD i % 8, so the
 // virtual id walks each XCD through a CONTIGUOUS range of (batch, head, block) triples: all blocks of one head run on
@@ -354,7 +313,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) { qf[f][kk] = *(const bf16x8*)(qp + kk * 32); dof[f][kk] = *(const bf16x8*)(dp + kk * 32); }
     lse[f] = a.lse2[((int64_t)b * a.H + h) * a.S_pad + q];
-    dsm[f] = a.dsum[((int64_t)b * a.H + h) * a.S_pad + q];
+    // dsum[q] = sum_d dO[q,d] * O[q,d] is computed HERE (the lane already holds its 32 dO elements of row q) and published
+    // for the dK/dV kernel, which runs after this one: no separate qfx_attn_bwd_prep launch or pass over O / dO is needed.
+    const bf16_t* op = a.O + ((int64_t)b * S + q) * a.ldo + h * DH + 8 * g;
+    float part = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+      const bf16x8 ov = *(const bf16x8*)(op + kk * 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part += bf2f((bf16_t)dof[f][kk][j]) * bf2f((bf16_t)ov[j]);
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    dsm[f] = part;
+    if (g == 0 && q0 + f * 16 + li < S) a.dsum[((int64_t)b * a.H + h) * a.S_pad + q] = part;
   }
   f32x4 dq[DF][2];
 #pragma unroll
@@ -465,25 +437,7 @@ __device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int6
     glds16(base + (int64_t)s * ld + sc * 8, lds + (w * RPW + i * RPI) * (DH * 2));
   }
 }
-template <int DH, int NW>
-__device__ __forceinline__ void stage_cols_n(char* lds, const bf16_t* base, int64_t S_pad, int s0, int w, int lane) {
-  constexpr int RPW = DH / NW, NI = RPW / 8;
-  static_assert(NI >= 1, "too many waves for this tile");
-  const int rr = lane >> 3, c = lane & 7;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int row = w * RPW + i * 8 + rr;
-    const int sc = c ^ ((row >> 1) & 7);
-    glds16(base + (int64_t)row * S_pad + s0 + sc * 8, lds + (w * RPW + i * 8) * 128);
-  }
-}
 
-__device__ __forceinline__ bf16x4 pack4(const f32x4& a) {
-  bf16x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = (short)f2bf(a[i]);
-  return r;
-}
 __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
   bf16x8 r;
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
@@ -719,8 +673,8 @@ extern "C" int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream) {
 extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
-  if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
-  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
+  if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
   dim3 grid(((a->S + 127) / 128) * a->H * a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);

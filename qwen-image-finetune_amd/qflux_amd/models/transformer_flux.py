@@ -514,7 +514,6 @@ class _FluxPlan(_QwenPlan):
         self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT[D:], K1=D, M=M, N=4 * D, C_=A["A2"], ldc=ldA2, epi=L.EPI_DGELU, aux=bb["h"],
                    ldaux=4 * D)
         q2 = bb["qkv"].view(M, 3 * D)
-        p.c(lib.qfx_attn_bwd_prep, C.byref(a))
         p.c(lib.qfx_attn_bwd_dq, C.byref(a))
         p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
         nq, nk = w["norms"]

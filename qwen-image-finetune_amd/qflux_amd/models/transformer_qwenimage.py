@@ -910,7 +910,6 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             # ---- attention backward
             q2 = bb["qkv"].view(B * S, 3 * D)
-            p.c(lib.qfx_attn_bwd_prep, C.byref(a))
             p.c(lib.qfx_attn_bwd_dq, C.byref(a))
             p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
             nq_t, nk_t, nq_i, nk_i = w["norms"]
