@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt) {
 }
 
 // ---------------------------------------------------------------- LayerNorm + modulate, backward
+template <int NP>   // passes of 512 columns: NP = ceil(D / 512) (register arrays are sized by it)
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,64 +110,75 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   if (row_mask != nullptr && row_mask[row] == 0.f) {   // padded token: no gradient flows through it
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int col = (p * 64 + lane) * 8;
       if (col < D) { *(u32x4*)(dx + ro + col) = z; if (dyg) *(u32x4*)(dyg + ro + col) = z; }
     }
     return;
   }
-  float v[MAXP][8];   // x, later xhat
-  float gq[MAXP][8];  // g = bf16(dy * bf16(1+scale))
-  float s = 0.f;
+  // All three HBM streams of the row (x, dy, dres) are requested up front and kept as packed bf16 (one memory latency instead of
+  // three dependent ones); g = bf16(dy * bf16(1+scale)) is exactly representable in bf16 and is kept packed too.
+  u32x4 xr[NP], dyr[NP], drr[NP], gp[NP];
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int col = (p * 64 + lane) * 8;
     if (col < D) {
-      ld8(x + ro + col, v[p]);
+      xr[p] = *(const u32x4*)(x + ro + col);
+      dyr[p] = *(const u32x4*)(dy + ro + col);
+      if (dres) drr[p] = *(const u32x4*)(dres + ro + col);
+    }
+  }
+  auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+  auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+  float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[p][i];
+  for (int p = 0; p < NP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += lo(xr[p][i]) + hi(xr[p][i]);
     }
   }
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int col = (p * 64 + lane) * 8;
     if (col < D) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const float d = v[p][i] - mean; q += d * d; }
+      for (int i = 0; i < 4; ++i) { const float d0 = lo(xr[p][i]) - mean, d1 = hi(xr[p][i]) - mean; q += d0 * d0 + d1 * d1; }
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
   float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int col = (p * 64 + lane) * 8;
     if (col < D) {
-      float sc[8], d[8];
-      ld8(scale + (int64_t)b * mod_bstride + col, sc);
-      ld8(dy + ro + col, d);
+      const u32x4 sc = *(const u32x4*)(scale + (int64_t)b * mod_bstride + col);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        v[p][i] = (v[p][i] - mean) * rstd;
-        gq[p][i] = rbf(d[i] * rbf(1.0f + sc[i]));
-        c1 += gq[p][i];
-        c2 += gq[p][i] * v[p][i];
+      for (int i = 0; i < 4; ++i) {
+        const float g0 = rbf(lo(dyr[p][i]) * rbf(1.0f + lo(sc[i])));
+        const float g1 = rbf(hi(dyr[p][i]) * rbf(1.0f + hi(sc[i])));
+        gp[p][i] = pack2bf(g0, g1);
+        c1 += g0 + g1;
+        c2 += g0 * ((lo(xr[p][i]) - mean) * rstd) + g1 * ((hi(xr[p][i]) - mean) * rstd);
       }
     }
   }
   c1 = wave_sum(c1) / (float)D;
   c2 = wave_sum(c2) / (float)D;
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int col = (p * 64 + lane) * 8;
     if (col < D) {
-      float o[8], r[8];
-      if (dres) ld8(dres + ro + col, r);
+      float o[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float dl = rbf((gq[p][i] - c1 - v[p][i] * c2) * rstd);
-        o[i] = dres ? rbf(r[i] + dl) : dl;
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = (lo(xr[p][i]) - mean) * rstd, x1 = (hi(xr[p][i]) - mean) * rstd;
+        const float d0 = rbf((lo(gp[p][i]) - c1 - x0 * c2) * rstd), d1 = rbf((hi(gp[p][i]) - c1 - x1 * c2) * rstd);
+        o[2 * i] = dres ? rbf(lo(drr[p][i]) + d0) : d0;
+        o[2 * i + 1] = dres ? rbf(hi(drr[p][i]) + d1) : d1;
       }
       st8(dx + ro + col, o);
       if (dyg) {
@@ -612,7 +624,10 @@ extern "C" int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n,
   }
   for (int i = n; i < QFX_MAX_LN_BATCH; ++i) bt.a[i] = list[0];
   bt.n = n;
-  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
+  int dmax = 0;
+  for (int i = 0; i < n; ++i) dmax = list[i].D > dmax ? list[i].D : dmax;
+  if (dmax <= 3072) hipLaunchKernelGGL(ln_mod_bwd_kernel<6>, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
+  else hipLaunchKernelGGL(ln_mod_bwd_kernel<MAXP>, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
