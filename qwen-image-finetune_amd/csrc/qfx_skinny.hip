@@ -17,10 +17,11 @@ namespace {
 struct DownBatch { qfx_lora_down_args a[QFX_MAX_BATCH]; int start[QFX_MAX_BATCH + 1]; int n; };
 struct GradBatch { qfx_lora_grad_args a[QFX_MAX_BATCH]; int start[QFX_MAX_BATCH + 1]; int n; };
 
-template <int NF>
+template <int NF, int RB>   // RB = 16-row groups per block: every block streams ALL of W (hi+lo) from L2, so two groups per block
+                            // halve that traffic (for R=48 it was 6x the X bytes and the actual bound of the kernel)
 __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by_value) {
   constexpr int NW = 8;
-  __shared__ float red[NW][NF * 256];
+  __shared__ float red[NW][RB * NF * 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -30,11 +31,15 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
   for (int i = 1; i < QFX_MAX_BATCH; ++i)
     if (i < kb.n && (int)blockIdx.x >= kb.start[i]) pi = i;
   const QFX_AS4 qfx_lora_down_args& p = kb.a[pi];
-  const int m0 = ((int)blockIdx.x - kb.start[pi]) * 16;
+  const int m0 = ((int)blockIdx.x - kb.start[pi]) * (16 * RB);
 
-  int mr = m0 + li;
-  mr = mr < p.M ? mr : p.M - 1;
-  const bf16_t* xrow = p.X + remap_row(mr, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + 8 * g;
+  const bf16_t* xrow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    int mr = m0 + rb * 16 + li;
+    mr = mr < p.M ? mr : p.M - 1;
+    xrow[rb] = p.X + remap_row(mr, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + 8 * g;
+  }
   const bf16_t* wh[NF];
   const bf16_t* wl[NF];
 #pragma unroll
@@ -42,21 +47,23 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
     wh[nf] = p.W_hi + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
     wl[nf] = p.W_lo + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
   }
-  f32x4 acc[NF];
+  f32x4 acc[RB][NF];
 #pragma unroll
-  for (int j = 0; j < NF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[rb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // The kernel is a latency chain, not a bandwidth stream (152 blocks, ~12 k-steps per wave): ALL X fragments of a
-  // 12-step chunk are requested up front (one HBM latency per chunk instead of one per step pair); the weight
-  // fragments are L2 hits and are double-buffered one step ahead of the MFMAs.
+  // The kernel is a latency chain, not a bandwidth stream (~12 k-steps per wave): ALL X fragments of a chunk are requested up
+  // front (one HBM latency per chunk); the weight fragments are L2 hits and are double-buffered one step ahead of the MFMAs.
   const int nks = p.K / 32;
-  constexpr int CHK = 12;
+  constexpr int CHK = RB == 1 ? 12 : 6;
   for (int base = w; base < nks; base += NW * CHK) {
-    bf16x8 xs[CHK];
+    bf16x8 xs[CHK][RB];
 #pragma unroll
     for (int i = 0; i < CHK; ++i) {
       const int ks = base + i * NW;
-      xs[i] = ks < nks ? *(const bf16x8*)(xrow + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) xs[i][rb] = ks < nks ? *(const bf16x8*)(xrow[rb] + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
     bf16x8 hcur[NF], lcur[NF], hnext[NF], lnext[NF];
 #pragma unroll
@@ -70,26 +77,31 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
       }
       if (base + i * NW < nks) {
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) {
-          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i], hcur[nf], acc[nf], 0, 0, 0);
-          acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i], lcur[nf], acc[nf], 0, 0, 0);
-        }
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            acc[rb][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i][rb], hcur[nf], acc[rb][nf], 0, 0, 0);
+            acc[rb][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i][rb], lcur[nf], acc[rb][nf], 0, 0, 0);
+          }
       }
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) { hcur[nf] = hnext[nf]; lcur[nf] = lnext[nf]; }
     }
   }
 #pragma unroll
-  for (int nf = 0; nf < NF; ++nf)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[w][(nf * 64 + lane) * 4 + r] = acc[nf][r];
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][((rb * NF + nf) * 64 + lane) * 4 + r] = acc[rb][nf][r];
   __syncthreads();
-  for (int e = tid; e < NF * 256; e += 512) {
+  for (int e = tid; e < RB * NF * 256; e += 512) {
     float v = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) v += red[ww][e];
-    const int r = e & 3, ln = (e >> 2) & 63, nf = e >> 8;
-    const int m = m0 + 4 * (ln >> 4) + r;   // D[i = 4g+r][j = lane&15]
+    const int r = e & 3, ln = (e >> 2) & 63, fi = e >> 8;
+    const int rb = fi / NF, nf = fi % NF;
+    const int m = m0 + rb * 16 + 4 * (ln >> 4) + r;   // D[i = 4g+r][j = lane&15]
     const int j = nf * 16 + (ln & 15);
     if (m >= p.M) continue;
     if (p.U) p.U[(int64_t)m * p.ldu + j] = v;
@@ -297,6 +309,11 @@ int check_grad(const qfx_lora_grad_args* a) {
 extern "C" int qfx_lora_down_batch(const qfx_lora_down_args* list, int32_t n, void* stream) {
   if (!list || n <= 0 || n > QFX_MAX_BATCH) return QFX_EINVAL;
   DownBatch b;
+  int blocks16 = 0;
+  for (int i = 0; i < n; ++i) blocks16 += (list[i].M + 15) / 16;
+  // two 16-row groups per block only when that still leaves >= ~200 blocks (measured: 384 -> 192 blocks 23.8 -> 18.5 us,
+  // but 128 -> 64 blocks 20.7 -> 23.7 us: the kernel is a latency chain and needs the CUs covered)
+  const int rb = (blocks16 >= 300 && list[0].R <= 48) ? 2 : 1;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
     const int rc = check_down(&list[i]);
@@ -304,20 +321,24 @@ extern "C" int qfx_lora_down_batch(const qfx_lora_down_args* list, int32_t n, vo
     if (list[i].R != list[0].R) return QFX_EINVAL;   /* one MFMA fragment count per launch */
     b.a[i] = list[i];
     b.start[i] = blocks;
-    blocks += (list[i].M + 15) / 16;
+    blocks += (list[i].M + 16 * rb - 1) / (16 * rb);
   }
   for (int i = n; i <= QFX_MAX_BATCH; ++i) b.start[i] = blocks;
   b.n = n;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(blocks), block(512);
+#define QFX_DOWN(NF) \
+  do { if (rb == 2) hipLaunchKernelGGL((lora_down_kernel<NF, 2>), grid, block, 0, s, b); \
+       else hipLaunchKernelGGL((lora_down_kernel<NF, 1>), grid, block, 0, s, b); } while (0)
   switch (list[0].R / 16) {
-    case 1: hipLaunchKernelGGL(lora_down_kernel<1>, grid, block, 0, s, b); break;
-    case 2: hipLaunchKernelGGL(lora_down_kernel<2>, grid, block, 0, s, b); break;
-    case 3: hipLaunchKernelGGL(lora_down_kernel<3>, grid, block, 0, s, b); break;
-    case 4: hipLaunchKernelGGL(lora_down_kernel<4>, grid, block, 0, s, b); break;
-    case 6: hipLaunchKernelGGL(lora_down_kernel<6>, grid, block, 0, s, b); break;
+    case 1: QFX_DOWN(1); break;
+    case 2: QFX_DOWN(2); break;
+    case 3: QFX_DOWN(3); break;
+    case 4: hipLaunchKernelGGL((lora_down_kernel<4, 1>), grid, block, 0, s, b); break;
+    case 6: hipLaunchKernelGGL((lora_down_kernel<6, 1>), grid, block, 0, s, b); break;
     default: return QFX_EUNSUPPORTED;
   }
+#undef QFX_DOWN
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
