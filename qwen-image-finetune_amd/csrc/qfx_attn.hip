@@ -63,6 +63,21 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (inputs <= 0 here)
 
 
+// 64 rows x DH tile staged by NW waves (rows s0..s0+63 clamped to S-1) -> LDS [64][DH], swizzled.
+template <int DH, int NW>
+__device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int64_t ld, int s0, int S, int w, int lane) {
+  constexpr int CPR = DH / 8, RPI = 64 / CPR, RPW = 64 / NW, NI = RPW / RPI;
+  static_assert(NI >= 1, "too many waves for this tile");
+  const int rr = lane / CPR, c = lane % CPR;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = w * RPW + i * RPI + rr;
+    int s = s0 + row; s = s < S ? s : S - 1;
+    const int sc = c ^ swz_row<DH>(row);
+    glds16(base + (int64_t)s * ld + sc * 8, lds + (w * RPW + i * RPI) * (DH * 2));
+  }
+}
+
 // 1-D grid -> (seq block, head, batch) with an XCD-aware bijection: hardware dispatches workgroup i to XCD i % 8, so the
 // virtual id walks each XCD through a CONTIGUOUS range of (batch, head, block) triples: all blocks of one head run on
 // one XCD and its K/V (or Q/dO) tiles are fetched into one L2 instead of eight (PMC: fabric-side fetch per launch was
@@ -81,8 +96,11 @@ __device__ __forceinline__ void attn_block_coord(int nx, int H, int& xb, int& h,
 
 // =============================================================================================
 // forward: block = 128 queries (4 waves x 32), loop over 64-key tiles, K/V^T double-buffered in LDS
-template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a) {
+// NW = waves per block (32 queries each).  8 waves / 256 queries, one block per CU, is used when it quantises better onto the
+// 256 CUs (S = 2432: 10 x 24 = 240 blocks, 94 % of the CUs, against 456 blocks on 512 half-CU slots = 89 %) and halves the K/V
+// LDS-DMA traffic per query; 4 waves / 128 queries, two blocks per CU, otherwise.
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(const qfx_attn_args a) {
   constexpr int KC = DH / 32, DF = DH / 16;
   constexpr int TB = 64 * DH * 2;  // bytes per tile (K tile and V^T tile are the same size)
   __shared__ __attribute__((aligned(16))) char smem[4 * TB];
@@ -90,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   int xb, h, b;
-  attn_block_coord((a.S + 127) / 128, a.H, xb, h, b);
-  const int q0 = xb * 128 + w * 32;
+  attn_block_coord((a.S + 32 * NW - 1) / (32 * NW), a.H, xb, h, b);
+  const int q0 = xb * (32 * NW) + w * 32;
   const int S = a.S;
 
   const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
@@ -120,16 +138,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const qfx_attn_args a)
   const int tr1 = 4 * g + (li >> 2);
   const int toff0 = tr1 * (DH * 2) + ((((li & 3) >> 1) ^ swz_row<DH>(tr1)) << 4) + (li & 1) * 8;
   const int ntiles = (S + 63) / 64;
-  stage_rows<DH>(smem, Kb, a.ldk, 0, S, w, lane);
-  stage_rows<DH>(smem + TB, Vb, a.ldv, 0, S, w, lane);
+  stage_rows_n<DH, NW>(smem, Kb, a.ldk, 0, S, w, lane);
+  stage_rows_n<DH, NW>(smem + TB, Vb, a.ldv, 0, S, w, lane);
   __syncthreads();
   for (int jt = 0; jt < ntiles; ++jt) {
     const char* sK = smem + (jt & 1) * 2 * TB;
     const char* sV = sK + TB;
     if (jt + 1 < ntiles) {
       char* nK = smem + ((jt + 1) & 1) * 2 * TB;
-      stage_rows<DH>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
-      stage_rows<DH>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
+      stage_rows_n<DH, NW>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
+      stage_rows_n<DH, NW>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
     }
     const int j0 = jt * 64;
     f32x4 sacc[4][2];
@@ -272,8 +290,8 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const qfx_attn_args a) {
 
 // =============================================================================================
 // dQ: block = 128 queries (4 waves x 32), loop over 64-key tiles (K, V row tiles + K^T column tile)
-template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args a) {
+template <int DH, int NW>   // NW as in attn_fwd_kernel
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_kernel(const qfx_attn_args a) {
   constexpr int KC = DH / 32, DF = DH / 16;
   constexpr int TB = 64 * DH * 2;
   __shared__ __attribute__((aligned(16))) char smem[4 * TB];   // 2 x [K | V] row tiles (double-buffered LDS-DMA)
@@ -281,24 +299,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   int xb, h, b;
-  attn_block_coord((a.S + 127) / 128, a.H, xb, h, b);
-  const int q0 = xb * 128 + w * 32;
+  attn_block_coord((a.S + 32 * NW - 1) / (32 * NW), a.H, xb, h, b);
+  const int q0 = xb * (32 * NW) + w * 32;
   const int S = a.S;
   const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
   const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
 
   // DMA sources as uniform base + 32-bit lane offset (rows past S clamp to S-1)
-  constexpr int CPR = DH / 8, RPI = 64 / CPR, NIS = 16 / RPI;
+  constexpr int CPR = DH / 8, RPI = 64 / CPR, RPW = 64 / NW, NIS = RPW / RPI;
   auto stage = [&](int jt, int buf) {
     const int j0 = jt * 64;
     char* dK_ = smem + buf * 2 * TB;
 #pragma unroll
     for (int i = 0; i < NIS; ++i) {
-      const int row = w * 16 + i * RPI + lane / CPR;
+      const int row = w * RPW + i * RPI + lane / CPR;
       const int sc8 = ((lane % CPR) ^ swz_row<DH>(row)) * 8;
       int sr = j0 + row; sr = sr < S ? sr : S - 1;
-      glds16(Kb + (unsigned)(sr * a.ldk + sc8), dK_ + (w * 16 + i * RPI) * (DH * 2));
-      glds16(Vb + (unsigned)(sr * a.ldv + sc8), dK_ + TB + (w * 16 + i * RPI) * (DH * 2));
+      glds16(Kb + (unsigned)(sr * a.ldk + sc8), dK_ + (w * RPW + i * RPI) * (DH * 2));
+      glds16(Vb + (unsigned)(sr * a.ldv + sc8), dK_ + TB + (w * RPW + i * RPI) * (DH * 2));
     }
   };
   stage(0, 0);
@@ -424,19 +442,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const qfx_attn_args
 
 // =============================================================================================
 // staging helpers for NW-wave blocks (64-row / 64-column tiles)
-template <int DH, int NW>
-__device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int64_t ld, int s0, int S, int w, int lane) {
-  constexpr int CPR = DH / 8, RPI = 64 / CPR, RPW = 64 / NW, NI = RPW / RPI;
-  static_assert(NI >= 1, "too many waves for this tile");
-  const int rr = lane / CPR, c = lane % CPR;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int row = w * RPW + i * RPI + rr;
-    int s = s0 + row; s = s < S ? s : S - 1;
-    const int sc = c ^ swz_row<DH>(row);
-    glds16(base + (int64_t)s * ld + sc * 8, lds + (w * RPW + i * RPI) * (DH * 2));
-  }
-}
 
 __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
   bf16x8 r;
@@ -638,6 +643,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
   }
 }
 
+// Waves per block of the forward kernel.  Two independent 4-wave blocks per CU hide each other's barriers and are faster per
+// unit of work (S = 8576: 837 vs 776 TF/s), so the 8-wave / one-block-per-CU form is chosen only where it fills the last round of
+// the 256 CUs clearly better (S = 2432: 240 blocks = 94 % vs 456 blocks on 512 half-CU slots = 89 %: 669 -> 710 TF/s).  The dQ
+// kernel measured slower with 8 waves in both cases and always uses 4.
+int pick_waves(const qfx_attn_args* a) {
+  const long hb = (long)a->H * a->B;
+  const long b4 = (long)((a->S + 127) / 128) * hb, b8 = (long)((a->S + 255) / 256) * hb;
+  const double e4 = (double)b4 / (double)(((b4 + 511) / 512) * 512), e8 = (double)b8 / (double)(((b8 + 255) / 256) * 256);
+  return e8 > 1.04 * e4 ? 8 : 4;
+}
+
 int check_common(const qfx_attn_args* a) {
   if (!a || a->B <= 0 || a->S <= 0 || a->H <= 0 || (a->S_pad % 64) || a->S_pad < a->S) return QFX_EINVAL;
   if (a->dh != 64 && a->dh != 128) return QFX_EUNSUPPORTED;
@@ -650,9 +666,15 @@ extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return QFX_EINVAL;
-  dim3 grid(((a->S + 127) / 128) * a->H * a->B);
-  if (a->dh == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  const int nw = pick_waves(a);
+  dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
+  if (a->dh == 128) {
+    if (nw == 8) hipLaunchKernelGGL((attn_fwd_kernel<128, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  } else {
+    if (nw == 8) hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
@@ -675,9 +697,15 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
-  dim3 grid(((a->S + 127) / 128) * a->H * a->B);
-  if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  const int nw = 4;   /* see pick_waves */
+  dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
+  if (a->dh == 128) {
+    if (nw == 8) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 4>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  } else {
+    if (nw == 8) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 8>), grid, dim3(512), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 4>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
