@@ -31,26 +31,24 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
-// tanh(u) = 1 - 2/(1 + e^{2u}) on the hardware exp2/rcp (1 ulp each): e overflows to +inf -> rcp 0 -> 1, underflows
-// to 0 -> -1.  Absolute error ~1e-7, far below the bf16 rounding every caller applies; the library tanhf costs ~5x
-// more VALU work and was 20 % of the fc1 / dgelu GEMM launches.
-__device__ __forceinline__ float fast_tanh_f(float u) {
-  const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+// gelu(approximate="tanh"): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3), evaluated with the
+// hardware exp2 / rcp (1 ulp each): s = 1 / (1 + 2^(-2u log2 e)).  e overflows to +inf -> s = 0, underflows to 0 -> s = 1.
+// Absolute error ~1e-7, far below the bf16 rounding every caller applies; the library tanhf costs ~5x more VALU work and was
+// 20 % of the fc1 / dgelu GEMM launches.  7 VALU ops per element (2 of them transcendental).
+__device__ __forceinline__ float gelu_sigmoid2u_f(float x, float x2) {
+  // -2 * log2(e) * sqrt(2/pi) = -2.3022082; 0.044715 * that = -0.10294324
+  const float t = x * __builtin_fmaf(x2, -0.10294324f, -2.3022082f);     // = -2u log2(e)
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // torch gelu(approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + fast_tanh_f(u));
+  return x * gelu_sigmoid2u_f(x, x * x);
 }
+// d/dx [x s(2u)] = s + x s (1 - s) 2u',  2u' = 2 sqrt(2/pi) (1 + 3*0.044715 x^2)
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float x2 = x * x;
-  float u = k0 * (x + k1 * x * x2);
-  float t = fast_tanh_f(u);
-  float du = k0 * (1.0f + 3.0f * k1 * x2);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+  const float x2 = x * x;
+  const float s = gelu_sigmoid2u_f(x, x2);
+  const float du2 = __builtin_fmaf(x2, 0.21406445f, 1.5957692f);          // 2 k0 (1 + 3 k1 x^2)
+  return __builtin_fmaf(x * du2, s - s * s, s);
 }
 
 // row remap for joint [text|image] buffers: row(m) = (m / rpb) * batch_rows + off + m % rpb
