@@ -126,8 +126,8 @@ def cpu_baseline(cfg_dims, blocks=1, steps=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--layers", type=int, default=60)
     ap.add_argument("--batch", type=int, default=1, help="per-GPU micro batch")
     ap.add_argument("--res", type=int, default=512)
