@@ -173,6 +173,12 @@ def main():
                prompt_embeds=(torch.randn(B, T, Jd) * 4).half().to(dev), prompt_embeds_mask=None,
                img_shapes=[[(1, side, side), (1, side, side)]] * B)
 
+    if world > 1:
+        # communicator / channel set-up outside the timed region even with --warmup 0: one collective of the gradient's size
+        dummy = torch.zeros_like(dit.lora_store.gflat)
+        dist.all_reduce(dummy)
+        torch.cuda.synchronize()
+        del dummy
     for _ in range(args.warmup):
         step.train_step(emb)
     if world > 1:
