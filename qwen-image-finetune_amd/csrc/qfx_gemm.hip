@@ -215,8 +215,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 // Grid = whole rounds over <= 256 CUs (multiple of 8 so that bid % 8 stays the XCD); grouped launch: up to
 // QFX_MAX_GROUPS independent problems (image/text streams, q/k/v) share one tile list.
 constexpr int BM2 = 256;
-constexpr int STAGE_BYTES = (BM2 + BN) * BK * 2;  // 48 KiB
-constexpr int NSTAGE = 3;
+// Tile width TN = 128: 8 compute waves 4x2 (64x64 each), 3-stage ring of 48 KiB.  TN = 256: 8 compute waves 2x4 (128x64 each,
+// 128 accumulator VGPRs, fragments streamed one at a time to stay inside the 168-VGPR budget of 10 waves per CU), 2-stage ring
+// of 64 KiB: a third less LDS-DMA and a quarter less fragment traffic per flop -- +8..10 % where the tile count still fills
+// whole rounds (N = 12288 problems), measured against the 128-wide form in tools/gemm_lab/ws256.hip.
+template <int TN> struct TileCfg {
+  static constexpr int STAGE = (BM2 + TN) * BK * 2;
+  static constexpr int NST = TN == 128 ? 3 : 2;
+  static constexpr int WRN = TN == 128 ? 4 : 2;     // compute waves along M
+  static constexpr int WCN = 8 / WRN;               // ... along N (64 columns each)
+  static constexpr int MI = BM2 / WRN / 16;         // 16-row MFMA fragments per wave
+};
 constexpr int NLD = 2;                            // loader waves
 constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
@@ -234,6 +243,7 @@ struct GroupedArgs {
 typedef const QFX_AS4 GroupedArgs KGroupedArgs;
 typedef const QFX_AS4 qfx_gemm_args KArgs;
 
+template <int TN>
 __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -245,18 +255,20 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
   // supertile order: consecutive tile ids walk 8 M-tiles before the next N-tile, so the ~32 tiles an XCD runs at
   // a time form an 8(M) x 4(N) patch that shares A rows and B rows in that XCD's L2.
   const int M = ga.g[gi].M, N = ga.g[gi].N;
-  const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + BN - 1) / BN;
+  const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + TN - 1) / TN;
   constexpr int GM = 8;
   const int per = GM * tiles_n, sg = lt / per, first = sg * GM;
   const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
   const int in = lt - sg * per;
   m0 = (first + in % gsz) * BM2;
-  n0 = (in / gsz) * BN;
+  n0 = (in / gsz) * TN;
 }
 
-template <int EPI>
+template <int EPI, int TN>
 __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArgs ga_by_value) {
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];  // 160 KiB
+  using TC = TileCfg<TN>;
+  constexpr int STAGE_BYTES = TC::STAGE, NSTAGE = TC::NST, MI = TC::MI;
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];  // 160 KiB (TN=128) / 144 KiB
   KGroupedArgs& ga = *(KGroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // == ga_by_value (sole explicit argument)
 
   const int tid = threadIdx.x;
@@ -267,33 +279,31 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   if (w >= 8) {
     // ================================================================ loader waves
     const int lw = w - 8;
-    constexpr int NA = 32 / NLD, NB = 16 / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
-    static_assert(NLD == 2 && NA + NB == 24, "vmcnt immediates below assume 24 pieces per K tile per loader wave");
+    constexpr int NA = 32 / NLD, NB = (TN / 8) / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
+    static_assert(NLD == 2 && (NA + NB == 24 || NSTAGE == 2), "vmcnt immediate below assumes 24 pieces per K tile per loader wave");
     const int srow = lane >> 3, schunk = lane & 7;
     // source column incl. the bank swizzle chunk ^ ((row>>1)&7); with NLD == 2 it is the same for every piece
     const int sc = (schunk ^ ((lw * 4 + (srow >> 1)) & 7)) * 8;
     const bf16_t* pa[NA];
     const bf16_t* pb[NB];
-    int ra[NA], rb[NB];
     int ibid = blockIdx.x, it = 0, int1 = 0, intt = 0, ist = 0;
+    int im0 = 0, in0 = 0, iM = 1, iN = 1;          // issue cursor's tile (rows are recomputed at the LoRA-segment switch)
     const bf16_t* iA2 = nullptr; const bf16_t* iB2 = nullptr;
     int ilda2 = 0, ildb2 = 0;
     auto setp = [&](int bid) {
-      int gi, m0, n0;
-      tile_coord(ga, nwg, bid, gi, m0, n0);
+      int gi;
+      tile_coord<TN>(ga, nwg, bid, gi, im0, in0);
       KArgs& p = ga.g[gi];
       int1 = p.K1 / BK; intt = int1 + p.K2 / BK;
-      iA2 = p.A2; iB2 = p.B2; ilda2 = p.lda2; ildb2 = p.ldb2;
+      iA2 = p.A2; iB2 = p.B2; ilda2 = p.lda2; ildb2 = p.ldb2; iM = p.M; iN = p.N;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        int gm = m0 + (lw + i * NLD) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
-        ra[i] = gm;
+        int gm = im0 + (lw + i * NLD) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
         pa[i] = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1 + sc;
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        int gn = n0 + (lw + i * NLD) * 8 + srow; gn = gn < p.N ? gn : p.N - 1;
-        rb[i] = gn;
+        int gn = in0 + (lw + i * NLD) * 8 + srow; gn = gn < p.N ? gn : p.N - 1;
         pb[i] = p.B1 + (int64_t)gn * p.ldb1 + sc;
       }
     };
@@ -301,9 +311,15 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     auto issue = [&]() {
       if (it == int1) {  // first K tile of the LoRA segment (A2 rows are never remapped)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) pa[i] = iA2 + (int64_t)ra[i] * ilda2 + sc;
+        for (int i = 0; i < NA; ++i) {
+          int gm = im0 + (lw + i * NLD) * 8 + srow; gm = gm < iM ? gm : iM - 1;
+          pa[i] = iA2 + (int64_t)gm * ilda2 + sc;
+        }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pb[i] = iB2 + (int64_t)rb[i] * ildb2 + sc;
+        for (int i = 0; i < NB; ++i) {
+          int gn = in0 + (lw + i * NLD) * 8 + srow; gn = gn < iN ? gn : iN - 1;
+          pb[i] = iB2 + (int64_t)gn * ildb2 + sc;
+        }
       }
       char* sA = smem + ist * STAGE_BYTES;
       char* sB = sA + BM2 * BK * 2;
@@ -321,14 +337,14 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     setp(ibid);
     int ahead = 0;  // K tiles issued and not yet handed over
     issue(); ++ahead;
-    if (more) { issue(); ++ahead; }
+    if (more && NSTAGE > 2) { issue(); ++ahead; }    // a 2-stage ring holds one K tile ahead only
     for (int wbid = blockIdx.x; wbid < nwg; wbid += gridDim.x) {
       int gi, m0, n0;
-      tile_coord(ga, nwg, wbid, gi, m0, n0);
+      tile_coord<TN>(ga, nwg, wbid, gi, m0, n0);
       const int ntw = ga.g[gi].K1 / BK + ga.g[gi].K2 / BK;
       for (int t = 0; t < ntw; ++t) {
         // the oldest K tile in flight must have landed; the one issued after it may still be in flight
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         --ahead;
@@ -339,24 +355,27 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   }
 
   // ================================================================== compute waves
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w / TC::WCN, wc = w % TC::WCN;
   const int g = lane >> 4, li = lane & 15;
+  constexpr int WROWS = 16 * MI;   // rows per compute wave
   char* stg = smem + NSTAGE * STAGE_BYTES + w * STG_BYTES;
   int buf = 0;
   for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
     int gi, m0, n0;
-    tile_coord(ga, nwg, bid, gi, m0, n0);
+    tile_coord<TN>(ga, nwg, bid, gi, m0, n0);
     KArgs& p = ga.g[gi];
     const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Rotated K loop: the second k-step of K tile t-1 is issued AFTER barrier t, under the first fragment reads of
-    // tile t, so the matrix pipe does not drain while the post-barrier ds_reads are in flight (+2..6 % in the lab).
+    // TN = 128 -- rotated K loop: the second k-step of K tile t-1 is issued AFTER barrier t, under the first fragment reads
+    // of tile t, so the matrix pipe does not drain while the post-barrier ds_reads are in flight (+2..6 % in the lab).
+    // TN = 256 -- streaming loop: per k-step the four B fragments stay resident and the eight A fragments pass through a
+    // three-deep ring, two reads ahead of the MFMAs that consume them (128 accumulators leave no room to double-buffer).
     auto round_base = [&]() {
       // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
 #pragma unroll
@@ -369,54 +388,88 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
           for (int r = 0; r < 4; ++r) bv[r] = bf2f((bf16_t)bb[r]);
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[mi][ni][r] = rbf(acc[mi][ni][r] + bv[r]);
       }
     };
     const bool mid_round = nt2 > 0 && !p.seg2_plain;
-    bf16x8 a0[4], b0[4], a1[4], b1[4];
-    for (int t = 0; t < nt; ++t) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of tile t-1 has returned: its stage may be refilled
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const char* sA = smem + buf * STAGE_BYTES;
-      const char* sB = sA + BM2 * BK * 2;
-      auto rdA = [&](int kk, int mi) {
-        const int row = wr * 64 + mi * 16 + li; const int chunk = kk * 4 + g;
-        return *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
-      };
-      auto rdB = [&](int kk, int ni) {
-        const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
-        return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
-      };
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-        if (mid_round && t == nt1) round_base();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-        a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+    if constexpr (TN == 128) {
+      bf16x8 a0[4], b0[4], a1[4], b1[4];
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of tile t-1 has returned: its stage may be refilled
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sA = smem + buf * STAGE_BYTES;
+        const char* sB = sA + BM2 * BK * 2;
+        auto rdA = [&](int kk, int mi) {
+          const int row = wr * WROWS + mi * 16 + li; const int chunk = kk * 4 + g;
+          return *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+        };
+        auto rdB = [&](int kk, int ni) {
+          const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
+          return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
+        };
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
         __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) {
+  #pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+  #pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+          if (mid_round && t == nt1) round_base();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+  #pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+          a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
       }
-      buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+  #pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+  #pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+    } else {
+      // lane-constant fragment offsets: the swizzle depends on li only (rows advance in multiples of 16), the k-step flips
+      // chunk bit 2, i.e. XOR 64 on the byte offset
+      const int swl = (li >> 1) & 7;
+      const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
+      const int offB0 = BM2 * BK * 2 + (wc * 64 + li) * (BK * 2) + ((g ^ swl) << 4);
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const char* pA = st + (offA0 ^ (kk << 6));
+          const char* pB = st + (offB0 ^ (kk << 6));
+          bf16x8 b[4];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(pB + ni * (16 * BK * 2));
+          bf16x8 fa0 = *(const bf16x8*)(pA), fa1 = *(const bf16x8*)(pA + 16 * BK * 2), fa2;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            if (mi + 2 < MI) fa2 = *(const bf16x8*)(pA + (mi + 2) * (16 * BK * 2));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], fa0, acc[mi][ni], 0, 0, 0);
+            fa0 = fa1; fa1 = fa2;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (mid_round && t == nt1 - 1) round_base();
+        buf ^= 1;
+      }
     }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
 
     // ---- epilogue (no block barrier): per 16-row pass the wave stages bf16(acc + bias) -- the nn.Linear output, first
     // rounding point of every epilogue -- in its private 2 KiB of LDS (8-byte unit u = ni*4+g of row li stored at
@@ -441,7 +494,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     float gt[8];
     int last_b = -1;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         u32x2 u;
@@ -453,7 +506,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       for (int j = 0; j < 2; ++j) {
         const int row = (lane >> 3) + 8 * j;
         const u32x4 yv = *(const u32x4*)(stg + row * 128 + ((ch ^ (row >> 1)) << 4));
-        const int m = m0 + wr * 64 + mi * 16 + row;
+        const int m = m0 + wr * WROWS + mi * 16 + row;
         if (m >= p.M || !n_ok) continue;
         const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
         if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
@@ -530,15 +583,29 @@ int validate(const qfx_gemm_args* a) {
 extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream) {
   if (!groups || n <= 0 || n > QFX_MAX_GROUPS) return QFX_EINVAL;
   GroupedArgs ga;
-  int tiles = 0;
+  long t128 = 0, t256 = 0;
+  bool can256 = true;
   for (int i = 0; i < n; ++i) {
     const int rc = validate(&groups[i]);
     if (rc) return rc;
     if (groups[i].epi != groups[0].epi) return QFX_EINVAL;
     if (!ok256(&groups[i])) return QFX_EINVAL;  /* 16-byte epilogue accesses */
+    const long tm = (groups[i].M + BM2 - 1) / BM2;
+    t128 += tm * ((groups[i].N + 127) / 128);
+    t256 += tm * ((groups[i].N + 255) / 256);
+    can256 = can256 && (groups[i].N % 256) == 0;
+  }
+  // Tile width: rounds over the 256 CUs x relative time per tile (a 256-wide tile is 2 / 1.09 of a 128-wide one: measured
+  // +9 % per flop).  N = 12288 problems (960 vs 480 tiles: 4 vs 2 rounds) take the wide tile; the N = 3072 ones (240 tiles, one
+  // round either way) and the 3-round q/k/v launch keep the narrow one.
+  const double cost128 = (double)((t128 + QFX_NUM_CU - 1) / QFX_NUM_CU);
+  const double cost256 = (double)((t256 + QFX_NUM_CU - 1) / QFX_NUM_CU) * (2.0 / 1.09);
+  const int tn = (can256 && cost256 < cost128) ? 256 : 128;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
     ga.g[i] = groups[i];
     ga.tile_start[i] = tiles;
-    tiles += ((groups[i].M + BM2 - 1) / BM2) * ((groups[i].N + BN - 1) / BN);
+    tiles += ((groups[i].M + BM2 - 1) / BM2) * ((groups[i].N + tn - 1) / tn);
   }
   for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
   ga.n = n;
@@ -548,12 +615,16 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
   int grid = (((tiles + rounds - 1) / rounds) + 7) & ~7;
   if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
   if (grid > tiles) grid = tiles;
+#define QFX_LAUNCH256(E) \
+  do { if (tn == 256) hipLaunchKernelGGL((gemm256_kernel<E, 256>), dim3(grid), dim3(WS_THREADS), 0, s, ga); \
+       else hipLaunchKernelGGL((gemm256_kernel<E, 128>), dim3(grid), dim3(WS_THREADS), 0, s, ga); } while (0)
   switch (groups[0].epi) {
-    case QFX_EPI_NONE: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_NONE>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-    case QFX_EPI_GELU: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GELU>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-    case QFX_EPI_GATE_RES: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_GATE_RES>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-    default: hipLaunchKernelGGL(gemm256_kernel<QFX_EPI_DGELU>, dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    case QFX_EPI_NONE: QFX_LAUNCH256(QFX_EPI_NONE); break;
+    case QFX_EPI_GELU: QFX_LAUNCH256(QFX_EPI_GELU); break;
+    case QFX_EPI_GATE_RES: QFX_LAUNCH256(QFX_EPI_GATE_RES); break;
+    default: QFX_LAUNCH256(QFX_EPI_DGELU); break;
   }
+#undef QFX_LAUNCH256
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

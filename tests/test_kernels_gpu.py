@@ -153,6 +153,60 @@ def test_gemm_dgelu():
     check("gemm_dgelu", out, ref, 1.5e-2)
 
 
+def test_gemm_wide_tile_all_epilogues():
+    """Shapes whose tile count selects the 256x256 tile (N % 256 == 0 and fewer weighted rounds): every epilogue, the LoRA
+    K segment with bf16 mid-rounding, a row remap, ragged M, a grouped launch and a row mask."""
+    ops = _ops()
+    M, N, K, K2 = 2000, 6144, 192, 64
+    a, b = randn(M, K, seed=1).to(BF), randn(N, K, seed=2, scale=0.2).to(BF)
+    a2, b2 = randn(M, K2, seed=3).to(BF), randn(N, K2, seed=4, scale=0.1).to(BF)
+    bias = randn(N, seed=5).to(BF)
+    base = rb(a.float() @ b.float().t() + bias.float())
+    h = rb(base + a2.float() @ b2.float().t())
+    g = rb(F.gelu(h, approximate="tanh"))
+    out2 = torch.empty(M, N, dtype=BF, device=DEV)
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), a2=a2.to(DEV), b2=b2.to(DEV), epi=1, out2=out2)
+    check("gemm_wide_seg2_pre", out, h, 1e-2)
+    check("gemm_wide_seg2_gelu", out2, g, 1e-2)
+    # plain + bias
+    check("gemm_wide_plain", ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV)), base, 1e-2)
+    # dgelu
+    hx = randn(M, N, seed=6).to(BF)
+    hh = hx.float().requires_grad_(True)
+    F.gelu(hh, approximate="tanh").sum().backward()
+    ref = rb(rb(a.float() @ b.float().t()) * hh.grad)
+    check("gemm_wide_dgelu", ops.gemm(a.to(DEV), b.to(DEV), epi=3, aux=hx.to(DEV)), ref, 1.5e-2)
+    # gate + residual with a C remap into a joint buffer and a row mask
+    Bn, rpb, T = 2, 1000, 24
+    S = T + rpb
+    gate = randn(Bn, N, seed=7).to(BF)
+    res = randn(M, N, seed=8).to(BF)
+    y = rb(a.float() @ b.float().t())
+    refg = rb(res.float() + rb(gate.float().repeat_interleave(rpb, 0) * y))
+    mask = torch.ones(M)
+    mask[777:1000] = 0
+    refg[mask == 0] = 0
+    cj = torch.zeros(Bn * S, N, dtype=BF, device=DEV)
+    resj = torch.zeros(Bn, S, N, dtype=BF)            # the residual lives in the same joint layout as C (aux is indexed like C)
+    resj[:, T:] = res.view(Bn, rpb, N)
+    ops.gemm(a.to(DEV), b.to(DEV), out=cj, epi=2, aux=resj.view(Bn * S, N).to(DEV), gate=gate.to(DEV), rows_per_batch=rpb, c_map=(S, T),
+             row_mask=mask.to(DEV))
+    check("gemm_wide_gate_res_cmap_mask", cj.view(Bn, S, N)[:, T:].reshape(M, N), refg, 1e-2)
+    assert cj.view(Bn, S, N)[:, :T].abs().max().item() == 0.0
+    # grouped: image-like + text-like problem in one launch
+    items, refs = [], []
+    for i, Mi in enumerate((2048, 384)):
+        ai = randn(Mi, K, seed=40 + i).to(BF)
+        bi = randn(N, K, seed=50 + i, scale=0.1).to(BF)
+        bs = randn(N, seed=60 + i).to(BF)
+        o = torch.zeros(Mi, N, dtype=BF, device=DEV)
+        items.append((ai.to(DEV), bi.to(DEV), o, dict(bias=bs.to(DEV))))
+        refs.append(rb(ai.float() @ bi.float().t() + bs.float()))
+    ops.gemm_grouped(items)
+    for i, (it, rf) in enumerate(zip(items, refs)):
+        check(f"gemm_wide_grouped_{i}", it[2], rf, 1e-2)
+
+
 # ------------------------------------------------------------------------------------------ LoRA pieces
 def _split(x):
     hi = x.to(BF)
