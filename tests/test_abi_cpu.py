@@ -73,3 +73,33 @@ def test_lr_schedules_host_logic():
     cos = get_scheduler("cosine", 0, 10)
     assert abs(cos(0) - 1.0) < 1e-12 and abs(cos(5) - 0.5) < 1e-12 and abs(cos(10)) < 1e-12
     assert get_scheduler("constant")(7) == 1.0
+
+
+def test_ctypes_structs_match_the_c_header_layout(tmp_path):
+    """Compile include/qfx.h with gcc and compare sizeof / field offsets of every argument struct with the ctypes mirrors
+    (an ABI drift between the header and qflux_amd/_lib.py would otherwise only show up as wrong results on the GPU)."""
+    import ctypes as C
+    import os
+    import subprocess
+    from qflux_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = {"qfx_gemm_args": L.GemmArgs, "qfx_lora_down_args": L.LoraDownArgs, "qfx_lora_grad_args": L.LoraGradArgs,
+             "qfx_lora_pack_args": L.LoraPackArgs, "qfx_attn_args": L.AttnArgs, "qfx_ln_fwd_args": L.LnFwdArgs, "qfx_ln_bwd_args": L.LnBwdArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "qfx.h"', "int main(void) {"]
+    for cname, ct in pairs.items():
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == len(pairs)
+    for line in out:
+        parts = line.split()
+        ct = pairs[parts[0]]
+        want = [C.sizeof(ct)] + [getattr(ct, f).offset for f, _ in ct._fields_]
+        assert [int(v) for v in parts[1:]] == want, (parts[0], parts[1:], want)
