@@ -9,8 +9,9 @@ the HIP library is missing.
 Pinning status (see DESIGN.md "Oracle"):
   * in-repo half of the reference (block wiring, RoPE tables, complex RoPE,
     modulation order, concat order, gating, model forward) is PINNED: the
-    oracle is checked against the reference's own ``transformer_qwenimage.py``
-    executed in the build container (``tests/golden/make_golden.py``) and the
+    oracle is checked against the reference's own ``transformer_qwenimage.py``,
+    ``transformer_qwen_custom.py``, ``transformer_flux.py``, ``transformer_flux_custom.py`` and its loss classes
+    (``qflux/losses``) executed in the build container (``tests/golden/make_golden.py``, max |diff| = 0.0) and the
     resulting vectors are committed under ``tests/golden/``.
   * third-party half (diffusers primitives, peft LoRA layer) is restated from
     their published semantics (diffusers>=0.36, peft unpinned); neither
