@@ -266,6 +266,31 @@ int qfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float eps, float weight_decay, float bias_corr1, float bias_corr2,
                    const float* gnorm_sq /* may be NULL */, float max_norm, float grad_scale, void* stream);
 
+/* ---- Prodigy, the reference's parameter-free optimizer choice (third party prodigyopt.Prodigy, requirements.txt:33; selected by
+ * configs/face_seg_flux_kontext_fp16_prodigy.yaml:41-47 and the optimizer section of every tests/test_configs/test_example_*.yaml;
+ * instantiated generically at base_trainer.py:884-898, stepped at :531 after clip_gradients :449-455).  One fused step over the
+ * flat fp32 LoRA buffers: EMA update + the two global reductions (<g, p0 - p>, |s|_1) -> on-device update of the distance estimate
+ * d -> parameter update.  The package's Python-float scalars live in `state` (device double[QFX_PRODIGY_STATE]: d, d_max,
+ * d_numerator, d_denom, d_hat, k, then scratch), so nothing synchronises.  lr == 0 is the package's early return (nothing changes,
+ * k does not advance).  beta3 <= 0 means sqrt(beta2).  Coupled weight decay (decouple = 0 with weight_decay != 0) is unsupported. */
+#define QFX_PRODIGY_STATE 12
+typedef struct qfx_prodigy_args {
+  float* p;              /* [n] parameters, updated in place */
+  const float* g;        /* [n] gradient (summed over ranks / micro-steps; scaled by grad_scale and the clip factor on the fly) */
+  float* exp_avg;        /* [n] */
+  float* exp_avg_sq;     /* [n] */
+  float* s;              /* [n] */
+  const float* p0;       /* [n] parameters at the first step() call */
+  int64_t n;
+  double* state;         /* device double[QFX_PRODIGY_STATE], initialised by qfx_prodigy_init_state */
+  float lr, beta1, beta2, beta3, eps, weight_decay, d0, d_coef, growth_rate;
+  int32_t use_bias_correction, safeguard_warmup, decouple;
+  const float* gnorm_sq; /* may be NULL: sum of squares of g (qfx_sumsq) for the global-norm clip */
+  float max_norm, grad_scale;
+} qfx_prodigy_args;
+int qfx_prodigy_init_state(double* state, double d0, void* stream);   /* d = d_max = d_hat = d0, everything else 0; synchronises */
+int qfx_prodigy_step(const qfx_prodigy_args* a, void* stream);
+
 /* ---- debug: lane mapping of ds_read_b64_tr_b16 (64 lanes x 4 bf16 in, same out) ---- */
 int qfx_debug_tr_read(const uint16_t* in, uint16_t* out, void* stream);
 

@@ -16,4 +16,6 @@ Pinning status (see DESIGN.md "Oracle"):
   * third-party half (diffusers primitives, peft LoRA layer) is restated from
     their published semantics (diffusers>=0.36, peft unpinned); neither
     package is installable offline -> for that half: **parity unpinned**.
+  * ``oracle/prodigy.py`` restates the third-party ``prodigyopt.Prodigy`` step (unpinned requirement of the reference, not
+    installable offline): **parity unpinned**; its formulas are pinned by hand-derived identities in ``tests/test_prodigy_cpu.py``.
 """

@@ -500,6 +500,81 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// ---- Prodigy (prodigyopt 1.x, Adam variant) over the flat LoRA buffers: see include/qfx.h.  Host scalars of the package (Python
+// float64: d, d_max, d_numerator, d_denom, k) live in a device double[QFX_PRODIGY_STATE] so the step never synchronises.
+enum { PS_D = 0, PS_DMAX, PS_NUM, PS_DEN, PS_DHAT, PS_K, PS_ACC_NUM, PS_ACC_DEN, PS_DLR, PS_SKIP };
+
+__global__ void prodigy_begin_kernel(double* __restrict__ st, double lr, double b1, double b2, int use_bc) {
+  const double k = st[PS_K];
+  const double bc = use_bc ? sqrt(1.0 - pow(b2, k + 1.0)) / (1.0 - pow(b1, k + 1.0)) : 1.0;
+  st[PS_DLR] = st[PS_D] * lr * bc;
+  st[PS_ACC_NUM] = 0.0;
+  st[PS_ACC_DEN] = 0.0;
+  st[PS_SKIP] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void prodigy_ema_kernel(const float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, float* __restrict__ sv, const float* __restrict__ p0,
+                                                          int64_t n, double* __restrict__ st, float b1, float b2, float b3, double d0,
+                                                          int safeguard, const float* __restrict__ gnorm_sq, float max_norm,
+                                                          float grad_scale) {
+  __shared__ float red[8];
+  float clip = grad_scale;
+  if (gnorm_sq != nullptr && max_norm > 0.f) {
+    const float nrm = sqrtf(*gnorm_sq) * grad_scale;
+    const float c = max_norm / (nrm + 1e-6f);
+    clip *= c < 1.0f ? c : 1.0f;
+  }
+  const double d = st[PS_D], dlr = st[PS_DLR];
+  const float am = (float)(d * (1.0 - (double)b1)), av = (float)(d * d * (1.0 - (double)b2));
+  const float as = (float)(safeguard ? (d / d0) * d : (d / d0) * dlr);
+  float num = 0.f, den = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    num += gi * (p0[i] - p[i]);
+    m[i] = m[i] * b1 + gi * am;
+    v[i] = v[i] * b2 + (av * gi) * gi;
+    const float si = sv[i] * b3 + gi * as;
+    sv[i] = si;
+    den += fabsf(si);
+  }
+  num = wave_sum(num); den = wave_sum(den);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = num; red[4 + (threadIdx.x >> 6)] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&st[PS_ACC_NUM], (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3]);
+    atomicAdd(&st[PS_ACC_DEN], (double)red[4] + (double)red[5] + (double)red[6] + (double)red[7]);
+  }
+}
+
+__global__ void prodigy_d_kernel(double* __restrict__ st, double b3, double d0, double d_coef, double growth) {
+  const double den = st[PS_ACC_DEN];
+  if (den == 0.0) { st[PS_SKIP] = 1.0; return; }   // no progress: the package returns before storing anything
+  double d = st[PS_D];
+  const double num = st[PS_NUM] * b3 + (d / d0) * st[PS_DLR] * st[PS_ACC_NUM];
+  const double d_hat = d_coef * num / den;
+  if (d == d0) d = d > d_hat ? d : d_hat;
+  double d_max = st[PS_DMAX];
+  d_max = d_max > d_hat ? d_max : d_hat;
+  const double dg = d * growth;
+  d = d_max < dg ? d_max : dg;
+  st[PS_NUM] = num; st[PS_DEN] = den; st[PS_D] = d; st[PS_DMAX] = d_max; st[PS_DHAT] = d_hat;
+  st[PS_K] += 1.0;
+}
+
+__global__ __launch_bounds__(256) void prodigy_apply_kernel(float* __restrict__ p, const float* __restrict__ m, const float* __restrict__ v,
+                                                            int64_t n, const double* __restrict__ st, float eps, float wd) {
+  if (st[PS_SKIP] != 0.0) return;
+  const double dlr = st[PS_DLR];
+  const float deps = (float)(st[PS_D] * (double)eps);
+  const float adec = (float)(-(double)wd * dlr), astep = (float)(-dlr);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    if (wd != 0.f) pi = pi + pi * adec;
+    p[i] = pi + astep * (m[i] / (sqrtf(v[i]) + deps));
+  }
+}
+
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __restrict__ t, int B, int dim, float scale,
                                                              float pre_scale, bf16_t* __restrict__ out) {
   const int half = dim / 2;
@@ -761,6 +836,36 @@ extern "C" int qfx_adamw_step(float* p, const float* g, float* m, float* v, int6
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, bias_corr1, bias_corr2, gnorm_sq, max_norm, grad_scale);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_prodigy_init_state(double* state, double d0, void* stream) {
+  if (!state || !(d0 > 0.0)) return QFX_EINVAL;
+  double h[QFX_PRODIGY_STATE] = {0};
+  h[PS_D] = d0; h[PS_DMAX] = d0; h[PS_DHAT] = d0;
+  if (hipMemcpyAsync(state, h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return QFX_EINVAL;
+  return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? QFX_OK : QFX_EINVAL;   // h is a stack buffer
+}
+
+extern "C" int qfx_prodigy_step(const qfx_prodigy_args* a, void* stream) {
+  if (!a || !a->p || !a->g || !a->exp_avg || !a->exp_avg_sq || !a->s || !a->p0 || !a->state || a->n <= 0) return QFX_EINVAL;
+  if (!(a->beta1 > 0.f) || !(a->d0 > 0.f) || a->lr < 0.f) return QFX_EINVAL;
+  if (a->weight_decay != 0.f && !a->decouple) return QFX_EUNSUPPORTED;   // coupled decay: not used by any reference config
+  if (a->lr == 0.f) return QFX_OK;   // warm-up step 0: the package creates its state and returns; k does not advance
+  hipStream_t s = (hipStream_t)stream;
+  const double b3 = a->beta3 > 0.f ? (double)a->beta3 : sqrt((double)a->beta2);
+  int blocks = (int)((a->n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(prodigy_begin_kernel, dim3(1), dim3(1), 0, s, a->state, (double)a->lr, (double)a->beta1, (double)a->beta2,
+                     a->use_bias_correction);
+  hipLaunchKernelGGL(prodigy_ema_kernel, dim3(blocks), dim3(256), 0, s, a->p, a->g, a->exp_avg, a->exp_avg_sq, a->s, a->p0, a->n,
+                     a->state, a->beta1, a->beta2, (float)b3, (double)a->d0, a->safeguard_warmup, a->gnorm_sq, a->max_norm,
+                     a->grad_scale);
+  hipLaunchKernelGGL(prodigy_d_kernel, dim3(1), dim3(1), 0, s, a->state, b3, (double)a->d0, (double)a->d_coef,
+                     (double)a->growth_rate);
+  hipLaunchKernelGGL(prodigy_apply_kernel, dim3(blocks), dim3(256), 0, s, a->p, a->exp_avg, a->exp_avg_sq, a->n, a->state, a->eps,
+                     a->weight_decay);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -73,6 +73,18 @@ class LoraPackArgs(C.Structure):
     ]
 
 
+class ProdigyArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("s", C.c_void_p),
+                ("p0", C.c_void_p), ("n", C.c_int64), ("state", C.c_void_p),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("beta3", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("d0", C.c_float), ("d_coef", C.c_float), ("growth_rate", C.c_float),
+                ("use_bias_correction", C.c_int32), ("safeguard_warmup", C.c_int32), ("decouple", C.c_int32),
+                ("gnorm_sq", C.c_void_p), ("max_norm", C.c_float), ("grad_scale", C.c_float)]
+
+
+PRODIGY_STATE = 12
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64),
@@ -121,6 +133,8 @@ SYMBOLS = {
     "qfx_flowmatch_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "qfx_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
     "qfx_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _vp]),
+    "qfx_prodigy_init_state": (C.c_int, [_vp, C.c_double, _vp]),
+    "qfx_prodigy_step": (C.c_int, [C.POINTER(ProdigyArgs), _vp]),
     "qfx_debug_tr_read": (C.c_int, [_vp, _vp, _vp]),
     "qfx_abi_version": (C.c_int, []),
     "qfx_build_arch": (C.c_char_p, []),

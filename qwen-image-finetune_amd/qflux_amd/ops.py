@@ -237,6 +237,20 @@ def sumsq(g, out):
     L.check(lib.qfx_sumsq(_p(g), g.numel(), _p(out), stream_ptr()), "qfx_sumsq")
 
 
+def prodigy_init_state(state, d0=1e-6):
+    """state: fp64[PRODIGY_STATE] device tensor (d, d_max, d_numerator, d_denom, d_hat, k, scratch...)."""
+    L.check(lib.qfx_prodigy_init_state(_p(state), float(d0), stream_ptr()), "qfx_prodigy_init_state")
+
+
+def prodigy_step(p, g, exp_avg, exp_avg_sq, s, p0, state, lr=1.0, betas=(0.9, 0.999), beta3=None, eps=1e-8, weight_decay=0.0,
+                 decouple=True, use_bias_correction=False, safeguard_warmup=False, d0=1e-6, d_coef=1.0, growth_rate=float("inf"),
+                 gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    a = L.ProdigyArgs(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), _p(s), _p(p0), p.numel(), _p(state), lr, betas[0], betas[1],
+                      0.0 if beta3 is None else beta3, eps, weight_decay, d0, d_coef, growth_rate, int(use_bias_correction),
+                      int(safeguard_warmup), int(decouple), _p(gnorm_sq), max_norm, grad_scale)
+    L.check(lib.qfx_prodigy_step(a, stream_ptr()), "qfx_prodigy_step")
+
+
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
+from .._lib import PRODIGY_STATE as L_PRODIGY_STATE
 
 BF = torch.bfloat16
 
@@ -47,11 +48,25 @@ def map_mask_to_latent(image_mask: torch.Tensor) -> torch.Tensor:
 class QwenLoraTrainStep:
     def __init__(self, dit, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
                  weight_dtype=BF, process_group=None, criterion="mse", forground_weight=2.0, background_weight=1.0,
-                 bucket_mb=24.0):
-        """criterion: "mse" = MseLoss (losses/mse_loss.py:46-83); "mask_edit" = MaskEditLoss(forground_weight,
+                 bucket_mb=24.0, optimizer="adamw", optimizer_args=None):
+        """optimizer: "adamw" (torch.optim.AdamW semantics, lr/betas/eps/weight_decay above) or "prodigy" (prodigyopt.Prodigy, the
+        reference's parameter-free choice: configs/face_seg_flux_kontext_fp16_prodigy.yaml:41-47); optimizer_args = the extra
+        init_args of that class (use_bias_correction, safeguard_warmup, beta3, decouple, d0, d_coef, growth_rate).  With Prodigy
+        `lr` is the schedule multiplier the reference sets to 1.0.
+        criterion: "mse" = MseLoss (losses/mse_loss.py:46-83); "mask_edit" = MaskEditLoss(forground_weight,
         background_weight) (losses/edit_mask_loss.py:39-90), fed by embeddings["edit_mask"] [B,S_t] (all-ones when absent)."""
         if criterion not in ("mse", "mask_edit"):
             raise ValueError(f"unknown criterion {criterion!r}")
+        if optimizer not in ("adamw", "prodigy"):
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        self.optimizer = optimizer
+        self.optimizer_args = dict(beta3=None, decouple=True, use_bias_correction=False, safeguard_warmup=False, d0=1e-6,
+                                   d_coef=1.0, growth_rate=float("inf"))
+        unknown = set(optimizer_args or {}) - set(self.optimizer_args)
+        if unknown or (optimizer_args and optimizer != "prodigy"):
+            raise ValueError(f"unsupported optimizer_args for {optimizer}: {sorted(unknown) or sorted(optimizer_args)}")
+        self.optimizer_args.update(optimizer_args or {})
+        self._ps = self._p0 = self._pstate = None
         self.criterion, self.fg, self.bg = criterion, float(forground_weight), float(background_weight)
         self.dit = dit
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -184,6 +199,16 @@ class QwenLoraTrainStep:
         self.global_step += 1
         self._gnorm.zero_()
         ops.sumsq(st.gflat, self._gnorm)
+        if self.optimizer == "prodigy":
+            if self._pstate is None or self._ps.numel() != st.pflat.numel():
+                self._ps = torch.zeros_like(st.pflat)
+                self._p0 = st.pflat.detach().clone()     # parameters at the first step() call
+                self._pstate = torch.zeros(L_PRODIGY_STATE, dtype=torch.float64, device=st.pflat.device)
+                ops.prodigy_init_state(self._pstate, self.optimizer_args["d0"])
+            ops.prodigy_step(st.pflat, st.gflat, self._m, self._v, self._ps, self._p0, self._pstate, lr=self.lr, betas=self.betas,
+                             eps=self.eps, weight_decay=self.weight_decay, gnorm_sq=self._gnorm, max_norm=self.max_grad_norm,
+                             grad_scale=grad_scale, **self.optimizer_args)
+            return
         ops.adamw_step(st.pflat, st.gflat, self._m, self._v, self.lr, self.betas[0], self.betas[1], self.eps,
                        self.weight_decay, self.global_step, gnorm_sq=self._gnorm, max_norm=self.max_grad_norm,
                        grad_scale=grad_scale)
@@ -197,6 +222,8 @@ class QwenLoraTrainStep:
         per LoRA parameter in named_parameters() order (what accelerate's optimizer.bin holds for the reference)."""
         st = self.dit.lora_store
         state = {}
+        if self.optimizer == "prodigy":
+            return self._prodigy_state_dict()
         for i, (_, p, off, k) in enumerate(st.entries):
             if self._m is None:
                 break
@@ -206,7 +233,54 @@ class QwenLoraTrainStep:
                  "params": list(range(len(st.entries)))}
         return {"state": state, "param_groups": [group], "global_step": self.global_step}
 
+    _PS_KEYS = ("d", "d_max", "d_numerator", "d_denom", "d_hat", "k")
+
+    def _prodigy_state_dict(self):
+        """prodigyopt layout: per-parameter {"step","s","p0","exp_avg","exp_avg_sq"}; the group carries d, d_max, d_numerator,
+        d_denom, d_hat, k next to the init_args."""
+        st = self.dit.lora_store
+        state = {}
+        group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, **self.optimizer_args)
+        d0 = self.optimizer_args["d0"]
+        group.update(d=d0, d_max=d0, d_numerator=0.0, d_denom=0.0, d_hat=d0, k=0)
+        if self._pstate is not None:
+            vals = self._pstate.cpu().tolist()
+            group.update({n: vals[i] for i, n in enumerate(self._PS_KEYS)})
+            group["k"] = int(group["k"])
+            for i, (_, p, off, k) in enumerate(st.entries):
+                state[i] = {"step": group["k"], "s": self._ps[off:off + k].detach().cpu().clone(),
+                            "p0": self._p0[off:off + k].detach().cpu().clone(),
+                            "exp_avg": self._m[off:off + k].view(p.shape).detach().cpu().clone(),
+                            "exp_avg_sq": self._v[off:off + k].view(p.shape).detach().cpu().clone()}
+        group["params"] = list(range(len(st.entries)))
+        return {"state": state, "param_groups": [group], "global_step": self.global_step}
+
+    def _load_prodigy_state_dict(self, sd):
+        st = self.dit.lora_store
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        for n in self.optimizer_args:
+            if n in g:
+                self.optimizer_args[n] = g[n]
+        self.global_step = int(sd.get("global_step", g.get("k", 0)))
+        self._gnorm = torch.zeros((), dtype=torch.float32, device=st.pflat.device)
+        if not sd["state"]:
+            self._pstate = None
+            return
+        self._m = torch.zeros_like(st.pflat); self._v = torch.zeros_like(st.pflat)
+        self._ps = torch.zeros_like(st.pflat); self._p0 = torch.zeros_like(st.pflat)
+        for i, (_, p, off, k) in enumerate(st.entries):
+            e = sd["state"][i]
+            self._m[off:off + k].copy_(e["exp_avg"].reshape(-1)); self._v[off:off + k].copy_(e["exp_avg_sq"].reshape(-1))
+            self._ps[off:off + k].copy_(e["s"].reshape(-1))
+            if e["p0"].numel() == k:            # the package stores a 0-dim zero for an all-zero parameter
+                self._p0[off:off + k].copy_(e["p0"].reshape(-1))
+        vals = [float(g[n]) for n in self._PS_KEYS] + [0.0] * (L_PRODIGY_STATE - len(self._PS_KEYS))
+        self._pstate = torch.tensor(vals, dtype=torch.float64).to(st.pflat.device)
+
     def load_state_dict(self, sd):
+        if self.optimizer == "prodigy":
+            return self._load_prodigy_state_dict(sd)
         st = self.dit.lora_store
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
