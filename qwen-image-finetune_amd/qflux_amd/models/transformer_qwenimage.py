@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..modules import (LoraConfig, LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm, init_lora_, match_target)
-from ..rope import normalize_img_shapes, qwen_joint_rope
+from ..rope import QwenEmbedRope, normalize_img_shapes, qwen_joint_rope
 
 lib = L.lib
 BF = torch.bfloat16
@@ -98,9 +98,10 @@ class _LoraW:
 
 
 class _LinW:
-    __slots__ = ("W", "b", "WT", "lora", "N", "K")
+    __slots__ = ("W", "b", "WT", "lora", "N", "K", "mod")
 
     def __init__(self, mod, need_T: bool):
+        self.mod = mod
         base = mod.base_layer if isinstance(mod, QfxLoraLinear) else mod
         self.W = base.weight.data
         assert self.W.is_contiguous() and self.W.dtype == BF
@@ -167,6 +168,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self.out_channels = out_channels or in_channels
         self.inner_dim = num_attention_heads * attention_head_dim
         D = self.inner_dim
+        self.pos_embed = QwenEmbedRope(theta=10000, axes_dim=list(axes_dims_rope), scale_rope=True)   # :546 (no parameters)
         self.time_text_embed = _TimeTextEmbed(D)
         self.txt_norm = QfxRMSNorm(joint_attention_dim, eps=1e-6)
         self.img_in = QfxLinear(in_channels, D)
@@ -220,8 +222,9 @@ class QwenImageTransformer2DModel(nn.Module):
         for n in names:
             if not self._lora_supported(n):
                 raise NotImplementedError(
-                    f"LoRA target '{n}': round-1 fused path covers the attention projections (to_q/to_k/to_v/to_out.0/add_*_proj/"
-                    f"to_add_out); MLP / modulation / embedder targets are next (DESIGN.md)")
+                    f"LoRA target '{n}': the fused path covers the attention projections (to_q/to_k/to_v/to_out.0/add_*_proj/"
+                    f"to_add_out) and the feed-forward linears (net.0.proj / net.2) of the double-stream blocks; modulation / "
+                    f"embedder targets are not built (DESIGN.md)")
         for n in names:
             parent_name, _, child = n.rpartition(".")
             parent = self.get_submodule(parent_name)
@@ -239,13 +242,29 @@ class QwenImageTransformer2DModel(nn.Module):
         return names
 
     _LORA_SUFFIXES = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj", "attn.add_k_proj",
-                      "attn.add_v_proj", "attn.to_add_out")
+                      "attn.add_v_proj", "attn.to_add_out",
+                      "img_mlp.net.0.proj", "img_mlp.net.2", "txt_mlp.net.0.proj", "txt_mlp.net.2",      # Qwen feed-forwards
+                      "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2")           # FLUX double blocks
 
     def _lora_supported(self, name: str) -> bool:
         return name.startswith("transformer_blocks.") and name.endswith(self._LORA_SUFFIXES)
 
     def set_adapter(self, adapter_name):
         self._adapter_name = adapter_name
+
+    def merge_adapter(self):
+        """PeftAdapterMixin.merge_adapter as BaseTrainer.merge_lora calls it (base_trainer.py:413-416): fold every adapter into its
+        base weight; the LoRA segment of the GEMMs then carries a zero scale (forward == merged base layer alone)."""
+        for m in self.modules():
+            if isinstance(m, QfxLoraLinear):
+                m.merge()
+        self._invalidate()
+
+    def unmerge_adapter(self):
+        for m in self.modules():
+            if isinstance(m, QfxLoraLinear):
+                m.unmerge()
+        self._invalidate()
 
     def save_lora_weights(self, save_folder, style="diffusers"):
         """pytorch_lora_weights.safetensors as BaseTrainer.save_lora writes it (base_trainer.py:858-875)."""
@@ -366,7 +385,8 @@ class QwenImageTransformer2DModel(nn.Module):
         md = 1
         for s, names in (("img", ("to_q", "to_k", "to_v")), ("txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
             md = max(md, self._prep_qkv_lora(w, s + ".", [getattr(a, n) for n in names], descs))
-        for key, m in (("img.o", a.to_out[0]), ("txt.o", a.to_add_out)):
+        for key in ("img.o", "txt.o", "img.fc1", "img.fc2", "txt.fc1", "txt.fc2"):
+            m = w[key].mod
             if isinstance(m, QfxLoraLinear):
                 r = m.r[m.active_adapter]
                 Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
@@ -398,7 +418,8 @@ class QwenImageTransformer2DModel(nn.Module):
     def _pack_desc(lo: _LoraW):
         d = L.LoraPackArgs()
         m = lo.mod
-        d.A, d.B, d.r, d.K, d.N, d.scale = m.A.data_ptr(), m.B.data_ptr(), lo.r, m.in_features, m.out_features, lo.scale
+        d.A, d.B, d.r, d.K, d.N = m.A.data_ptr(), m.B.data_ptr(), lo.r, m.in_features, m.out_features
+        d.scale = 0.0 if m.merged else lo.scale      # merged adapter: the base weight already holds scale * B A
         d.A_hi, d.A_lo, d.ld_a = lo.A_hi.data_ptr(), lo.A_lo.data_ptr(), lo.A_hi.stride(0)
         d.Bt_hi, d.Bt_lo, d.ld_bt = lo.Bt_hi.data_ptr(), lo.Bt_lo.data_ptr(), lo.Bt_hi.stride(0)
         d.We, d.ld_we = lo.We.data_ptr(), lo.We.stride(0)
@@ -554,6 +575,15 @@ class _QwenPlan:
             if w[s + ".o"].lora is not None:
                 rp_o = w[s + ".o"].lora.Rp
                 b["Uo." + s] = (buf(rp_o, mp, zero=True), buf(rp_o, mp, zero=True))
+            # feed-forward adapters: their inputs (LN2 output / GELU output) are scratch otherwise and must be kept for dA
+            if w[s + ".fc1"].lora is not None:
+                rp = w[s + ".fc1"].lora.Rp
+                b["xm2." + s] = buf(rows[s], D)
+                b["Uf1." + s] = (buf(rp, mp, zero=True), buf(rp, mp, zero=True))
+            if w[s + ".fc2"].lora is not None:
+                rp = w[s + ".fc2"].lora.Rp
+                b["g." + s] = buf(rows[s], 4 * D)
+                b["Uf2." + s] = (buf(rp, mp, zero=True), buf(rp, mp, zero=True))
         return b
 
     def _alloc_double_scratch(self, blocks):
@@ -567,14 +597,16 @@ class _QwenPlan:
             for s in ("img", "txt"):
                 if w[s + ".qkv_lora"] is not None:
                     kext_max = max(kext_max, w[s + ".qkv_lora"]["Kext"]); rp_max = max(rp_max, w[s + ".qkv_lora"]["Rp"])
-                if w[s + ".o"].lora is not None:
-                    kext_max = max(kext_max, w[s + ".o"].lora.Kext); rp_max = max(rp_max, w[s + ".o"].lora.Rp)
+                for key in (".o", ".fc1", ".fc2"):
+                    if w[s + key].lora is not None:
+                        kext_max = max(kext_max, w[s + key].lora.Kext); rp_max = max(rp_max, w[s + key].lora.Rp)
         self.has_lora = kext_max > 0
         if self.has_lora:
             A["ext3"] = {s: buf(rows[s], 3 * kext_max, zero=True) for s in ("img", "txt")}
             A["ext1"] = {s: buf(rows[s], kext_max, zero=True) for s in ("img", "txt")}
-            A["VtO"] = {s: (buf(rp_max, _ceil(rows[s], 128), zero=True), buf(rp_max, _ceil(rows[s], 128), zero=True))
-                        for s in ("img", "txt")}
+            for name in ("VtO", "VtF1", "VtF2"):   # one v^T scratch per adapter site: the deferred dA launches read them at block end
+                A[name] = {s: (buf(rp_max, _ceil(rows[s], 128), zero=True), buf(rp_max, _ceil(rows[s], 128), zero=True))
+                           for s in ("img", "txt")}
             A["Vt"] = {s: (buf(3 * rp_max, _ceil(rows[s], 128), zero=True), buf(3 * rp_max, _ceil(rows[s], 128), zero=True))
                        for s in ("img", "txt")}   # v^T hi/lo scratch (pad columns stay zero)
         A["dX"] = {s: [buf(rows[s], D), buf(rows[s], D)] for s in ("img", "txt")}
@@ -816,21 +848,35 @@ class _QwenPlan:
                                           rpb=rpb[s], a_map=(S, off[s]), **kw))
             self._gemm_group(p, groups)
             groups = []
-            lnl = [self._ln_fwd_args(bb["x1"][s], mods[s][:, 3 * D:4 * D], mods[s][:, 4 * D:5 * D], 6 * D, A["xm"][s], rows[s], D, rpb[s], eps)
+            # feed-forward (+ LoRA on net.0.proj / net.2: the adapter's input is then kept per block instead of in scratch)
+            xm2 = {s: (bb["xm2." + s] if w[s + ".fc1"].lora is not None else A["xm"][s]) for s, _ in live}
+            gact = {s: (bb["g." + s] if w[s + ".fc2"].lora is not None else A["g"][s]) for s, _ in live}
+            lnl = [self._ln_fwd_args(bb["x1"][s], mods[s][:, 3 * D:4 * D], mods[s][:, 4 * D:5 * D], 6 * D, xm2[s], rows[s], D, rpb[s], eps)
                    for s, sidx in live]
             self._flush_ln(p, lnl, L.LnFwdArgs, lib.qfx_ln_modulate_fwd_batch)
+
+            def lora_ext(s, lw, X, ldx, ukey):
+                """Down-projection of a single adapted linear; returns the K-extension arguments of its GEMM."""
+                if lw.lora is None:
+                    return {}
+                lo, e1 = lw.lora, A["ext1"][s]
+                self._down(p, X=X, ldx=ldx, M=rows[s], K=lw.K, W_hi=lo.A_hi, W_lo=lo.A_lo, ldw=lo.A_hi.stride(0), R=lo.Rp,
+                           Ut=bb[ukey + s], ext=e1, ld_ext=e1.stride(0))
+                return dict(A2=e1, lda2=e1.stride(0), B2=lo.We, ldb2=lo.We.stride(0), K2=lo.Kext)
+
             for s, sidx in live:
-                mod = mods[s]
                 f1 = w[s + ".fc1"]
-                groups.append(self._gargs(A1=A["xm"][s], lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D,
-                                          bias=f1.b, epi=L.EPI_GELU, C2=A["g"][s], ldc2=4 * D))
+                kw = lora_ext(s, f1, xm2[s], D, "Uf1.")
+                groups.append(self._gargs(A1=xm2[s], lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D,
+                                          bias=f1.b, epi=L.EPI_GELU, C2=gact[s], ldc2=4 * D, **kw))
             self._gemm_group(p, groups)
             groups = []
             for s, sidx in live:
                 f2 = w[s + ".fc2"]
-                groups.append(self._gargs(A1=A["g"][s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
+                kw = lora_ext(s, f2, gact[s], 4 * D, "Uf2.")
+                groups.append(self._gargs(A1=gact[s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
                                           bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
-                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1, row_mask=self.rmask[s]))
+                                          gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1, row_mask=self.rmask[s], **kw))
             self._gemm_group(p, groups)
 
     # ------------------------------------------------------------------ backward program
@@ -873,7 +919,8 @@ class _QwenPlan:
         STREAMS = (("img", 0), ("txt", 1))
         i = 0 if first else 1
         # LoRA weight gradients are leaves: every qfx_lora_grad of the block is deferred to ONE batched launch per rank at the
-        # end of the block (their X operands -- dyg1, ao, dqkv, xm1 -- stay intact until the next block's backward starts)
+        # end of the block (their X operands -- dyg1, ao, dqkv, xm1, dh, the kept feed-forward inputs -- stay intact until the next block's backward
+        # starts; the one exception, dyg2, is flushed early)
         gl = []
         if True:
             ao2 = bb["ao"].view(B * S, D)
@@ -882,10 +929,36 @@ class _QwenPlan:
                 # no gradient reaches the last block's text tail: d(attn out) of the text rows is zero
                 p.py(A["dao"][:, :T].zero_)
             # ---- MLP backward: dh = (gate2*dx2) W2 * gelu'(h) ; dxm2 = dh W1   (both streams per launch)
-            self._gemm_group(p, [self._gargs(A1=A["dyg2"][s], lda1=D, B1=w[s + ".fc2"].WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s],
-                                             ldc=4 * D, epi=L.EPI_DGELU, aux=bb["h"][s], ldaux=4 * D) for s, _ in live])
-            self._gemm_group(p, [self._gargs(A1=A["dh"][s], lda1=4 * D, B1=w[s + ".fc1"].WT, K1=4 * D, M=rows[s], N=D,
-                                             C_=A["dxm"][s], ldc=D) for s, _ in live])
+            ge = []   # gradients whose X operand (dyg2) is overwritten before the end of the block: flushed right after the MLP
+
+            def lora_bwd(s, lw, dY, ldy, Xin, ldxin, ukey, vkey, early):
+                """dY -> v = dY B (K-extension of the dX GEMM) + the two deferred weight-gradient problems of an adapted linear."""
+                if lw.lora is None:
+                    return {}
+                lo, e1 = lw.lora, A["ext1"][s]
+                Vt = (A[vkey][s][0][:lo.Rp], A[vkey][s][1][:lo.Rp])
+                self._down(p, X=dY, ldx=ldy, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp,
+                           Ut=Vt, ext=e1, ld_ext=e1.stride(0))
+                self._grad(p, Vt=bb[ukey + s], R=lo.Rp, r_valid=lo.r, X=dY, ldx=ldy, M=rows[s], K=lw.N, G=lo.gB, g_sr=1, g_sc=lo.r,
+                           out_scale=lo.scale, defer=ge if early else gl)
+                self._grad(p, Vt=Vt, R=lo.Rp, r_valid=lo.r, X=Xin, ldx=ldxin, M=rows[s], K=lw.K, G=lo.gA, g_sr=lw.K, g_sc=1, defer=gl)
+                return dict(A2=e1, lda2=e1.stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
+
+            groups = []
+            for s, _ in live:
+                f2 = w[s + ".fc2"]
+                kw = lora_bwd(s, f2, A["dyg2"][s], D, bb.get("g." + s), 4 * D, "Uf2.", "VtF2", early=True)
+                groups.append(self._gargs(A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s],
+                                          ldc=4 * D, epi=L.EPI_DGELU, aux=bb["h"][s], ldaux=4 * D, **kw))
+            self._gemm_group(p, groups)
+            groups = []
+            for s, _ in live:
+                f1 = w[s + ".fc1"]
+                kw = lora_bwd(s, f1, A["dh"][s], 4 * D, bb.get("xm2." + s), D, "Uf1.", "VtF1", early=False)
+                groups.append(self._gargs(A1=A["dh"][s], lda1=4 * D, B1=f1.WT, K1=4 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D, **kw))
+            self._gemm_group(p, groups)
+            if ge:
+                self._flush_batch(p, ge, L.LoraGradArgs, lib.qfx_lora_grad_batch)
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
                                      A["dx1"][s], A["dyg1"][s], rows[s], D, rpb[s], eps, None) for s, sidx in live]

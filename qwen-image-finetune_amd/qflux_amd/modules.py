@@ -56,6 +56,7 @@ class QfxLoraLinear(nn.Module):
         self.lora_alpha = {adapter_name: lora_alpha}
         self.scaling = {adapter_name: float(lora_alpha) / float(r)}
         self.active_adapter = adapter_name
+        self.merged = False
         dev = base.weight.device
         self.lora_A = nn.ModuleDict({adapter_name: _W(torch.zeros(r, base.in_features, dtype=torch.float32, device=dev), True)})
         self.lora_B = nn.ModuleDict({adapter_name: _W(torch.zeros(base.out_features, r, dtype=torch.float32, device=dev), True)})
@@ -67,6 +68,22 @@ class QfxLoraLinear(nn.Module):
     @property
     def B(self) -> nn.Parameter:
         return self.lora_B[self.active_adapter].weight
+
+    def get_delta_weight(self) -> torch.Tensor:
+        """peft lora.Linear.get_delta_weight: (B @ A) * scaling in the adapter dtype (fp32)."""
+        return (self.B.detach() @ self.A.detach()) * self.scaling[self.active_adapter]
+
+    def merge(self):
+        """peft LoraLayer.merge (safe_merge=False): `base_layer.weight.data += delta` -- an fp32 delta added in place to the bf16
+        weight (computed in fp32, rounded once); afterwards the forward is the base layer alone."""
+        if not self.merged:
+            self.base_layer.weight.data += self.get_delta_weight().to(self.base_layer.weight.device)
+            self.merged = True
+
+    def unmerge(self):
+        if self.merged:
+            self.base_layer.weight.data -= self.get_delta_weight().to(self.base_layer.weight.device)
+            self.merged = False
 
     def forward(self, *a, **k):
         raise RuntimeError("QfxLoraLinear is a parameter holder")

@@ -46,3 +46,27 @@ def normalize_img_shapes(img_shapes) -> tuple:
     if isinstance(s, (list, tuple)) and len(s) == 3 and all(isinstance(v, int) for v in s):
         s = [s]
     return tuple(tuple(int(v) for v in fhw) for fhw in s)
+
+
+class QwenEmbedRope:
+    """Call-compatible stand-in for the module the reference keeps at `dit.pos_embed` (transformer_qwenimage.py:159-254; called as
+    `self.dit.pos_embed([img_shapes[b]], [txt_seq_lens[b]], device=device)` at qwen_image_edit_trainer.py:734): returns
+    (vid_freqs [S_i, sum(axes)/2] complex64, txt_freqs [max(txt_seq_lens), ...] complex64).  Holds no parameters or buffers, like the
+    reference's (its tables are plain attributes, so the state dict has no pos_embed keys).  Host-side table construction; the
+    kernels consume the same table through qwen_joint_rope()."""
+
+    def __init__(self, theta: int, axes_dim, scale_rope: bool = True):
+        if not scale_rope:
+            raise NotImplementedError("scale_rope=False is not used by the reference model (transformer_qwenimage.py:549)")
+        self.theta, self.axes_dim, self.scale_rope = theta, tuple(axes_dim), scale_rope
+
+    def __call__(self, video_fhw, txt_seq_lens, device=None):
+        shapes = normalize_img_shapes(video_fhw)          # only the first sample's list is used (:206-207)
+        T = int(max(txt_seq_lens))
+        joint = torch.view_as_complex(qwen_joint_rope(shapes, T, self.axes_dim, float(self.theta)))
+        txt, vid = joint[:T].contiguous(), joint[T:].contiguous()
+        if device is not None:
+            txt, vid = txt.to(device), vid.to(device)
+        return vid, txt
+
+    forward = __call__

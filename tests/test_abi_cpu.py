@@ -104,3 +104,18 @@ def test_ctypes_structs_match_the_c_header_layout(tmp_path):
         ct = pairs[parts[0]]
         want = [C.sizeof(ct)] + [getattr(ct, f).offset for f, _ in ct._fields_]
         assert [int(v) for v in parts[1:]] == want, (parts[0], parts[1:], want)
+
+
+def test_pos_embed_stand_in_matches_pinned_tables():
+    """dit.pos_embed(video_fhw, txt_seq_lens, device) (qwen_image_edit_trainer.py:734) vs the oracle tables that are pinned against the
+    reference's QwenEmbedRope; the holder adds no state-dict keys (the reference's tables are plain attributes)."""
+    import torch
+    from oracle.qwen_dit import qwen_rope_tables
+    from qflux_amd.rope import QwenEmbedRope
+    pe = QwenEmbedRope(theta=10000, axes_dim=[8, 28, 28], scale_rope=True)
+    for shapes, lens in ((((1, 4, 6), (1, 4, 6)), [5, 3]), (((1, 6, 4), (1, 8, 8), (1, 2, 10)), [9]), (((1, 3, 5),), [1, 7])):
+        vid, txt = pe([[list(s) for s in shapes]], lens, device=torch.device("cpu"))
+        v0, t0 = qwen_rope_tables(shapes, max(lens), (8, 28, 28))
+        assert vid.dtype == torch.complex64 and vid.shape == v0.shape and txt.shape == t0.shape
+        assert torch.equal(vid, v0) and torch.equal(txt, t0)
+    assert not [k for k in vars(pe) if isinstance(getattr(pe, k), torch.Tensor)]

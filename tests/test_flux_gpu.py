@@ -24,6 +24,15 @@ def test_flux_both_stream_lora_b1_odd_sizes():
     assert res["ok"], res
 
 
+def test_flux_feed_forward_lora_targets():
+    """FLUX double blocks with adapters on ff / ff_context (part of the reference's broad regex config,
+    configs/face_seg_flux_kontext_fp16.yaml:11) next to attention adapters on double and single blocks."""
+    res = run_flux_step_parity(DEV, verbose=True, hw=(6, 4), T=9, B=2, r=8,
+                               targets=("to_q", "to_v", "to_out.0", "to_add_out", "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj",
+                                        "ff_context.net.2"))
+    assert res["ok"], res
+
+
 def test_flux_head_dim_128():
     cfg = dict(patch_size=1, in_channels=64, out_channels=64, num_layers=1, num_single_layers=2, attention_head_dim=128,
                num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=32, guidance_embeds=True, axes_dims_rope=(16, 56, 56))

@@ -1,6 +1,7 @@
 """CPU: LoRA injection naming (peft look-alike) and checkpoint round trip in the reference's two key styles."""
 import os
 
+import pytest
 import torch
 from safetensors.torch import load_file
 
@@ -28,17 +29,18 @@ def test_adapter_names_and_trainable_filter():
     names = f.add_adapter(LoraConfig(r=8, lora_alpha=8, target_modules=".*attn[.]to_[qkv]"), "a")
     assert len(names) == 3 * (FLUX_TINY["num_layers"] + FLUX_TINY["num_single_layers"])
     try:
-        q.add_adapter(LoraConfig(r=4, target_modules=["img_mlp.net.2"]), "b")
+        q.add_adapter(LoraConfig(r=4, target_modules=["img_mod.1"]), "b")   # modulation linears are not built
         raise AssertionError("expected NotImplementedError for an unsupported target")
     except NotImplementedError:
         pass
 
 
-def test_lora_checkpoint_roundtrip_both_styles(tmp_path):
+@pytest.mark.parametrize("targets", [("to_k", "to_q", "to_v", "to_out.0"), ("to_k", "to_q", "to_v", "to_out.0", "net.0.proj", "net.2")])
+def test_lora_checkpoint_roundtrip_both_styles(tmp_path, targets):
     from qflux_amd.lora_io import classify_lora_keys
     from qflux_amd.modules import LoraConfig
     q, _ = _models()
-    q.add_adapter(LoraConfig(r=4, lora_alpha=8), "lora_edit", generator=torch.Generator().manual_seed(0))
+    q.add_adapter(LoraConfig(r=4, lora_alpha=8, target_modules=list(targets)), "lora_edit", generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
         for n, p in q.named_parameters():
             if "lora_B" in n:
@@ -53,7 +55,10 @@ def test_lora_checkpoint_roundtrip_both_styles(tmp_path):
             assert "transformer.transformer_blocks.1.attn.to_k.lora.down.weight" in keys   # docs/guide/lora.md:171-180
         q2, _ = _models()
         loaded = q2.load_lora_adapter(str(tmp_path / style), adapter_name="lora_edit", lora_alpha=8)
-        assert len(loaded) == 8
+        assert len(loaded) == 2 * len(targets) + (4 if len(targets) > 4 else 0)    # 2 blocks; net.* matches both streams
+        if len(targets) > 4 and style == "diffusers":
+            assert "transformer.transformer_blocks.0.img_mlp.net.0.proj.lora.down.weight" in keys
+            assert "transformer.transformer_blocks.1.txt_mlp.net.2.lora.up.weight" in keys
         got = {n: p for n, p in q2.named_parameters() if "lora" in n}
         assert set(got) == set(ref)
         for n in ref:

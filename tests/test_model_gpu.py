@@ -41,6 +41,18 @@ def test_three_image_rope_and_text_stream_lora():
     assert res["ok"], res
 
 
+@pytest.mark.parametrize("targets", [
+    ("to_k", "to_q", "to_v", "to_out.0", "img_mlp.net.0.proj", "img_mlp.net.2", "txt_mlp.net.0.proj", "txt_mlp.net.2"),
+    ("net.0.proj", "net.2"),                                   # feed-forwards only (no attention adapter in the plan)
+    ("to_q", "add_k_proj", "img_mlp.net.2", "txt_mlp.net.0.proj")])   # mixed sites
+def test_feed_forward_lora_targets(targets):
+    """LoRA on the feed-forward linears of both streams (regex / list targets beyond the reference's default four): forward, dX
+    and every adapter gradient vs the oracle; the last block's text tail is dead compute -> those gradients are exactly zero."""
+    res = run_tiny_step_parity(DEV, verbose=True, shapes=((1, 6, 4), (1, 8, 8)), T=9, B=2, r=8, targets=targets)
+    _dump("ff_lora_" + str(len(targets)), res)
+    assert res["ok"], res
+
+
 def test_head_dim_128_config():
     cfg = dict(patch_size=2, in_channels=64, out_channels=16, num_layers=2, attention_head_dim=128, num_attention_heads=2,
                joint_attention_dim=512, axes_dims_rope=(16, 56, 56))
@@ -269,3 +281,46 @@ def test_qwen_multires_forward_backward_matches_oracle():
         b = hip(hidden_states=x.to(DEV), encoder_hidden_states=pe.to(DEV), timestep=tt.to(DEV), img_shapes=sh2, txt_seq_lens=[T, T],
                 return_dict=False)[0]
     assert torch.equal(a, b)
+
+
+def test_merge_adapter_matches_oracle_with_folded_weights():
+    """merge_adapter() (BaseTrainer.merge_lora, base_trainer.py:413-416): peft folds `scale * B A` (fp32) into the bf16 base weight
+    in place; the forward is then the base layer alone.  HIP merged forward vs the oracle with the same folding and a zero B; the
+    merged output stays within bf16 weight-rounding distance of the un-merged one; unmerge_adapter() restores the LoRA path."""
+    from common import TINY
+    from oracle import qwen_dit as O
+    from parity_util import build_pair, tiny_embeddings
+    oracle, hip = build_pair(dict(TINY), device=DEV)
+    emb, _, _ = tiny_embeddings(seed=21)
+    x = torch.cat([emb["image_latents"], emb["control_latents"]], dim=1).to(BF)
+    pe = emb["prompt_embeds"].to(BF)
+    tt = torch.tensor([0.3, 0.8])
+    T = pe.shape[1]
+
+    def fwd_hip():
+        with torch.no_grad():
+            return hip(hidden_states=x.to(DEV), encoder_hidden_states=pe.to(DEV), encoder_hidden_states_mask=emb["prompt_embeds_mask"],
+                       timestep=tt.to(DEV), img_shapes=emb["img_shapes"], txt_seq_lens=[T] * 2, return_dict=False)[0].float().cpu()
+
+    out_u = fwd_hip()
+    w_before = hip.transformer_blocks[0].attn.to_q.base_layer.weight.detach().clone()
+    hip.merge_adapter()
+    assert not torch.equal(hip.transformer_blocks[0].attn.to_q.base_layer.weight, w_before)
+    out_m = fwd_hip()
+    n = 0
+    for m in oracle.modules():
+        if isinstance(m, O.OracleLoraLinear):
+            A, B_ = m.lora_A[m.adapter_name].weight.data, m.lora_B[m.adapter_name].weight.data
+            m.base_layer.weight.data += (B_ @ A) * m.scaling
+            B_.zero_()
+            n += 1
+    assert n == 8
+    with torch.no_grad():
+        out_o = oracle(hidden_states=x, encoder_hidden_states=pe, timestep=tt, img_shapes=emb["img_shapes"], txt_seq_lens=[T] * 2)[0].float()
+    e_o, e_u = relmax(out_m, out_o), relmax(out_m, out_u)
+    print("merged: vs oracle(folded)", e_o, " vs un-merged", e_u)
+    assert e_o < 1e-2 and 0 < e_u < 3e-2
+    hip.merge_adapter()                                # idempotent (peft skips an already merged adapter)
+    assert relmax(fwd_hip(), out_m) == 0.0
+    hip.unmerge_adapter()                              # w + d - d is not bit-exact in bf16: restored within weight rounding
+    assert relmax(fwd_hip(), out_u) < 1e-2
