@@ -75,7 +75,8 @@ def run_profiled(prog, fn_target):
     st_obj = torch.cuda.current_stream()
     st = st_obj.cuda_stream
     evs = []
-    for fn, args in prog.calls:
+    for ent in prog.calls:
+        fn, args = ent[0], ent[1]      # (side-stream entries carry a third field; the profiled replay keeps one stream)
         if fn is None:
             args()
             continue

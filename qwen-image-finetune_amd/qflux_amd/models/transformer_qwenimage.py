@@ -126,19 +126,26 @@ class _Prog:
     def c(self, fn, *args):
         self.calls.append((fn, args))
 
+    def c_side(self, fn, *args):
+        """C call issued on the program's side stream (leaf work that overlaps the main stream; joined by explicit events)."""
+        self.calls.append((fn, args, True))
+
     def py(self, fn):
         self.calls.append((None, fn))
 
     def mark(self, prefix: str):
         self.marks.append((len(self.calls), prefix))
 
+    side = None   # torch.cuda.Stream for c_side calls (set by the plan that uses them)
+
     def run(self, start: int = 0, end: int | None = None):
         st = torch.cuda.current_stream().cuda_stream
-        for fn, args in self.calls[start:end]:
+        for ent in self.calls[start:end]:
+            fn, args = ent[0], ent[1]
             if fn is None:
                 args()
             else:
-                rc = fn(*args, st)
+                rc = fn(*args, self.side.cuda_stream if len(ent) > 2 else st)
                 if rc != 0:
                     raise L.QfxError(f"{fn.__name__} failed with code {rc}")
 
@@ -497,6 +504,9 @@ class QwenImageTransformer2DModel(nn.Module):
 class _QwenPlan:
     """Launch programs (forward, backward) + persistent arena for one shape signature."""
 
+    side_grads = False        # see _init_side_grads (plans that do not call it keep every launch on the main stream)
+    _side_pending = None
+
     def __init__(self, model, B: int, S_i: int, T: int, shapes, multires: bool = False):
         self._setup(model, B, S_i, T)
         cfg = model.config
@@ -534,8 +544,37 @@ class _QwenPlan:
         self._alloc_double_scratch(P["blocks"])
         self.fwd = _Prog()
         self.bwd = _Prog()
+        self._init_side_grads(P["blocks"], type(self) is _QwenPlan)
         self._build_forward(P)
         self._build_backward(P)
+
+    def _init_side_grads(self, blocks, allowed):
+        """LoRA weight gradients are leaves of the backward: the batched lora_grad launch of block i goes to a low-priority side
+        stream and overlaps the first two GEMMs of block i-1 (persistent 240-block grids leave 16 CUs idle); the main stream joins
+        it right before block i-1 first overwrites one of its operands (dyg1).  Not with feed-forward adapters (their operands dh /
+        dyg2 are overwritten at once).  QFX_SIDE_GRADS=0 keeps everything on the main stream."""
+        import os
+        ff = any(w[s + k].lora is not None for w in blocks for s in ("img", "txt") for k in (".fc1", ".fc2"))
+        self.side_grads = bool(allowed and self.has_lora and not ff and os.environ.get("QFX_SIDE_GRADS", "1") != "0")
+        self._side_pending = None      # (event, prefix) of the block whose gradient launch is in flight on the side stream
+        if self.side_grads:
+            dev = self.model.device
+            self.bwd.side = torch.cuda.Stream(device=dev, priority=0 if os.environ.get("QFX_SIDE_PRIO") == "0" else 1)
+            self._ev_fork = torch.cuda.Event()
+
+    def _side_fork(self):
+        self._ev_fork.record(torch.cuda.current_stream())
+        self.bwd.side.wait_event(self._ev_fork)
+
+    def _side_join(self, p):
+        """Emit the join with the in-flight side-stream gradient launch (if any) and the mark that its gradients are final."""
+        if self._side_pending is None:
+            return
+        ev, prefix = self._side_pending
+        self._side_pending = None
+        p.py(lambda ev=ev: torch.cuda.current_stream().wait_event(ev))
+        if prefix is not None:
+            p.mark(prefix)
 
     def _setup(self, model, B, S_i, T):
         self.model = model
@@ -709,7 +748,7 @@ class _QwenPlan:
         pending.clear()
 
     @staticmethod
-    def _flush_batch(prog, pending, struct, fn):
+    def _flush_batch(prog, pending, struct, fn, side=False):
         """Emit deferred skinny-kernel problems as batched launches: same R per launch, at most QFX_MAX_BATCH each."""
         by_r = {}
         for a in pending:
@@ -719,7 +758,7 @@ class _QwenPlan:
                 chunk = lst[i:i + L.MAX_BATCH]
                 arr = (struct * len(chunk))(*chunk)
                 prog.keep.append(arr)
-                prog.c(fn, arr, len(chunk))
+                (prog.c_side if side else prog.c)(fn, arr, len(chunk))
         pending.clear()
 
     def _grad(self, prog, *, Vt, R, r_valid, X, ldx, M, K, G, g_sr, g_sc, group_R=None, rpb=None, x_map=(0, 0), out_scale=1.0,
@@ -903,11 +942,14 @@ class _QwenPlan:
             gate_prev = None if i == 0 else {"img": A["mods"][2 * (i - 1)][:, 5 * D:6 * D], "txt": A["mods"][2 * (i - 1) + 1][:, 5 * D:6 * D]}
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
-                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0), norm_flags=0)
-            p.mark(f"transformer_blocks.{i}.")
+                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0), norm_flags=0,
+                                  prefix=f"transformer_blocks.{i}.")
+            if not self.side_grads:
+                p.mark(f"transformer_blocks.{i}.")
             cur = nxt
+        self._side_join(p)
 
-    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags):
+    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None):
         """Backward of one double-stream block.  In: dx2[s] = d(block output), A["dyg2"][s] = gate2*dx2 (emitted by whoever
         produced dx2).  Out: out_dx[s] = d(block input) and A["dyg2"][s] = gate_prev*out_dx (for the previous block)."""
         A, B, D, S, H, dh, T = self.A, self.B, self.D, self.S, self.H, self.dh, self.T
@@ -959,6 +1001,7 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             if ge:
                 self._flush_batch(p, ge, L.LoraGradArgs, lib.qfx_lora_grad_batch)
+            self._side_join(p)   # the previous block's gradient launch read dyg1 / dqkv / v^T scratch: overwritten from here on
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
                                      A["dx1"][s], A["dyg1"][s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
@@ -1036,7 +1079,14 @@ class _QwenPlan:
                                                  (gp.stride(0) if gp is not None else 0), out_dx[s],
                                                  A["dyg2"][s] if gp is not None else None, rows[s], D, rpb[s], eps, self.rmask[s]))
                 self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
-        self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
+        if self.side_grads and gl:
+            p.py(self._side_fork)
+            self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch, side=True)
+            ev = torch.cuda.Event()
+            p.py(lambda ev=ev: ev.record(self.bwd.side))
+            self._side_pending = (ev, prefix)
+        else:
+            self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
 
     def set_multires(self, img_shapes, txt_seq_lens, attention_mask):
         """Per-batch tables of the multi-resolution path (host-side plumbing of transformer_qwen_custom.py:72-150,175-228,

@@ -324,3 +324,38 @@ def test_merge_adapter_matches_oracle_with_folded_weights():
     assert relmax(fwd_hip(), out_m) == 0.0
     hip.unmerge_adapter()                              # w + d - d is not bit-exact in bf16: restored within weight rounding
     assert relmax(fwd_hip(), out_u) < 1e-2
+
+
+def test_loss_curve_matches_oracle_training_run():
+    """BASELINE north_star: "loss-curve match to the reference within 1e-3 MSE".  60 optimisation steps on a rotating pool of
+    batches with fresh (injected) noise / timestep draws: the fused HIP step (forward, backward, clip, AdamW) vs the oracle DiT trained
+    by torch.optim.AdamW + clip_grad_norm_ on the same draws (bf16 trunk, fp32 adapters, as the reference trains)."""
+    from common import TINY
+    from oracle import qwen_dit as O
+    from qflux_amd.trainer import QwenLoraTrainStep
+    oracle, hip = build_pair(dict(TINY), device=DEV)
+    lr, wd, steps = 3e-3, 0.01, 60
+    step = QwenLoraTrainStep(hip, lr=lr, weight_decay=wd, max_grad_norm=1.0)
+    params = [p for n, p in oracle.named_parameters() if "lora" in n]
+    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    pool = [tiny_embeddings(seed=100 + i)[0] for i in range(4)]
+    g = torch.Generator().manual_seed(7)
+    lo, lh = [], []
+    for it in range(steps):
+        emb = pool[it % len(pool)]
+        noise = torch.randn(emb["image_latents"].shape, generator=g)
+        u = torch.rand(emb["image_latents"].shape[0], generator=g)
+        loss_o = O.qwen_compute_loss(oracle, emb, noise, u, BF)
+        opt.zero_grad(set_to_none=True)
+        loss_o.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        lo.append(loss_o.item())
+        lh.append(step.train_step(emb, noise=noise, u=u).item())
+    d = torch.tensor(lh) - torch.tensor(lo)
+    mse, worst = float((d ** 2).mean()), float(d.abs().max())
+    got = {n: p.detach().float().cpu() for n, p in hip.named_parameters() if "lora" in n}
+    drift = max(relmax(got[n], p) for n, p in oracle.named_parameters() if "lora" in n)
+    print("loss curve: mse", mse, "max |d|", worst, "first/last", lo[0], lo[-1], "adapter drift after", steps, "steps:", drift)
+    _dump("loss_curve", dict(steps=steps, mse=mse, max_abs_diff=worst, oracle=lo, hip=lh, adapter_rel_drift=drift))
+    assert mse < 1e-3 and sum(lo[-8:]) < 0.97 * sum(lo[:8])     # matched AND actually trained

@@ -44,7 +44,8 @@ def label(fn, args):
 for phase, prog in (("fwd", plan.fwd), ("bwd", plan.bwd)):
     st_obj = torch.cuda.current_stream(); st = st_obj.cuda_stream
     evs = []
-    for fn, args in prog.calls:
+    for ent in prog.calls:
+        fn, args = ent[0], ent[1]      # (side-stream entries carry a third field; the profiled replay keeps one stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st_obj)
         if fn is None:
