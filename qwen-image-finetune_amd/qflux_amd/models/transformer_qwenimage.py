@@ -505,7 +505,7 @@ class _QwenPlan:
     """Launch programs (forward, backward) + persistent arena for one shape signature."""
 
     side_grads = False        # see _init_side_grads (plans that do not call it keep every launch on the main stream)
-    _side_pending = None
+    _side_q = ()
 
     def __init__(self, model, B: int, S_i: int, T: int, shapes, multires: bool = False):
         self._setup(model, B, S_i, T)
@@ -556,25 +556,38 @@ class _QwenPlan:
         import os
         ff = any(w[s + k].lora is not None for w in blocks for s in ("img", "txt") for k in (".fc1", ".fc2"))
         self.side_grads = bool(allowed and self.has_lora and not ff and os.environ.get("QFX_SIDE_GRADS", "1") != "0")
-        self._side_pending = None      # (event, prefix) of the block whose gradient launch is in flight on the side stream
+        self._side_q = []              # (event, prefix) of the blocks whose gradient launches are in flight on the side stream
         if self.side_grads:
             dev = self.model.device
             self.bwd.side = torch.cuda.Stream(device=dev, priority=0 if os.environ.get("QFX_SIDE_PRIO") == "0" else 1)
             self._ev_fork = torch.cuda.Event()
+            # the scratch operands of those launches (dyg1, dqkv, v^T) alternate between two copies by block parity, so a launch
+            # has a whole block of main-stream work to hide under (on the 16 idle CUs it runs ~5x longer than alone)
+            A = self.A
+            for name in ("dyg1", "dqkv", "Vt", "VtO"):
+                src = A[name]
+                if isinstance(src, dict):
+                    A[name + "#1"] = {s: (tuple(torch.zeros_like(t) for t in v) if isinstance(v, tuple) else torch.zeros_like(v))
+                                      for s, v in src.items()}
+                else:
+                    A[name + "#1"] = torch.zeros_like(src)
+
+    def _sb(self, name, par):
+        """Scratch buffer `name` of block parity `par` (second copies exist only with side-stream gradient launches)."""
+        return self.A[name + "#1"] if (par and self.side_grads) else self.A.get(name)   # v^T scratch exists only with adapters
 
     def _side_fork(self):
         self._ev_fork.record(torch.cuda.current_stream())
         self.bwd.side.wait_event(self._ev_fork)
 
-    def _side_join(self, p):
-        """Emit the join with the in-flight side-stream gradient launch (if any) and the mark that its gradients are final."""
-        if self._side_pending is None:
-            return
-        ev, prefix = self._side_pending
-        self._side_pending = None
-        p.py(lambda ev=ev: torch.cuda.current_stream().wait_event(ev))
-        if prefix is not None:
-            p.mark(prefix)
+    def _side_join(self, p, keep=0):
+        """Emit the joins with the oldest in-flight side-stream gradient launches until at most `keep` stay in flight, each
+        followed by the mark that its block's gradients are final."""
+        while len(self._side_q) > keep:
+            ev, prefix = self._side_q.pop(0)
+            p.py(lambda ev=ev: torch.cuda.current_stream().wait_event(ev))
+            if prefix is not None:
+                p.mark(prefix)
 
     def _setup(self, model, B, S_i, T):
         self.model = model
@@ -807,7 +820,7 @@ class _QwenPlan:
         for i in range(Lyr):
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
             self._emit_double_fwd(p, P["blocks"][i], A["blk"][i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
-                                  {s: (A["X"][s][i + 1], (0, 0)) for s in ("img", "txt")}, last=(i == Lyr - 1), norm_flags=0)
+                                  {s: (A["X"][s][i + 1], (0, 0)) for s in ("img", "txt")}, last=(i == Lyr - 1), norm_flags=0, par=i & 1)
         mo = A["mod_out"][0]  # [B, 2D]: scale | shift  (AdaLayerNormContinuous chunk order)
         p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
             rows["img"], D, rpb["img"], eps)
@@ -815,7 +828,7 @@ class _QwenPlan:
         self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b,
                    row_mask=self.rmask["img"])
 
-    def _emit_double_fwd(self, p, w, bb, mods, x_in, x_out, last, norm_flags):
+    def _emit_double_fwd(self, p, w, bb, mods, x_in, x_out, last, norm_flags, par=0):
         """One double-stream block (reference: transformer_qwenimage.py:425-494; FLUX: transformer_flux.py:467-523).
         x_in[s]: [rows_s, D] block input; x_out[s] = (tensor, c_map): where the block output goes (possibly a joint buffer)."""
         A, B, D, S, H, dh, T = self.A, self.B, self.D, self.S, self.H, self.dh, self.T
@@ -866,7 +879,7 @@ class _QwenPlan:
             # backward fields (same struct reused by the backward program)
             a.dsum = _ptr(A["dsum"])
             a.dO, a.lddo = _ptr(A["dao"]), D
-            dq2 = A["dqkv"].view(B * S, 3 * D)
+            dq2 = self._sb("dqkv", par).view(B * S, 3 * D)
             a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
             a.lddq = a.lddk = a.lddv = 3 * D
             self.attn_args.append(a)
@@ -943,13 +956,13 @@ class _QwenPlan:
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
                                   gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0), norm_flags=0,
-                                  prefix=f"transformer_blocks.{i}.")
+                                  prefix=f"transformer_blocks.{i}.", par=i & 1)
             if not self.side_grads:
                 p.mark(f"transformer_blocks.{i}.")
             cur = nxt
         self._side_join(p)
 
-    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None):
+    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None, par=0):
         """Backward of one double-stream block.  In: dx2[s] = d(block output), A["dyg2"][s] = gate2*dx2 (emitted by whoever
         produced dx2).  Out: out_dx[s] = d(block input) and A["dyg2"][s] = gate_prev*out_dx (for the previous block)."""
         A, B, D, S, H, dh, T = self.A, self.B, self.D, self.S, self.H, self.dh, self.T
@@ -957,7 +970,8 @@ class _QwenPlan:
         rows, rpb, off = self.rows, self.rpb, self.off
         eps = 1e-6
         dao2 = A["dao"].view(B * S, D)
-        dq2 = A["dqkv"].view(B * S, 3 * D)
+        dqkv, dyg1, VtO, VtQ = self._sb("dqkv", par), self._sb("dyg1", par), self._sb("VtO", par), self._sb("Vt", par)
+        dq2 = dqkv.view(B * S, 3 * D)
         STREAMS = (("img", 0), ("txt", 1))
         i = 0 if first else 1
         # LoRA weight gradients are leaves: every qfx_lora_grad of the block is deferred to ONE batched launch per rank at the
@@ -1001,10 +1015,10 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             if ge:
                 self._flush_batch(p, ge, L.LoraGradArgs, lib.qfx_lora_grad_batch)
-            self._side_join(p)   # the previous block's gradient launch read dyg1 / dqkv / v^T scratch: overwritten from here on
+            self._side_join(p, keep=1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
-                                     A["dx1"][s], A["dyg1"][s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
+                                     A["dx1"][s], dyg1[s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
             self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
             for s, sidx in live:
                 mod = mods[s]
@@ -1013,15 +1027,15 @@ class _QwenPlan:
                 kw = {}
                 if lw.lora is not None:
                     lo = lw.lora
-                    Vt = (A["VtO"][s][0][:lo.Rp], A["VtO"][s][1][:lo.Rp])
-                    self._down(p, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0),
+                    Vt = (VtO[s][0][:lo.Rp], VtO[s][1][:lo.Rp])
+                    self._down(p, X=dyg1[s], ldx=D, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0),
                                R=lo.Rp, Ut=Vt, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0))
-                    self._grad(p, Vt=bb["Uo." + s], R=lo.Rp, r_valid=lo.r, X=A["dyg1"][s], ldx=D, M=rows[s], K=lw.N,
+                    self._grad(p, Vt=bb["Uo." + s], R=lo.Rp, r_valid=lo.r, X=dyg1[s], ldx=D, M=rows[s], K=lw.N,
                                G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale, defer=gl)
                     self._grad(p, Vt=Vt, R=lo.Rp, r_valid=lo.r, X=ao2, ldx=D, M=rows[s], K=lw.K, G=lo.gA,
                                g_sr=lw.K, g_sc=1, rpb=rpb[s], x_map=(S, off[s]), defer=gl)
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
-                groups.append(self._gargs(A1=A["dyg1"][s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
+                groups.append(self._gargs(A1=dyg1[s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
                                           c_map=(S, off[s]), **kw))
             self._gemm_group(p, groups)
             # ---- attention backward
@@ -1029,7 +1043,7 @@ class _QwenPlan:
             p.c(lib.qfx_attn_bwd_dq, C.byref(a))
             p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
             nq_t, nk_t, nq_i, nk_i = w["norms"]
-            p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
+            p.c(lib.qfx_qk_norm_rope_bwd, _ptr(dqkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
                 _ptr(nk_i), B, S, T, H, dh, eps, norm_flags, self.rope_bs)
             # ---- q/k/v projection backward (+ LoRA), both streams in one launch
             groups = []
@@ -1039,7 +1053,7 @@ class _QwenPlan:
                 kw = {}
                 if grp is not None:
                     Rp, Kext = grp["Rp"], grp["Kext"]
-                    Vth, Vtl = A["Vt"][s]
+                    Vth, Vtl = VtQ[s]
                     Uth, Utl = bb["Uqkv." + s]
                     e3 = A["ext3"][s]
                     for sec in range(3):
@@ -1084,7 +1098,7 @@ class _QwenPlan:
             self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch, side=True)
             ev = torch.cuda.Event()
             p.py(lambda ev=ev: ev.record(self.bwd.side))
-            self._side_pending = (ev, prefix)
+            self._side_q.append((ev, prefix))
         else:
             self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
 
