@@ -291,6 +291,16 @@ typedef struct qfx_prodigy_args {
 int qfx_prodigy_init_state(double* state, double d0, void* stream);   /* d = d_max = d_hat = d0, everything else 0; synchronises */
 int qfx_prodigy_step(const qfx_prodigy_args* a, void* stream);
 
+/* ---- runtime: a HIP stream confined to the first `n_cus` bits of the driver's CU mask (consecutive bits walk the 8 XCDs first, so
+ * 16 = two CUs per XCD).  The persistent GEMM grids occupy 240 of the 256 CUs; leaf work of the backward (the LoRA weight-gradient
+ * launches, which the reference's autograd also schedules off the dX critical path) runs here without ever taking a CU a GEMM block
+ * is waiting for.  Streams are plain hipStream_t handles; destroy with qfx_stream_destroy. ---- */
+#define QFX_NUM_CU_TOTAL 256
+int qfx_stream_create_cu_masked(int32_t n_cus, void** stream_out);
+int qfx_stream_destroy(void* stream);
+/* debug: out[2*b] = HW_ID register, out[2*b+1] = XCC_ID register of the CU block b ran on (blocks spin ~0.1 ms) */
+int qfx_debug_where(uint32_t* out, int32_t n_blocks, void* stream);
+
 /* ---- debug: lane mapping of ds_read_b64_tr_b16 (64 lanes x 4 bf16 in, same out) ---- */
 int qfx_debug_tr_read(const uint16_t* in, uint16_t* out, void* stream);
 

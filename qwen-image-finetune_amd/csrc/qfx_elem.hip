@@ -575,6 +575,20 @@ __global__ __launch_bounds__(256) void prodigy_apply_kernel(float* __restrict__ 
   }
 }
 
+// ---- runtime helpers: CU-masked side stream + a probe of where blocks run --------------------------------------------------
+__global__ void where_kernel(uint32_t* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[2 * blockIdx.x] = hw;
+    out[2 * blockIdx.x + 1] = xcc;
+  }
+  // stay resident long enough that concurrently launched blocks have to spread over every allowed CU
+  const uint64_t t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < 200000) {}
+}
+
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* __restrict__ t, int B, int dim, float scale,
                                                              float pre_scale, bf16_t* __restrict__ out) {
   const int half = dim / 2;
@@ -866,6 +880,30 @@ extern "C" int qfx_prodigy_step(const qfx_prodigy_args* a, void* stream) {
                      (double)a->growth_rate);
   hipLaunchKernelGGL(prodigy_apply_kernel, dim3(blocks), dim3(256), 0, s, a->p, a->exp_avg, a->exp_avg_sq, a->n, a->state, a->eps,
                      a->weight_decay);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_stream_create_cu_masked(int32_t n_cus, void** stream_out) {
+  if (!stream_out || n_cus <= 0 || n_cus > QFX_NUM_CU_TOTAL) return QFX_EINVAL;
+  uint32_t mask[QFX_NUM_CU_TOTAL / 32] = {0};
+  for (int i = 0; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);   // driver order: consecutive bits walk the XCDs first
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, QFX_NUM_CU_TOTAL / 32, mask);
+  if (e != hipSuccess) return -1000 - (int)e;
+  *stream_out = (void*)s;
+  return QFX_OK;
+}
+
+extern "C" int qfx_stream_destroy(void* stream) {
+  if (!stream) return QFX_EINVAL;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  return e == hipSuccess ? QFX_OK : -1000 - (int)e;
+}
+
+extern "C" int qfx_debug_where(uint32_t* out, int32_t n_blocks, void* stream) {
+  if (!out || n_blocks <= 0) return QFX_EINVAL;
+  hipLaunchKernelGGL(where_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, out);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -135,6 +135,9 @@ SYMBOLS = {
     "qfx_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _vp]),
     "qfx_prodigy_init_state": (C.c_int, [_vp, C.c_double, _vp]),
     "qfx_prodigy_step": (C.c_int, [C.POINTER(ProdigyArgs), _vp]),
+    "qfx_stream_create_cu_masked": (C.c_int, [_i32, C.POINTER(C.c_void_p)]),
+    "qfx_stream_destroy": (C.c_int, [_vp]),
+    "qfx_debug_where": (C.c_int, [_vp, _i32, _vp]),
     "qfx_debug_tr_read": (C.c_int, [_vp, _vp, _vp]),
     "qfx_abi_version": (C.c_int, []),
     "qfx_build_arch": (C.c_char_p, []),

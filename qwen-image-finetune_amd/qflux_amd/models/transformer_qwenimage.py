@@ -559,7 +559,10 @@ class _QwenPlan:
         self._side_q = []              # (event, prefix) of the blocks whose gradient launches are in flight on the side stream
         if self.side_grads:
             dev = self.model.device
-            self.bwd.side = torch.cuda.Stream(device=dev, priority=0 if os.environ.get("QFX_SIDE_PRIO") == "0" else 1)
+            from .. import ops
+            # QFX_SIDE_CUS=16 confines the side stream to two CUs per XCD (qfx_stream_create_cu_masked).  Measured: the mask works
+            # (tools/cu_mask_probe.py) but the whole step slows from 99.7 to 127.9 ms with such a queue alive -> default: no mask
+            self.bwd.side = ops.side_stream(dev, int(os.environ.get("QFX_SIDE_CUS", "0")))
             self._ev_fork = torch.cuda.Event()
             # the scratch operands of those launches (dyg1, dqkv, v^T) alternate between two copies by block parity, so a launch
             # has a whole block of main-stream work to hide under (on the 16 idle CUs it runs ~5x longer than alone)

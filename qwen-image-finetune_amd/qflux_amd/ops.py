@@ -237,6 +237,27 @@ def sumsq(g, out):
     L.check(lib.qfx_sumsq(_p(g), g.numel(), _p(out), stream_ptr()), "qfx_sumsq")
 
 
+_side_streams = {}
+
+
+def side_stream(device, n_cus=16):
+    """Process-wide CU-masked side stream of `device` (qfx_stream_create_cu_masked) as a torch stream object; n_cus = 0 or a driver
+    that refuses the mask -> an ordinary lowest-priority stream."""
+    key = (torch.device(device).index or 0, int(n_cus))
+    if key not in _side_streams:
+        st = None
+        if n_cus > 0:
+            out = C.c_void_p()
+            with torch.cuda.device(key[0]):
+                rc = lib.qfx_stream_create_cu_masked(int(n_cus), C.byref(out))
+            if rc == 0 and out.value:
+                st = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key[0]))
+        if st is None:
+            st = torch.cuda.Stream(device=torch.device("cuda", key[0]), priority=1)
+        _side_streams[key] = st
+    return _side_streams[key]
+
+
 def prodigy_init_state(state, d0=1e-6):
     """state: fp64[PRODIGY_STATE] device tensor (d, d_max, d_numerator, d_denom, d_hat, k, scratch...)."""
     L.check(lib.qfx_prodigy_init_state(_p(state), float(d0), stream_ptr()), "qfx_prodigy_init_state")
