@@ -265,12 +265,14 @@ class QwenImageTransformer2DModel(nn.Module):
         for m in self.modules():
             if isinstance(m, QfxLoraLinear):
                 m.merge()
+        self._merged = True
         self._invalidate()
 
     def unmerge_adapter(self):
         for m in self.modules():
             if isinstance(m, QfxLoraLinear):
                 m.unmerge()
+        self._merged = False
         self._invalidate()
 
     def save_lora_weights(self, save_folder, style="diffusers"):
@@ -1156,6 +1158,8 @@ class _QwenPlan:
     def run_backward(self, dpred, on_segment=None):
         """on_segment(prefixes): called after each marked segment of the backward program with the parameter-name prefixes
         whose LoRA gradients just became final (data-parallel bucketed all-reduce hooks in here)."""
+        if getattr(self.model, "_merged", False):
+            raise RuntimeError("adapters are merged into the base weights (merge_adapter): call unmerge_adapter() before training")
         self.A["dpred"].view(self.B, self.S_i, -1).copy_(dpred)
         self.model._lora.ensure_grads()
         if on_segment is None:

@@ -322,6 +322,9 @@ def test_merge_adapter_matches_oracle_with_folded_weights():
     assert e_o < 1e-2 and 0 < e_u < 3e-2
     hip.merge_adapter()                                # idempotent (peft skips an already merged adapter)
     assert relmax(fwd_hip(), out_m) == 0.0
+    from qflux_amd.trainer import QwenLoraTrainStep
+    with pytest.raises(RuntimeError, match="merged"):  # training a merged adapter would use gradients of a path the forward skips
+        QwenLoraTrainStep(hip).forward_backward(emb)
     hip.unmerge_adapter()                              # w + d - d is not bit-exact in bf16: restored within weight rounding
     assert relmax(fwd_hip(), out_u) < 1e-2
 
