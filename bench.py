@@ -70,8 +70,34 @@ def gemm_bytes_of(*progs):
     return tot
 
 
-def run_profiled(prog, fn_target):
-    """Replay a program with a HIP event pair around every launch of `fn_target`; returns summed ms and count."""
+def hbm_bytes_of_call(name, args):
+    """Algorithmic HBM bytes of one launch of a bandwidth-bound entry point, from its argument structs (bf16 streams touched once;
+    rank-side operands included, the few-KB outputs of the rank-r kernels ignored)."""
+    from qflux_amd import _lib as L
+
+    def structs(a, n=None):
+        obj = getattr(a, "_obj", a)          # ctypes.byref(struct) keeps the struct in ._obj
+        return [obj] if n is None else [obj[i] for i in range(n)]
+
+    if name in ("qfx_lora_down", "qfx_lora_down_batch"):
+        return sum(2 * x.M * x.K + 4 * x.R * x.K for x in structs(args[0], args[1] if name.endswith("batch") else None))
+    if name in ("qfx_lora_grad", "qfx_lora_grad_batch"):
+        return sum(2 * x.M * x.K + 4 * x.R * x.M + 4 * x.R * x.K for x in structs(args[0], args[1] if name.endswith("batch") else None))
+    if name == "qfx_ln_modulate_fwd_batch":
+        return sum(4 * x.rows * x.D for x in structs(args[0], args[1]))
+    if name == "qfx_ln_modulate_bwd_batch":
+        return sum(2 * x.rows * x.D * (3 + (1 if x.dres else 0) + (1 if x.dyg else 0)) for x in structs(args[0], args[1]))
+    if name == "qfx_mod_gemv":               # (temb, B, K, W, bias, nmat, N, silu, out)
+        return 2 * args[5] * args[6] * args[2]
+    if name in ("qfx_qk_norm_rope_fwd", "qfx_qk_norm_rope_bwd"):   # q and k rows of the joint buffer, read + written (+ saved copy)
+        Bq, Sq, Hq, dh = args[7], args[8], args[10], args[11]
+        return 2 * Bq * Sq * 2 * Hq * dh * 3
+    return None
+
+
+def run_profiled(prog, fn_target, hbm=None):
+    """Replay a program with a HIP event pair around every launch of `fn_target` (returned as a list) and, when `hbm` is a dict,
+    around every bandwidth-bound entry point too (hbm[name] -> [events, bytes, launches])."""
     st_obj = torch.cuda.current_stream()
     st = st_obj.cuda_stream
     evs = []
@@ -80,12 +106,17 @@ def run_profiled(prog, fn_target):
         if fn is None:
             args()
             continue
-        if fn in fn_target:
+        nbytes = hbm_bytes_of_call(fn.__name__, args) if hbm is not None else None
+        if fn in fn_target or nbytes is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st_obj)
             rc = fn(*args, st)
             e1.record(st_obj)
-            evs.append((e0, e1))
+            if fn in fn_target:
+                evs.append((e0, e1))
+            else:
+                rec = hbm.setdefault(fn.__name__.replace("_batch", ""), [[], 0, 0])
+                rec[0].append((e0, e1)); rec[1] += nbytes; rec[2] += 1
         else:
             rc = fn(*args, st)
         if rc != 0:
@@ -204,10 +235,9 @@ def main():
     plan = list(dit._plans.values())[0]
     dit.refresh_lora_operands()
     gemm_fns = (L.lib.qfx_gemm_bf16, L.lib.qfx_gemm_grouped)
-    ev = run_profiled(plan.fwd, gemm_fns)
-    loss2, dpred = None, None
-    from qflux_amd import ops
-    ev += run_profiled(plan.bwd, gemm_fns)
+    hbm = {}
+    ev = run_profiled(plan.fwd, gemm_fns, hbm)
+    ev += run_profiled(plan.bwd, gemm_fns, hbm)
     torch.cuda.synchronize()
     gemm_ms = sum(a.elapsed_time(b) for a, b in ev)
     gf_f, n_f = gemm_flops_of(plan.fwd)
@@ -247,6 +277,12 @@ def main():
                      "algorithmic_bytes_per_launch": int(gemm_bytes_of(plan.fwd, plan.bwd) / n_launch),
                      "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                      "gemm_share_of_step": round(gemm_ms / ms_per_step, 3)},
+        # the bandwidth-bound kernels of the same replayed step (serial replay: the weight-gradient launches are timed alone here,
+        # in the step they overlap the main stream): algorithmic bytes / summed launch time against the 8 TB/s HBM3E peak
+        "hbm_kernels": {k: {"GBps": round(v[1] / (sum(a.elapsed_time(b) for a, b in v[0]) * 1e-3) / 1e9, 1),
+                            "frac_of_8TBps": round(v[1] / (sum(a.elapsed_time(b) for a, b in v[0]) * 1e-3) / 8e12, 3),
+                            "ms_per_step": round(sum(a.elapsed_time(b) for a, b in v[0]), 3), "launches": v[2]}
+                        for k, v in sorted(hbm.items())},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
