@@ -27,6 +27,28 @@ def test_tiny_step_fused_matches_oracle():
     assert res["ok"], res
 
 
+def test_tiny_step_single_stream_backward(monkeypatch):
+    """QFX_SIDE_GRADS=0: the LoRA weight-gradient launches stay on the main stream (the layout every plan used before the side
+    stream; FLUX plans and plans with feed-forward adapters still do) -- same parity bar, and the plan really is the inline one."""
+    from common import TINY
+    from qflux_amd.trainer import QwenLoraTrainStep
+    monkeypatch.setenv("QFX_SIDE_GRADS", "0")
+    res = run_tiny_step_parity(DEV, verbose=True)
+    assert res["ok"], res
+    _, hip = build_pair(dict(TINY), device=DEV)
+    emb, noise, u = tiny_embeddings()
+    QwenLoraTrainStep(hip).forward_backward(emb, noise=noise, u=u)
+    plan = list(hip._plans.values())[0]
+    assert plan.side_grads is False and len(plan.bwd.marks) == TINY["num_layers"]
+    monkeypatch.setenv("QFX_SIDE_GRADS", "1")
+    _, hip2 = build_pair(dict(TINY), device=DEV)
+    QwenLoraTrainStep(hip2).forward_backward(emb, noise=noise, u=u)
+    plan2 = list(hip2._plans.values())[0]
+    assert plan2.side_grads is True and [m[1] for m in plan2.bwd.marks] == [m[1] for m in plan.bwd.marks]
+    rel = relmax(hip2.lora_store.gflat, hip.lora_store.gflat)
+    assert rel < 1e-5, rel       # same gradients up to the order of the fp32 atomics
+
+
 def test_tiny_step_autograd_path_matches_oracle():
     res = run_tiny_step_parity(DEV, verbose=True, fused=False)
     _dump("tiny_autograd", res)
