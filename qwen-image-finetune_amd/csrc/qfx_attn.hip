@@ -183,17 +183,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
           }
         }
     } else {
+      // common case: the maximum is taken over the RAW scores (scale > 0 commutes with max) and the scale rides in the FMA that
+      // feeds v_exp -- one VALU op per score less than scaling first
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) {
-            const float sv = sacc[kf][f][r] * c2;
-            sacc[kf][f][r] = sv;
-            mx[f] = fmaxf(mx[f], sv);
-          }
+          for (int f = 0; f < 2; ++f) mx[f] = fmaxf(mx[f], sacc[kf][f][r]);
     }
+    const float cs = need_mask ? 1.0f : c2;   // scores are already scaled (and masked) on the masked path
     bf16x8 pb[2][2];
     float alpha[2];
 #pragma unroll
@@ -201,6 +200,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
       float m = mx[f];
       m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
+      m *= cs;
       const float mnew = fmaxf(mrow[f], m);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
       alpha[f] = fexp2(mrow[f] - msafe);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = fexp2(sacc[kf][f][r] - msafe);
+          const float p = fexp2(fmaf(sacc[kf][f][r], cs, -msafe));
           sacc[kf][f][r] = p;
           ps += p;
         }
