@@ -18,7 +18,6 @@ from __future__ import annotations
 import glob
 import json
 import os
-import queue
 import random
 import threading
 
@@ -121,12 +120,19 @@ class PrefetchLoader:
         self.epoch = epoch
 
     def indices(self):
+        """Batches of this rank.  Every rank gets the SAME number of batches (the permutation is cut to a multiple of
+        world * batch_size before striding -- or wrap-padded when drop_last is False, as accelerate's prepared DataLoader does,
+        base_trainer.py:378-393): a rank with one batch more would sit alone in the step's collectives at the end of the epoch."""
         idx = list(range(len(self.ds)))
         if self.shuffle:
             random.Random(self.seed + self.epoch).shuffle(idx)
+        chunk = self.world * self.bs
+        if self.drop_last or not idx:
+            idx = idx[:len(idx) // chunk * chunk]
+        elif len(idx) % chunk:
+            idx = idx + (idx * chunk)[:chunk - len(idx) % chunk]   # wrap-around padding to a whole number of global batches
         idx = idx[self.rank::self.world]            # rank-strided shard
-        n = len(idx) // self.bs * self.bs if self.drop_last else len(idx)
-        return [idx[i:i + self.bs] for i in range(0, n, self.bs)]
+        return [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
 
     def __len__(self):
         return len(self.indices())
@@ -141,21 +147,35 @@ class PrefetchLoader:
 
     def __iter__(self):
         batches = self.indices()
-        q: queue.Queue = queue.Queue(maxsize=max(1, self.prefetch))
+        depth = max(1, self.prefetch)
         slots = {}
-        lock = threading.Lock()
-        nxt = [0]
+        cv = threading.Condition()
+        state = {"next": 0, "consumed": 0, "stop": False, "staged_max": 0, "error": None}
+        self.stats = state          # staged_max = the largest number of host batches ever staged at once (tests read it)
 
         def work():
+            # back-pressure: batch i is read only once i < consumed + depth, so at most `depth` collated (pinned) batches exist
+            # on the host at any time however fast the disk readers are
             while True:
-                with lock:
-                    i = nxt[0]
-                    nxt[0] += 1
-                if i >= len(batches):
+                with cv:
+                    while not state["stop"] and state["next"] < len(batches) and state["next"] >= state["consumed"] + depth:
+                        cv.wait()
+                    if state["stop"] or state["next"] >= len(batches):
+                        return
+                    i = state["next"]
+                    state["next"] += 1
+                try:
+                    hb = self._host_batch(batches[i])
+                except BaseException as e:   # noqa: BLE001  (surfaced in the consumer thread)
+                    with cv:
+                        state["error"] = e
+                        state["stop"] = True
+                        cv.notify_all()
                     return
-                hb = self._host_batch(batches[i])
-                with lock:
+                with cv:
                     slots[i] = hb
+                    state["staged_max"] = max(state["staged_max"], len(slots))
+                    cv.notify_all()
 
         threads = [threading.Thread(target=work, daemon=True) for _ in range(min(self.workers, max(1, len(batches))))]
         for t in threads:
@@ -163,13 +183,19 @@ class PrefetchLoader:
         use_cuda = self.device.type == "cuda"
         side = torch.cuda.Stream(device=self.device) if use_cuda else None
 
+        def take(i):
+            with cv:
+                while i not in slots and state["error"] is None:
+                    cv.wait()
+                if state["error"] is not None:
+                    raise state["error"]
+                hb = slots.pop(i)
+                state["consumed"] = i + 1
+                cv.notify_all()
+            return hb
+
         def upload(i):
-            while True:
-                with lock:
-                    hb = slots.pop(i, None)
-                if hb is not None:
-                    break
-                threading.Event().wait(0.0005)
+            hb = take(i)
             if not use_cuda:
                 return hb, None
             ev = torch.cuda.Event()
@@ -180,13 +206,24 @@ class PrefetchLoader:
             db["_host"] = hb     # keep the pinned buffers alive until the copy has been consumed
             return db, ev
 
-        pending = upload(0) if batches else None
-        for i in range(len(batches)):
-            cur, ev = pending
-            pending = upload(i + 1) if i + 1 < len(batches) else None    # next batch uploads while this one trains
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
-            cur.pop("_host", None)
-            yield cur
-        for t in threads:
-            t.join()
+        try:
+            pending = upload(0) if batches else None
+            for i in range(len(batches)):
+                cur, ev = pending
+                pending = upload(i + 1) if i + 1 < len(batches) else None    # next batch uploads while this one trains
+                if ev is not None:
+                    consumer = torch.cuda.current_stream(self.device)
+                    consumer.wait_event(ev)
+                    # the tensors were allocated on the side stream's pool: tell the caching allocator that the consumer stream
+                    # uses them too, or their blocks could be handed to upload(i+2) while this step's kernels are still queued
+                    for v in cur.values():
+                        if isinstance(v, torch.Tensor) and v.is_cuda:
+                            v.record_stream(consumer)
+                cur.pop("_host", None)
+                yield cur
+        finally:
+            with cv:
+                state["stop"] = True
+                cv.notify_all()
+            for t in threads:
+                t.join()

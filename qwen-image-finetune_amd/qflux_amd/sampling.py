@@ -33,6 +33,36 @@ class FlowMatchEulerSchedule:
                         max_shift=max_shift)
         self.shift_terminal = shift_terminal
 
+    _KEYS = ("num_train_timesteps", "base_image_seq_len", "max_image_seq_len", "base_shift", "max_shift", "shift_terminal")
+
+    @classmethod
+    def from_config(cls, config):
+        """Build the schedule from the model repository's scheduler/scheduler_config.json (a path to the json / the folder that
+        holds it, or the parsed dict).  The reference reads base/max_image_seq_len, base/max_shift from `scheduler.config`
+        (base_trainer.py:1027-1034) and the scheduler itself applies `shift_terminal`; the constructor defaults above are only
+        the reference's `.get(..., default)` fall-backs, NOT the values of a given checkpoint -- validation sampling of a real
+        model should always come through here.  Only use_dynamic_shifting=True / time_shift_type="exponential" schedulers are
+        restated (what Qwen-Image and FLUX ship); anything else raises."""
+        import json
+        import os
+        if not isinstance(config, dict):
+            path = str(config)
+            if os.path.isdir(path):
+                for cand in ("scheduler_config.json", os.path.join("scheduler", "scheduler_config.json")):
+                    if os.path.exists(os.path.join(path, cand)):
+                        path = os.path.join(path, cand)
+                        break
+            with open(path) as f:
+                config = json.load(f)
+        if not config.get("use_dynamic_shifting", True):
+            raise NotImplementedError("FlowMatchEulerSchedule restates the dynamic-shifting scheduler only")
+        if config.get("time_shift_type", "exponential") != "exponential":
+            raise NotImplementedError(f"time_shift_type {config.get('time_shift_type')!r}")
+        for k in ("use_karras_sigmas", "use_exponential_sigmas", "use_beta_sigmas", "invert_sigmas", "stochastic_sampling"):
+            if config.get(k):
+                raise NotImplementedError(f"scheduler option {k} is not part of the restated sampling path")
+        return cls(**{k: config[k] for k in cls._KEYS if k in config})
+
     def set_timesteps(self, num_inference_steps: int, image_seq_len: int):
         sig = torch.linspace(1.0, 1.0 / num_inference_steps, num_inference_steps, dtype=torch.float64)
         mu = calculate_shift(image_seq_len, self.cfg["base_image_seq_len"], self.cfg["max_image_seq_len"], self.cfg["base_shift"],
@@ -53,10 +83,14 @@ class FlowMatchEulerSchedule:
 
 
 class QwenSampler:
-    def __init__(self, dit, weight_dtype=BF, schedule: FlowMatchEulerSchedule | None = None):
+    def __init__(self, dit, weight_dtype=BF, schedule: FlowMatchEulerSchedule | None = None, scheduler_config=None):
+        """scheduler_config: the checkpoint's scheduler_config.json (path, folder or dict) -> FlowMatchEulerSchedule.from_config.
+        With neither argument the reference's fall-back constants are used (base_trainer.py:1027-1034 defaults)."""
         self.dit = dit
         self.weight_dtype = weight_dtype
-        self.schedule = schedule or FlowMatchEulerSchedule()
+        if schedule is None:
+            schedule = FlowMatchEulerSchedule.from_config(scheduler_config) if scheduler_config is not None else FlowMatchEulerSchedule()
+        self.schedule = schedule
 
     @torch.inference_mode()
     def sample(self, embeddings: dict) -> torch.Tensor:

@@ -44,24 +44,38 @@ class FluxKontextTrainStep(QwenLoraTrainStep):
         pred = self.dit(hidden_states=packed, timestep=t, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=pe,
                         txt_ids=txt_ids, img_ids=img_ids, joint_attention_kwargs={}, return_dict=False)[0]
         pred = pred[:, :S_t]
-        return torch.nn.functional.mse_loss(pred.float(), target.float(), reduction="mean")
+        el = (pred.float() - target.float()) ** 2
+        if self.criterion == "mask_edit":      # forward_loss(..., edit_mask=embeddings["edit_mask"]) (flux_kontext_trainer.py:570-574)
+            el = el * self._token_weights(embeddings, target.shape[0], S_t, el.device).unsqueeze(-1)
+        return torch.mean(el.reshape(target.shape[0], -1), dim=1).mean()
 
-    def forward_backward(self, embeddings, noise=None, t=None, grad_scale=1.0):
+    def forward_backward(self, embeddings, noise=None, t=None, grad_scale=1.0, sync=True):
+        """Same contract as QwenLoraTrainStep.forward_backward (criterion "mse" | "mask_edit", sync=False = no_sync micro-step)."""
         packed, target, pe, pooled, t, guidance, img_ids, txt_ids, S_t = self._prepare_flux(embeddings, noise, t)
         dit = self.dit
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], img_ids, txt_ids)
         dit.lora_store
         pred = plan.run_forward((packed, pooled, guidance), pe, t)
-        loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
-        plan.run_backward(dpred, on_segment=self._bucket_hook() if self.world > 1 else None)
+        if self.criterion == "mask_edit":
+            B = packed.shape[0]
+            tw = self._token_weights(embeddings, B, S_t, pred.device)
+            loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
+        else:
+            loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
+        plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
         return loss
 
-    def train_step(self, embeddings, noise=None, t=None):
-        loss = self.forward_backward(embeddings, noise, t)
-        scale = self.allreduce_grads()
+    def train_step(self, embeddings, noise=None, t=None, micro_batches=None):
+        """One optimisation step; micro_batches = further embedding dicts of the gradient-accumulation window (as the base class)."""
+        extra = list(micro_batches or [])
+        k = 1 + len(extra)
+        loss = self.forward_backward(embeddings, noise, t, sync=not extra)
+        for j, mb in enumerate(extra):
+            loss = loss + self.forward_backward(mb, sync=(j == len(extra) - 1))
+        scale = self.allreduce_grads() / k
         self.optimizer_step(grad_scale=scale)
         self.zero_grad()
-        return loss
+        return loss / k if k > 1 else loss
 
 
 def _build_multires_batch(step, samples, txt):
@@ -122,7 +136,7 @@ def _compute_loss_multires(self, samples, txt):
     return tok.sum() / (b["n_valid"] + 1e-12)
 
 
-def _forward_backward_multires(self, samples, txt, grad_scale=1.0):
+def _forward_backward_multires(self, samples, txt, grad_scale=1.0, sync=True):
     b = _build_multires_batch(self, samples, txt)
     dit = self.dit
     B, S_i, T = b["inp"].shape[0], b["inp"].shape[1], b["pe"].shape[1]
@@ -132,7 +146,7 @@ def _forward_backward_multires(self, samples, txt, grad_scale=1.0):
     pred = plan.run_forward((b["inp"], b["pooled"], b["guidance"]), b["pe"], b["timestep"])
     loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, b["target"], b["tok_w"].contiguous(), b["n_t_max"], 1.0 / (b["n_valid"] + 1e-12),
                                                  gscale=grad_scale)
-    plan.run_backward(dpred, on_segment=self._bucket_hook() if self.world > 1 else None)
+    plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
     return loss
 
 

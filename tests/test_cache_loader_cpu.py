@@ -1,4 +1,5 @@
 """Cache-only loader on CPU: the reference's on-disk layout, collate semantics, rank-strided sharding."""
+import glob
 import os
 import sys
 
@@ -66,3 +67,52 @@ def test_prefetch_loader_shards_disjointly(tmp_path):
     ld.set_epoch(3)
     c = [h for b in ld for h in b["main_hash"]]
     assert a == b_ and a != c and sorted(a) == sorted(c)
+
+
+def test_every_rank_gets_the_same_number_of_batches(tmp_path):
+    """10 samples over 4 ranks used to give 3,3,2,2 batches: the ranks with the extra batch then hang in the step's collectives.
+    The reference's accelerate-prepared DataLoader yields the same count on every rank (base_trainer.py:378-393)."""
+    from qflux_amd.data import CachedEmbeddingDataset, PrefetchLoader
+    _make_cache(tmp_path, n=10)
+    ds = CachedEmbeddingDataset(str(tmp_path))
+    for world, bs, drop_last, want in ((4, 1, True, 2), (4, 1, False, 3), (3, 2, True, 1), (3, 2, False, 2), (2, 5, True, 1)):
+        lens, seen = [], []
+        for r in range(world):
+            ld = PrefetchLoader(ds, batch_size=bs, device="cpu", rank=r, world=world, seed=3, workers=2, drop_last=drop_last)
+            got = [h for b in ld for h in b["main_hash"]]
+            lens.append(len(ld))
+            assert len(got) == len(ld) * bs
+            seen += got
+        assert lens == [want] * world, (world, bs, drop_last, lens)
+        if drop_last:
+            assert len(set(seen)) == len(seen)               # disjoint shards
+        else:
+            assert len(set(seen)) == 10                      # wrap-around padding covers every sample
+
+
+def test_prefetch_window_bounds_the_staged_batches(tmp_path):
+    """The readers must not run ahead of the consumer by more than `prefetch` batches (pinned host memory is bounded)."""
+    import time
+    from qflux_amd.data import CachedEmbeddingDataset, PrefetchLoader
+    _make_cache(tmp_path, n=24)
+    ds = CachedEmbeddingDataset(str(tmp_path))
+    for prefetch in (1, 3):
+        ld = PrefetchLoader(ds, batch_size=1, device="cpu", seed=1, workers=6, prefetch=prefetch)
+        n = 0
+        for _ in ld:
+            time.sleep(0.01)      # a slow consumer: fast readers would otherwise stage the whole epoch
+            n += 1
+        assert n == 24 and 1 <= ld.stats["staged_max"] <= prefetch, ld.stats
+
+
+def test_loader_surfaces_reader_errors(tmp_path):
+    from qflux_amd.data import CachedEmbeddingDataset, PrefetchLoader
+    _make_cache(tmp_path, n=4)
+    ds = CachedEmbeddingDataset(str(tmp_path))
+    os.remove(glob.glob(str(tmp_path / "image_latents" / "*.pt"))[0])
+    ld = PrefetchLoader(ds, batch_size=1, device="cpu", shuffle=False, workers=2)
+    try:
+        list(ld)
+    except FileNotFoundError:
+        return
+    raise AssertionError("a missing cache file must raise in the consumer, not hang it")
