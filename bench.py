@@ -124,10 +124,11 @@ def run_profiled(prog, fn_target, hbm=None):
     return evs
 
 
-def cpu_baseline(cfg_dims, blocks=1, steps=1):
-    """The oracle (a CPU restatement of the reference's module graph, fp32 eager PyTorch) timed on this host's
-    cores on a BOUNDED sample: K=1 of the 60 blocks + head/tail at the full sequence length, one forward+backward+AdamW
-    step on the LoRA params (no warm-up: eager CPU has nothing to warm), extrapolated x(60/K)."""
+def cpu_baseline(cfg_dims, blocks=2, warmup=1, steps=3):
+    """The oracle (a CPU restatement of the reference's module graph, fp32 eager PyTorch) timed on this host's cores on a
+    BOUNDED sample (BASELINE.md section 3 protocol): K=2 of the 60 blocks + head/tail at the full sequence length,
+    forward+backward+AdamW on the LoRA params, 1 warm-up step (allocator, thread pool) + 3 timed steps; the per-block time is
+    measured as (K-block step) / K with head/tail included, extrapolated x(60/K)."""
     sys.path.insert(0, ROOT)
     from oracle import qwen_dit as O
     D_h, H, Jd, S_t, T = cfg_dims
@@ -141,18 +142,60 @@ def cpu_baseline(cfg_dims, blocks=1, steps=1):
                prompt_embeds=torch.randn(1, T, Jd) * 4, prompt_embeds_mask=torch.ones(1, T, dtype=torch.int64),
                img_shapes=[[(1, 32, 32), (1, 32, 32)]])
     times = []
-    for i in range(steps):
+    for i in range(warmup + steps):
         t0 = time.time()
         loss = O.qwen_compute_loss(m, emb, torch.randn(1, S_t, 64), torch.rand(1), torch.float32)
         loss.backward()
         opt.step()
         opt.zero_grad()
-        times.append(time.time() - t0)
+        if i >= warmup:
+            times.append(time.time() - t0)
     per_step = sum(times) / len(times)
     full = per_step * (60.0 / blocks)
     return {"value": 1.0 / full, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{blocks} of 60 DiT blocks + head/tail, fp32 eager, B=1, 512^2 (S_i=2048,T={T}), fwd+bwd+AdamW, "
-                      f"{steps} timed steps of {per_step:.2f} s, extrapolated x{60 // blocks}"}
+            "sample": f"{blocks} of 60 DiT blocks + head/tail, fp32 eager, B=1, 512^2 (S_i={2 * S_t},T={T}), fwd+bwd+AdamW, "
+                      f"{warmup} warm-up + {steps} timed steps of {per_step:.2f} s (min {min(times):.2f}, max {max(times):.2f}), "
+                      f"extrapolated x{60 // blocks}"}
+
+
+def _git_blob_sha1(path):
+    """`git hash-object` of a file (so the bench line names exactly which committed PMC summary `traffic` came from)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_traffic(kernel="gemm256_kernel"):
+    """HBM-side traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the newest committed
+    rocprofv3 summary profiles/rNN_pmc_hbm.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, converted
+    by tools/pmc_to_json.py with the gfx950 FETCH_SIZE x2 correction) gives bytes per launch of the same kernel on the same
+    workload.  Returns (bytes per launch | None, {"file", "git_blob"})."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm.json")))
+    if not files:
+        return None, None
+    path = files[-1]
+    try:
+        with open(path) as fh:
+            t = json.load(fh)["kernels"][kernel]["traffic_bytes_per_launch"]
+        return t, {"file": os.path.relpath(path, ROOT), "git_blob": _git_blob_sha1(path)}
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (one process per GPU, RCCL) and
+    relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -166,6 +209,8 @@ def main():
     ap.add_argument("--rank", type=int, default=16, help="LoRA rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args.gpus))
 
     from qflux_amd.models import QwenImageTransformer2DModel
     from qflux_amd.modules import LoraConfig
@@ -249,16 +294,39 @@ def main():
     cfgd = dit.config
     fwd_fl, bwd_fl = algorithmic_flops(cfgd.num_layers, dit.inner_dim, 2 * S_t, T, Jd, cfgd.in_channels, dit.proj_out.out_features,
                                        args.rank, 4)
-    # HBM-side traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the committed
-    # rocprofv3 passes (profiles/r01_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command,
-    # FETCH_SIZE x2 gfx950 correction) give bytes per launch of the same kernel on the same workload.
-    traffic = None
-    try:
-        if B == 1 and args.layers == 60 and args.res == 512 and args.rank == 16:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
-                traffic = json.load(fh)["kernels"]["gemm256_kernel"]["traffic_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        traffic = None
+    traffic, traffic_src = (None, None)
+    if B == 1 and args.layers == 60 and args.res == 512 and args.rank == 16:
+        traffic, traffic_src = pmc_traffic()
+
+    # ---- data-parallel exchange: what the bucketed all-reduce costs on top of the step, and how much of it the backward hides
+    dp = None
+    if world > 1:
+        gflat = dit.lora_store.gflat
+        k2 = max(2, min(args.steps, 10))
+        step.world = 1                      # same step without the gradient exchange (measurement only: replicas would diverge)
+        step.train_step(emb)
+        dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step.train_step(emb)
+        dist.barrier(); torch.cuda.synchronize()
+        noex = (time.perf_counter() - t1) / k2 * 1e3
+        step.world = world
+        dist.all_reduce(gflat); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_reduce(gflat)
+        torch.cuda.synchronize()
+        alone = (time.perf_counter() - t1) / 5 * 1e3
+        vals = torch.tensor([noex, alone], dtype=torch.float64, device=dev)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        noex, alone = vals.tolist()
+        exposed = max(0.0, ms_per_step - noex)
+        dp = {"collective": "all_reduce(SUM) of the flat fp32 LoRA gradient, bucketed behind the backward", "backend": dist.get_backend(),
+              "bytes_per_step": gflat.numel() * 4, "bucket_mb": step.bucket_bytes / (1 << 20),
+              "ms_per_step_without_exchange": round(noex, 3), "allreduce_alone_ms": round(alone, 3),
+              "exposed_ms_per_step": round(exposed, 3), "hidden_ms_per_step": round(max(0.0, alone - exposed), 3)}
+        step.zero_grad()
     out = {
         "metric": "train images/sec, Qwen-Image-Edit LoRA r=16 bf16 512^2, cached-embed",
         "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,6 +342,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "gemm256_kernel / gemm_kernel (qfx_gemm_grouped + qfx_gemm_bf16, all epilogue variants)",
                      "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic, "traffic_unit": "bytes per launch, L2 fabric side incl. Infinity-Cache hits (committed PMC pass)",
+                     "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(gemm_bytes_of(plan.fwd, plan.bwd) / n_launch),
                      "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
                      "gemm_share_of_step": round(gemm_ms / ms_per_step, 3)},
@@ -284,6 +353,8 @@ def main():
                             "ms_per_step": round(sum(a.elapsed_time(b) for a, b in v[0]), 3), "launches": v[2]}
                         for k, v in sorted(hbm.items())},
     }
+    if dp is not None:
+        out["dp_exchange"] = dp
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline((cfgd.attention_head_dim, cfgd.num_attention_heads, Jd, S_t, T))

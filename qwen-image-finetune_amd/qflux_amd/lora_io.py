@@ -20,11 +20,22 @@ WEIGHT_NAME = "pytorch_lora_weights.safetensors"
 
 
 def classify_lora_keys(keys) -> str:
+    """Same labels as the reference's classify_lora_weight (src/qflux/utils/lora_utils.py:12-22) on a file's key list; pinned by
+    tests/golden/ref_lora_classify.json (labels assigned by the reference's own function)."""
+    keys = list(keys)
     peft = any(re.search(r"\.lora_[AB](\.|$)", k) for k in keys)
     diff = any(".lora.down.weight" in k or ".lora.up.weight" in k for k in keys)
     if peft and not diff:
         return "PEFT"
-    return "DIFFUSERS" if diff else "UNKNOWN"
+    if diff:
+        return "DIFFUSERS(attn-processor)" if any(".processor" in k for k in keys) else "DIFFUSERS"
+    return "UNKNOWN"
+
+
+# diffusers.utils.convert_state_dict_to_diffusers (PEFT -> DIFFUSERS table, third party, restated -- parity unpinned): only the
+# attention projections below are renamed to `.lora.down/.lora.up`; every other adapted module keeps `.lora_A/.lora_B.weight`.
+# A file the reference saves with broad targets (all-linear) therefore carries BOTH spellings; the loaders accept either per key.
+_DIFFUSERS_RENAMED = ("to_q", "to_k", "to_v", "to_out.0")
 
 
 def get_lora_state_dict(model, style: str = "diffusers", prefix: str = "transformer.") -> dict:
@@ -32,9 +43,12 @@ def get_lora_state_dict(model, style: str = "diffusers", prefix: str = "transfor
     for name, m in model.named_modules():
         if isinstance(m, QfxLoraLinear):
             a, b = m.A.detach().cpu().contiguous(), m.B.detach().cpu().contiguous()
-            if style == "diffusers":
+            if style == "diffusers" and name.endswith(_DIFFUSERS_RENAMED):
                 out[f"{prefix}{name}.lora.down.weight"] = a
                 out[f"{prefix}{name}.lora.up.weight"] = b
+            elif style == "diffusers":
+                out[f"{prefix}{name}.lora_A.weight"] = a
+                out[f"{prefix}{name}.lora_B.weight"] = b
             else:  # peft (adapter name stripped, as get_peft_model_state_dict does)
                 out[f"{name}.lora_A.weight"] = a
                 out[f"{name}.lora_B.weight"] = b

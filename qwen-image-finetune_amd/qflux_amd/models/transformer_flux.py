@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from ..plan_cache import PlanCache, ladder
 from ..modules import LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm
 from .transformer_qwenimage import (BF, F32, QfxAttention, QfxFeedForward, QwenImageTransformer2DModel, _AdaLNOut, _Cfg, _LinW,
                                     _Prog, _QwenPlan, _TimestepEmbedder, _ceil, _ptr)
@@ -121,7 +122,7 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
         self._adapter_name = None
         self._prepared = None
         self._lora_prep = None
-        self._plans = {}
+        self._plans = PlanCache()
         self._version = 0
         self._rope_cache = {}
 
@@ -252,21 +253,19 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
         self._prepare()
         self._prepare_lora()
         key = (B, S_i, T, rkey, self._version)
-        if key not in self._plans:
-            self._plans[key] = _FluxPlan(self, B, S_i, T, ids)
-        return self._plans[key]
+        return self._plans.get_or_build(key, lambda: _FluxPlan(self, B, S_i, T, ids))
 
 
 def _get_plan_multires(self, B, S_i, T, img_ids, valid_lens):
-    """Multi-resolution plan (one per padded shape); RoPE / masks are refreshed every call."""
+    """Multi-resolution plan: one per LADDER size of the padded shape, in an LRU-bounded cache (plan_cache.py); rows between the
+    batch maximum and the ladder size are further padded rows.  RoPE / masks are refreshed every call."""
     if img_ids.ndim == 2:
         img_ids = img_ids.unsqueeze(0).expand(B, -1, -1)
     self._prepare()
     self._prepare_lora()
-    key = (B, S_i, T, "multires", self._version)
-    if key not in self._plans:
-        self._plans[key] = _FluxPlan(self, B, S_i, T, None, multires=True)
-    plan = self._plans[key]
+    S_plan = ladder(S_i)
+    key = (B, S_plan, T, "multires", self._version)
+    plan = self._plans.get_or_build(key, lambda: _FluxPlan(self, B, S_plan, T, None, multires=True))
     plan.set_multires(img_ids, valid_lens)
     return plan
 
@@ -590,7 +589,7 @@ class _FluxPlan(_QwenPlan):
     def run_forward(self, inputs, encoder_hidden_states, timestep):
         hidden_states, pooled, guidance = inputs
         A = self.A
-        A["in_img"].view(self.B, self.S_i, -1).copy_(hidden_states)
+        self._copy_rows(A["in_img"].view(self.B, self.S_i, -1), hidden_states)
         A["in_txt"].view(self.B, self.T, -1)[:, :, : encoder_hidden_states.shape[-1]].copy_(encoder_hidden_states)
         A["pooled"].copy_(pooled)
         A["t"].copy_(timestep.reshape(self.B).to(F32))

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from ..plan_cache import PlanCache, ladder
 from ..modules import (LoraConfig, LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm, init_lora_, match_target)
 from ..rope import QwenEmbedRope, normalize_img_shapes, qwen_joint_rope
 
@@ -189,7 +190,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self._adapter_name = None
         self._prepared = None      # prepared weights
         self._lora_prep = None     # packed-operand buffers + descriptors
-        self._plans = {}
+        self._plans = PlanCache()
         self._version = 0
 
     # ------------------------------------------------------------------ reference-surface methods
@@ -208,7 +209,7 @@ class QwenImageTransformer2DModel(nn.Module):
     def _invalidate(self):
         self._prepared = None
         self._lora_prep = None
-        self._plans = {}
+        self._plans = PlanCache()
         self._version += 1
 
     def _apply(self, fn, *a, **k):
@@ -300,7 +301,7 @@ class QwenImageTransformer2DModel(nn.Module):
         if not self._lora.is_consistent(self.device):
             self._lora.rebuild(self.device)
             self._lora_prep = None
-            self._plans = {}
+            self._plans = PlanCache()
         self._lora.ensure_grads()
 
     def _prepare(self):
@@ -485,20 +486,18 @@ class QwenImageTransformer2DModel(nn.Module):
         self._prepare()
         self._prepare_lora()
         key = (B, S_i, T, shapes, self._version)
-        if key not in self._plans:
-            self._plans[key] = _QwenPlan(self, B, S_i, T, shapes)
-        return self._plans[key]
+        return self._plans.get_or_build(key, lambda: _QwenPlan(self, B, S_i, T, shapes))
 
     def get_plan_multires(self, B, S_i, T, img_shapes, txt_seq_lens, attention_mask):
-        """One plan per padded shape (B, S_max, T); the per-batch contents (per-sample RoPE, key mask, row masks) are refreshed
-        on every call."""
+        """One plan per LADDER size of the padded shape (B, ladder(S_max), T) in an LRU-bounded cache (plan_cache.py): the rows
+        between S_max and the ladder size are further padded rows of the masked program.  The per-batch contents (per-sample
+        RoPE, key mask, row masks) are refreshed on every call."""
         self._prepare()
         self._prepare_lora()
-        key = ("multires", B, S_i, T, self._version)
-        if key not in self._plans:
-            self._plans[key] = _QwenPlan(self, B, S_i, T, None, multires=True)
-        plan = self._plans[key]
-        plan.set_multires(img_shapes, txt_seq_lens, attention_mask)
+        S_plan = ladder(S_i)
+        key = ("multires", B, S_plan, T, self._version)
+        plan = self._plans.get_or_build(key, lambda: _QwenPlan(self, B, S_plan, T, None, multires=True))
+        plan.set_multires(img_shapes, txt_seq_lens, attention_mask, S_in=S_i)
         return plan
 
 
@@ -1107,7 +1106,7 @@ class _QwenPlan:
         else:
             self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
 
-    def set_multires(self, img_shapes, txt_seq_lens, attention_mask):
+    def set_multires(self, img_shapes, txt_seq_lens, attention_mask, S_in=None):
         """Per-batch tables of the multi-resolution path (host-side plumbing of transformer_qwen_custom.py:72-150,175-228,
         444-512).  Per sample the joint table [text rows | image rows] starts at joint row 0, i.e. the image rows follow the
         sample's OWN text length (the reference's placement); every other row keeps the identity rotation."""
@@ -1133,9 +1132,14 @@ class _QwenPlan:
         km = torch.zeros(B, S)
         rm_i = torch.ones(B, S_i)
         rm_t = torch.ones(B, T)
-        if attention_mask is not None:
-            m = attention_mask if attention_mask.dtype == torch.bool else attention_mask > 0
-            m = m[:, :S].cpu()
+        S_in = S_i if S_in is None else S_in          # image rows the caller hands over; rows S_in..S_i are ladder padding
+        if attention_mask is not None or S_in < S_i:
+            m = torch.zeros(B, S, dtype=torch.bool)
+            if attention_mask is not None:
+                am = attention_mask if attention_mask.dtype == torch.bool else attention_mask > 0
+                m[:, : T + S_in] = am[:, : T + S_in].cpu()
+            else:
+                m[:, : T + S_in] = True
             km.masked_fill_(~m, float("-inf"))
             rm_i = m[:, T:].float()
             rm_t = m[:, :T].float()
@@ -1148,19 +1152,29 @@ class _QwenPlan:
     # ------------------------------------------------------------------ execution
     def run_forward(self, hidden_states, encoder_hidden_states, timestep):
         A = self.A
-        A["in_img"].view(self.B, self.S_i, -1).copy_(hidden_states)
+        self._copy_rows(A["in_img"].view(self.B, self.S_i, -1), hidden_states)
         A["in_txt"].view(self.B, self.T, -1).copy_(encoder_hidden_states)
         A["t"].copy_(timestep.reshape(self.B).to(F32))
         self.model.refresh_lora_operands()
         self.fwd.run()
         return A["out"].view(self.B, self.S_i, -1)
 
+    @staticmethod
+    def _copy_rows(dst, src):
+        """dst [B, S_plan, C] <- src [B, S_in <= S_plan, C]; the ladder-padding rows (masked everywhere) are zeroed."""
+        n = src.shape[1]
+        if n == dst.shape[1]:
+            dst.copy_(src)
+        else:
+            dst[:, :n].copy_(src)
+            dst[:, n:].zero_()
+
     def run_backward(self, dpred, on_segment=None):
         """on_segment(prefixes): called after each marked segment of the backward program with the parameter-name prefixes
         whose LoRA gradients just became final (data-parallel bucketed all-reduce hooks in here)."""
         if getattr(self.model, "_merged", False):
             raise RuntimeError("adapters are merged into the base weights (merge_adapter): call unmerge_adapter() before training")
-        self.A["dpred"].view(self.B, self.S_i, -1).copy_(dpred)
+        self._copy_rows(self.A["dpred"].view(self.B, self.S_i, -1), dpred)
         self.model._lora.ensure_grads()
         if on_segment is None:
             self.bwd.run()
@@ -1181,7 +1195,8 @@ class _QwenDiTFn(torch.autograd.Function):
     def forward(ctx, model, plan, hidden_states, encoder_hidden_states, timestep, *lora_params):
         ctx.plan = plan
         out = plan.run_forward(hidden_states, encoder_hidden_states, timestep)
-        return out.clone()
+        n = (hidden_states[0] if isinstance(hidden_states, tuple) else hidden_states).shape[1]
+        return out[:, :n].clone()      # a ladder plan carries more rows than the caller handed over
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -252,7 +252,7 @@ def import_reference_flux():
 
 
 sys.path.insert(0, HERE)
-from common import TINY, fill_weights, weight_checksum  # noqa: E402
+from common import FLUX_TINY, TINY, fill_weights, weight_checksum  # noqa: E402
 
 
 def tiny_inputs(seed=0, B=2, shapes=((1, 4, 6), (1, 4, 6)), T=5):
@@ -264,6 +264,109 @@ def tiny_inputs(seed=0, B=2, shapes=((1, 4, 6), (1, 4, 6)), T=5):
         timestep=torch.tensor([0.7109, 0.1611][:B]),  # constants of tests/e2e/test_flux_loss.py:119
         mask=torch.ones(B, T, dtype=torch.int64),
     ), [list(map(tuple, shapes))] * B, [T] * B
+
+
+
+def import_reference_by_path(*mods):
+    """Import reference modules by file path without executing qflux/__init__.py (it needs dotenv + a HF login).  The two
+    third-party hash libraries qflux/utils/tools.py imports at module level (imagehash, blake3: absent offline, used only inside
+    hashing helpers that the cache save/load path never calls) are satisfied by empty stand-in modules."""
+    for name in ("imagehash", "blake3"):
+        try:
+            importlib.import_module(name)
+        except Exception:  # noqa: BLE001
+            mod = types.ModuleType(name)
+            mod.blake3 = None
+            sys.modules[name] = mod
+    for pk, sub in (("qflux", ""), ("qflux.utils", "utils"), ("qflux.data", "data")):
+        if pk not in sys.modules:
+            m = types.ModuleType(pk)
+            m.__path__ = [os.path.join(REF, "src", "qflux", sub)]
+            sys.modules[pk] = m
+    return [importlib.import_module(m) for m in mods]
+
+
+def make_f1_f3_fixtures():
+    """SURVEY 8(f1)/(f3) pins, produced by the reference's OWN code:
+      tests/golden/ref_cache/            a 3-sample embedding cache written by EmbeddingCacheManager.save_cache_embedding
+                                         (src/qflux/data/cache_manager.py:48-93)
+      tests/golden/ref_cache_expected.safetensors   what EmbeddingCacheManager.load_cache returns for each sample (plain and with
+                                         replace_empty_embeddings), + the tensors that were handed to the writer
+      tests/golden/ref_lora_classify.json   labels given by classify_lora_weight (src/qflux/utils/lora_utils.py:12-22) to (a) the
+                                         key sets of the reference's own tests (tests/src/utils/test_lora_utils.py:16-52) and (b) the
+                                         files qflux_amd.lora_io writes in both key styles
+    """
+    import json
+    import shutil
+    cm, lu = import_reference_by_path("qflux.data.cache_manager", "qflux.utils.lora_utils")
+    root = os.path.join(HERE, "ref_cache")
+    shutil.rmtree(root, ignore_errors=True)
+    mgr = cm.EmbeddingCacheManager(root)
+    g = torch.Generator().manual_seed(20260926)
+    expected = {}
+    samples = []
+    for i in range(3):
+        S_t = (12, 20, 12)[i]
+        S_c = (12, 20, 24)[i]                 # sample 2: two control images
+        T = 5 + i
+        data = dict(image_latents=torch.randn(S_t, 64, generator=g), control_latents=torch.randn(S_c, 64, generator=g),
+                    prompt_embeds=torch.randn(T, 32, generator=g) * 4, prompt_embeds_mask=torch.ones(T, dtype=torch.int64),
+                    empty_prompt_embeds=torch.randn(2, 32, generator=g), empty_prompt_embeds_mask=torch.ones(2, dtype=torch.int64))
+        hash_maps = dict(image_latents="image_hash", control_latents="control_hash", prompt_embeds="prompt_hash",
+                         prompt_embeds_mask="prompt_hash", empty_prompt_embeds="empty_prompt_hash",
+                         empty_prompt_embeds_mask="empty_prompt_hash")
+        fh = dict(main_hash=f"{i:04x}main", image_hash=f"{i:04x}img", control_hash=[f"{i:04x}ctl"], prompt_hash=f"{i:04x}txt",
+                  empty_prompt_hash="emptyprompt")
+        shapes = [[3, 48, 64], [3, 48, 64]] if i < 2 else torch.tensor([[3, 48, 64], [3, 48, 64], [3, 48, 64]])
+        mgr.save_cache_embedding(data, hash_maps, fh, img_shapes=shapes)
+        samples.append((data, fh))
+        for k, v in data.items():
+            expected[f"in.{i}.{k}"] = v.clone()
+    for i, (data, fh) in enumerate(samples):
+        got = mgr.load_cache({"file_hashes": {"main_hash": fh["main_hash"]}})
+        for k, v in got.items():
+            if isinstance(v, torch.Tensor):
+                expected[f"load.{i}.{k}"] = v.clone()
+        got = mgr.load_cache({"file_hashes": {"main_hash": fh["main_hash"]}}, replace_empty_embeddings=True,
+                             prompt_empty_drop_keys=["empty_prompt_embeds", "empty_prompt_embeds_mask"])
+        for k, v in got.items():
+            if isinstance(v, torch.Tensor):
+                expected[f"load_drop.{i}.{k}"] = v.clone()
+    assert cm.EmbeddingCacheManager.exist(root)
+    save_file({k: v.contiguous() for k, v in expected.items()}, os.path.join(HERE, "ref_cache_expected.safetensors"),
+              metadata={"writer": "EmbeddingCacheManager.save_cache_embedding (reference)", "reader": "EmbeddingCacheManager.load_cache"})
+    # ---- f3: the reference's classifier on its own test vectors and on the files this repo writes
+    import safetensors.torch as st
+    sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.models import FluxTransformer2DModel, QwenImageTransformer2DModel
+    out = {"reference_test_vectors": [], "repo_written_files": []}
+    tmp = tempfile.mkdtemp()
+    vecs = [["model.layer.lora_A", "model.layer.lora_B"], ["model.layer.lora.down.weight", "model.layer.lora.up.weight"],
+            ["model.layer.processor.lora.down.weight", "model.layer.processor.lora.up.weight"], ["model.layer.weight"]]
+    for j, keys in enumerate(vecs):
+        f = os.path.join(tmp, f"v{j}.safetensors")
+        st.save_file({k: torch.zeros(2, 2) for k in keys}, f)
+        out["reference_test_vectors"].append({"keys": keys, "label": lu.classify_lora_weight(f)})
+    for tag, model, targets in (
+            ("qwen_default_targets", QwenImageTransformer2DModel(**TINY), ["to_k", "to_q", "to_v", "to_out.0"]),
+            ("qwen_attention_and_ff", QwenImageTransformer2DModel(**TINY), ["to_k", "to_q", "to_v", "to_out.0", "net.0.proj", "net.2"]),
+            ("flux_attention_both_streams", FluxTransformer2DModel(**FLUX_TINY), ["to_q", "to_k", "to_v", "to_out.0", "add_q_proj", "to_add_out"])):
+        model.add_adapter(LoraConfig(r=4, lora_alpha=8, target_modules=targets), "lora_edit", generator=torch.Generator().manual_seed(0))
+        for style in ("diffusers", "peft"):
+            path = model.save_lora_weights(os.path.join(tmp, tag + "_" + style), style=style)
+            out["repo_written_files"].append({"model": tag, "targets": targets, "style": style, "label": lu.classify_lora_weight(path),
+                                              "keys": sorted(st.load_file(path).keys())})
+        # the accelerate `model.safetensors` flavour: full state-dict names incl. the adapter name (what the reference's PEFT branch
+        # feeds to load_state_dict(strict=False), base_trainer.py:985-990)
+        f = os.path.join(tmp, tag + "_statedict.safetensors")
+        st.save_file({k: v.detach().clone() for k, v in model.state_dict().items() if "lora" in k}, f)
+        out["repo_written_files"].append({"model": tag, "targets": targets, "style": "state_dict", "label": lu.classify_lora_weight(f),
+                                          "keys": sorted(st.load_file(f).keys())})
+    with open(os.path.join(HERE, "ref_lora_classify.json"), "w") as fjs:
+        json.dump(out, fjs, indent=1)
+    print("f1/f3: wrote ref_cache/ (reference writer), ref_cache_expected.safetensors (reference reader), ref_lora_classify.json:",
+          [(e["model"], e["style"], e["label"]) for e in out["repo_written_files"]])
 
 
 def main():
@@ -500,8 +603,13 @@ def main():
     assert abs(O.mse_loss(pr, tg).item() - out["mse"].item()) < 1e-6
     save_file({k: v.contiguous().clone() for k, v in out.items()}, os.path.join(HERE, "losses.safetensors"))
     print("criteria: oracle == reference MseLoss / MaskEditLoss / AttentionMaskMseLoss / map_mask_to_latent")
+    make_f1_f3_fixtures()
     print("wrote golden vectors to", HERE)
 
 
 if __name__ == "__main__":
-    main()
+    if "--f1f3" in sys.argv:      # only the cache / LoRA-file pins (does not need the diffusers shim)
+        from common import FLUX_TINY, TINY  # noqa: F401
+        make_f1_f3_fixtures()
+    else:
+        main()

@@ -148,3 +148,80 @@ def test_flux_multires_step_matches_oracle(fused):
     print("multires", fused, "loss", loss_o.item(), loss_h.item(), "pred rel", e_pred, "grad worst", worst)
     assert abs(loss_h.item() - loss_o.item()) / abs(loss_o.item()) < 2e-2
     assert e_pred < 4e-2 and worst < 8e-2
+
+
+def test_multires_plan_cache_is_bounded_over_20_distinct_ragged_batches():
+    """cfg #5: bucketed batches arrive with a continuum of padded lengths.  The plans live on a ladder of lengths in an LRU cache
+    with a byte budget (plan_cache.py): 20 distinct ragged batches build only a few plans, device memory stops growing, and a
+    batch that re-uses a ladder size gives the same loss as on its first visit (no stale per-batch state in a cached plan)."""
+    import gc
+    import random
+    from common import FLUX_TINY
+    from qflux_amd.models import FluxTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.plan_cache import PlanCache, ladder
+    from qflux_amd.trainer import FluxKontextTrainStep
+    cfg = dict(FLUX_TINY, guidance_embeds=True, joint_attention_dim=64)
+    with torch.device(DEV):
+        m = FluxTransformer2DModel(**cfg)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * (0.5 / p.shape[-1] ** 0.5 if p.ndim == 2 else 0.05) + (1.0 if "norm_" in n and p.ndim == 1 else 0.0)).to(p.dtype))
+    m.add_adapter(LoraConfig(r=4, lora_alpha=8), "a", generator=g)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.02)
+    step = FluxKontextTrainStep(m)
+    rng = random.Random(5)
+    T = 7
+
+    def batch(seed):
+        gg = torch.Generator().manual_seed(seed)
+        r = random.Random(seed)
+        samples = []
+        for _ in range(2):
+            h, w = r.randint(4, 22), r.randint(4, 22)
+            ch, cw = r.randint(4, 22), r.randint(4, 22)
+            samples.append(dict(image_latents=torch.randn(h * w, 64, generator=gg).half(), control_latents=torch.randn(ch * cw, 64, generator=gg).half(),
+                                hw=(h, w), control_hw=[(ch, cw)], noise=torch.randn(h * w, 64, generator=gg).to(BF),
+                                t=torch.rand((), generator=gg).to(BF)))
+        txt = dict(text_ids=torch.zeros(T, 3), pooled_prompt_embeds=torch.randn(2, 16, generator=gg).half(),
+                   prompt_embeds=torch.randn(2, T, 64, generator=gg).half())
+        return samples, txt
+
+    first = {}
+    lens = set()
+    mem = []
+    for i in range(20):
+        samples, txt = batch(100 + i)
+        lens.add(max(s["image_latents"].shape[0] + s["control_latents"].shape[0] for s in samples))
+        first[i] = step.forward_backward_multires(samples, txt).item()
+        step.zero_grad()
+        torch.cuda.synchronize()
+        mem.append(torch.cuda.memory_allocated())
+    plans = m._plans
+    assert isinstance(plans, PlanCache)
+    sizes = {ladder(n) for n in lens}
+    print("distinct padded lengths", len(lens), "ladder sizes", len(sizes), "plans built", plans.builds, "cached", len(plans),
+          "MB", [round(x / 2**20) for x in mem])
+    assert len(lens) >= 15 and plans.builds == len(sizes) <= 8
+    # replay: same batches -> no new plan, identical losses (fp32 atomics in the loss reduction aside), no memory growth
+    for i in range(20):
+        samples, txt = batch(100 + i)
+        l2 = step.forward_backward_multires(samples, txt).item()
+        step.zero_grad()
+        assert abs(l2 - first[i]) <= 1e-5 * abs(first[i]), (i, l2, first[i])
+    torch.cuda.synchronize()
+    assert plans.builds == len(sizes) and torch.cuda.memory_allocated() <= max(mem) * 1.02
+    # a tight byte budget evicts least-recently-used plans and gives their arena back
+    biggest = max(plans.sizes.values())
+    plans._budget = int(biggest * 1.5)
+    plans._evict(keep=next(reversed(plans)))
+    gc.collect()
+    torch.cuda.synchronize()
+    assert plans.total_bytes() <= plans._budget and len(plans) < len(sizes)
+    assert torch.cuda.memory_allocated() < max(mem)
+    samples, txt = batch(100)
+    assert abs(step.forward_backward_multires(samples, txt).item() - first[0]) <= 1e-5 * abs(first[0])     # rebuilt on demand
