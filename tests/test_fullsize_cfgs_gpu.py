@@ -92,7 +92,7 @@ def test_attention_s8576_all_heads_vs_fp32_sdpa():
     print("attention S=8576 H=24 dh=128 rel-to-max errors:", {k: round(v, 5) for k, v in worst.items()})
     assert worst["o"] < 1e-2 and worst["lse"] < 1e-3 and worst["dsum"] < 2e-2
     assert worst["dq"] < 2e-2 and worst["dk"] < 2e-2 and worst["dv"] < 2e-2
-    assert lse2[0, :, S:].abs().max().item() == 0.0      # pad columns of the statistics stay untouched
+    assert S_pad == S or lse2[0, :, S:].abs().max().item() == 0.0      # pad columns of the statistics stay untouched
 
 
 # ---------------------------------------------------------------------------------------------- cfg #3
