@@ -126,10 +126,14 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
         self._version = 0
         self._rope_cache = {}
 
+    _HEAD_SITES = {"x_embedder": "x_in", "context_embedder": "c_in", "proj_out": "proj_out"}
+
     def _lora_supported(self, name: str) -> bool:
+        if name in self._HEAD_SITES:
+            return True
         if name.startswith("transformer_blocks."):
             return name.endswith(self._LORA_SUFFIXES)
-        return name.startswith("single_transformer_blocks.") and name.endswith(("attn.to_q", "attn.to_k", "attn.to_v"))
+        return name.startswith("single_transformer_blocks.") and name.endswith(("attn.to_q", "attn.to_k", "attn.to_v", "proj_mlp", "proj_out"))
 
     # ------------------------------------------------------------------ preparation
     def _prepare(self):
@@ -202,14 +206,30 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
         for w, blk in zip(P["singles"], self.single_transformer_blocks):
             a = blk.attn
 
-            def make_wet(Kext, w=w):
+            # adapters on proj_mlp / proj_out (configs/face_seg_flux_kontext_fp16.yaml:11) are stand-alone sites; proj_mlp's
+            # backward K-extension joins segment 2 of the block's dX GEMM: [W_mlp^T | WeT(q) WeT(k) WeT(v) | WeT(mlp)]
+            max_dim = max(max_dim, self._prep_site_lora(w["mlp"], descs), self._prep_site_lora(w["out"], descs))
+            kx_mlp = w["mlp"].lora.Kext if w["mlp"].lora is not None else 0
+
+            def make_wet(Kext, w=w, kx_mlp=kx_mlp):
                 # dX B operand of the single block: [W_mlp^T | WeT(q) WeT(k) WeT(v)] so the LoRA K-extension rides in segment 2
-                b2 = torch.zeros(D, 4 * D + 3 * Kext, dtype=BF, device=dev)
+                b2 = torch.zeros(D, 4 * D + 3 * Kext + kx_mlp, dtype=BF, device=dev)
                 b2[:, : 4 * D].copy_(w["mlp"].WT)
                 w["B2"] = b2
-                return b2[:, 4 * D:]
+                return b2[:, 4 * D: 4 * D + 3 * Kext]
 
             max_dim = max(max_dim, self._prep_qkv_lora(w, "", [a.to_q, a.to_k, a.to_v], descs, WeT=make_wet))
+            if kx_mlp:
+                if w["qkv_lora"] is None:
+                    make_wet(0)
+                # the packed WeT of proj_mlp must live inside B2: re-point the adapter's WeT (and its pack descriptor) there
+                lo = w["mlp"].lora
+                kq = 3 * w["qkv_lora"]["Kext"] if w["qkv_lora"] is not None else 0
+                lo.WeT = w["B2"][:, 4 * D + kq: 4 * D + kq + kx_mlp]
+                for d_ in descs:
+                    if d_.A == lo.mod.A.data_ptr():
+                        d_.WeT, d_.ld_wet = lo.WeT.data_ptr(), lo.WeT.stride(0)
+        max_dim = max(max_dim, self._prep_head_lora(P, descs))
         prep = dict(n=len(descs), max_dim=max_dim, descs=None)
         if descs:
             arr = (L.LoraPackArgs * len(descs))(*descs)
@@ -315,17 +335,34 @@ class _FluxPlan(_QwenPlan):
         mpj = _ceil(B * S, 128)
         A["sblk"] = []
         kext_s, rp_s = 0, 0
+        kext_m = 0
         for w in P["singles"]:
-            b = dict(qkv=buf(B, S, 3 * D), sqk=buf(B, S, 2 * D), ao=buf(B, S, D), lse=buf(B, H, S_pad, dtype=F32, zero=True),
-                     h=buf(B * S, 4 * D))
+            b = dict(qkv=buf(B, S, 3 * D), sqk=buf(B, S, 2 * D), lse=buf(B, H, S_pad, dtype=F32, zero=True), h=buf(B * S, 4 * D))
+            if w["out"].lora is not None:
+                # adapter on proj_out: its input [attn | gelu(mlp)] is kept as ONE row-major buffer (attention and the GELU epilogue
+                # write straight into its two column ranges), so that u = cat A^T and dA = v^T cat are single rank-r launches
+                b["cat"] = buf(B * S, 5 * D)
+                b["ao"] = b["cat"][:, :D]
+            else:
+                b["ao"] = buf(B * S, D)
             grp = w["qkv_lora"]
-            if grp is not None:
+            if grp is not None or w["mlp"].lora is not None:
                 b["xm"] = buf(B * S, D)
+            if grp is not None:
                 b["Uqkv"] = (buf(3 * grp["Rp"], mpj, zero=True), buf(3 * grp["Rp"], mpj, zero=True))
                 kext_s, rp_s = max(kext_s, grp["Kext"]), max(rp_s, grp["Rp"])
+            b["site_mlp"] = self._site_alloc(w["mlp"], B * S)
+            b["site_out"] = self._site_alloc(w["out"], B * S)
+            if w["mlp"].lora is not None:
+                kext_m = max(kext_m, w["mlp"].lora.Kext)
             A["sblk"].append(b)
         A["xm_j"] = buf(B * S, D); A["g_j"] = buf(B * S, 4 * D)
-        A["A2"] = buf(B * S, 4 * D + 3 * kext_s, zero=True)       # [d(mlp pre-act) | LoRA v ext] : A operand, segment 2 of the dX GEMM
+        A["A2"] = buf(B * S, 4 * D + 3 * kext_s + kext_m, zero=True)   # [d(mlp pre-act) | LoRA v ext (q,k,v) | LoRA v ext (proj_mlp)] : A operand, segment 2 of the dX GEMM
+        A["site"] = {"x_in": self._site_alloc(P["x_in"], rows["img"]), "c_in": self._site_alloc(P["c_in"], rows["txt"]),
+                     "proj_out": self._site_alloc(P["proj_out"], rows["img"])}
+        self.in_grad = P["x_in"].lora is not None or P["c_in"].lora is not None
+        if self.in_grad and Ld == 0:
+            raise NotImplementedError("LoRA on the embedders of a FLUX model without double-stream blocks")
         if kext_s:
             A["ext3_j"] = buf(B * S, 3 * kext_s, zero=True)
             A["Vt_j"] = (buf(3 * rp_s, mpj, zero=True), buf(3 * rp_s, mpj, zero=True))
@@ -374,10 +411,12 @@ class _FluxPlan(_QwenPlan):
         if Ld == 0 and Ls == 0:
             raise NotImplementedError("FLUX model without any transformer block")
         first_out = {s: ((A["X"][s][0], (0, 0)) if Ld else (A["J"][0], (S, off[s]))) for s in ("img", "txt")}
+        kw = self._site_fwd(p, P["x_in"], A["site"]["x_in"], A["in_img"], cfg.in_channels, rows["img"])
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["x_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
-                   C_=first_out["img"][0], ldc=D, bias=P["x_in"].b, rpb=rpb["img"], c_map=first_out["img"][1], row_mask=self.rmask["img"])
+                   C_=first_out["img"][0], ldc=D, bias=P["x_in"].b, rpb=rpb["img"], c_map=first_out["img"][1], row_mask=self.rmask["img"], **kw)
+        kw = self._site_fwd(p, P["c_in"], A["site"]["c_in"], A["in_txt"], P["c_in"].K, rows["txt"])
         self._gemm(p, A1=A["in_txt"], lda1=P["c_in"].K, B1=P["c_in"].W, K1=P["c_in"].K, M=rows["txt"], N=D,
-                   C_=first_out["txt"][0], ldc=D, bias=P["c_in"].b, rpb=rpb["txt"], c_map=first_out["txt"][1])
+                   C_=first_out["txt"][0], ldc=D, bias=P["c_in"].b, rpb=rpb["txt"], c_map=first_out["txt"][1], **kw)
         self.attn_args = []
         for i in range(Ld):
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}
@@ -399,8 +438,9 @@ class _FluxPlan(_QwenPlan):
             p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Ld]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
                 rows["img"], D, rpb["img"], eps)
         po = P["proj_out"]
+        kw = self._site_fwd(p, po, A["site"]["proj_out"], A["xn_out"], D, rows["img"])
         self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b,
-                   row_mask=self.rmask["img"])
+                   row_mask=self.rmask["img"], **kw)
 
     def _emit_single_fwd(self, p, w, bb, mod, x, x_next):
         """FluxSingleTransformerBlock.forward (transformer_flux.py:407-436) on the joint buffer; mod [B,3D] = shift|scale|gate."""
@@ -409,7 +449,7 @@ class _FluxPlan(_QwenPlan):
         eps = 1e-6
         M = B * S
         grp = w["qkv_lora"]
-        xm = bb["xm"] if grp is not None else A["xm_j"]
+        xm = bb.get("xm", A["xm_j"])
         p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 3 * D, _ptr(xm), M, D, S, eps)
         q2 = bb["qkv"].view(M, 3 * D)
         if grp is not None:
@@ -424,8 +464,11 @@ class _FluxPlan(_QwenPlan):
                           K2=lw.lora.Kext)
             groups.append(self._gargs(A1=xm, lda1=D, B1=lw.W, K1=D, M=M, N=D, C_=q2[:, sec * D:], ldc=3 * D, bias=lw.b, **kw))
         self._gemm_group(p, groups)
-        ml = w["mlp"]
-        self._gemm(p, A1=xm, lda1=D, B1=ml.W, K1=D, M=M, N=4 * D, C_=bb["h"], ldc=4 * D, bias=ml.b, epi=L.EPI_GELU, C2=A["g_j"], ldc2=4 * D)
+        ml, wo = w["mlp"], w["out"]
+        cat = bb.get("cat")                       # [M, 5D] = [attn | gelu(mlp)] when proj_out carries an adapter
+        gact, ldg = (cat[:, D:], 5 * D) if cat is not None else (A["g_j"], 4 * D)
+        kw = self._site_fwd(p, ml, bb["site_mlp"], xm, D, M)
+        self._gemm(p, A1=xm, lda1=D, B1=ml.W, K1=D, M=M, N=4 * D, C_=bb["h"], ldc=4 * D, bias=ml.b, epi=L.EPI_GELU, C2=gact, ldc2=ldg, **kw)
         nq, nk = w["norms"]
         p.c(lib.qfx_qk_norm_rope_fwd, _ptr(bb["qkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
             B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
@@ -433,7 +476,7 @@ class _FluxPlan(_QwenPlan):
         a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, 1.0 / math.sqrt(dh)
         a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])
         a.ldq = a.ldk = a.ldv = 3 * D
-        a.O, a.ldo, a.lse2 = _ptr(bb["ao"]), D, _ptr(bb["lse"])
+        a.O, a.ldo, a.lse2 = _ptr(bb["ao"]), bb["ao"].stride(0), _ptr(bb["lse"])
         a.key_mask = _ptr(self.kmask)
         a.dsum = _ptr(A["dsum"])
         a.dO, a.lddo = _ptr(A["dao"]), D
@@ -442,8 +485,13 @@ class _FluxPlan(_QwenPlan):
         a.lddq = a.lddk = a.lddv = 3 * D
         self.sattn_args.append(a)
         p.c(lib.qfx_attn_fwd, C.byref(a))
+        if cat is not None:
+            # adapted proj_out: ONE contraction over the kept [attn | gelu(mlp)] buffer + the LoRA K-extension (base rounded first)
+            kw = self._site_fwd(p, wo, bb["site_out"], cat, 5 * D, M)
+            self._gemm(p, A1=cat, lda1=5 * D, B1=wo.W, ldb1=5 * D, K1=5 * D, M=M, N=D, C_=x_next, ldc=D, bias=wo.b, epi=L.EPI_GATE_RES,
+                       aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D], gate_bs=3 * D, rpb=S, row_mask=self.rmask["joint"], **kw)
+            return
         # proj_out([attn | gelu(mlp)]) as a two-segment contraction, epilogue x + gate * y
-        wo = w["out"]
         self._gemm(p, A1=bb["ao"].view(M, D), lda1=D, B1=wo.W, ldb1=5 * D, K1=D, A2=A["g_j"], lda2=4 * D, B2=wo.W[:, D:], ldb2=5 * D,
                    K2=4 * D, M=M, N=D, C_=x_next, ldc=D, bias=wo.b, epi=L.EPI_GATE_RES, aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D],
                    gate_bs=3 * D, rpb=S, seg2_plain=1, row_mask=self.rmask["joint"])
@@ -457,7 +505,8 @@ class _FluxPlan(_QwenPlan):
         rows, rpb, off = self.rows, self.rpb, self.off
         eps = 1e-6
         po = P["proj_out"]
-        self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D)
+        kw = self._site_bwd(p, po, A["site"]["proj_out"], A["dpred"], po.N, rows["img"], A["xn_out"], D)
+        self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D, **kw)
         mo = A["mod_out"][0]
         cur = 0
         if Ls:
@@ -491,9 +540,13 @@ class _FluxPlan(_QwenPlan):
             gate_prev = None if i == 0 else {"img": A["mods"][2 * (i - 1)][:, 5 * D:6 * D], "txt": A["mods"][2 * (i - 1) + 1][:, 5 * D:6 * D]}
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][dcur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
-                                  gate_prev=gate_prev, last=(i + 1 == Ld and Ls == 0), first=(i == 0), norm_flags=self.NORM_FLAGS)
+                                  gate_prev=gate_prev, last=(i + 1 == Ld and Ls == 0), first=(i == 0 and not self.in_grad),
+                                  norm_flags=self.NORM_FLAGS)
             p.mark(f"transformer_blocks.{i}.")
             dcur = nxt
+        if self.in_grad:   # the embedders' adapters: d(block-0 input) = A["dX"][s][dcur]; their own inputs carry no gradient
+            self._site_bwd(p, P["x_in"], A["site"]["x_in"], A["dX"]["img"][dcur], D, rows["img"], A["in_img"], cfg.in_channels)
+            self._site_bwd(p, P["c_in"], A["site"]["c_in"], A["dX"]["txt"][dcur], D, rows["txt"], A["in_txt"], P["c_in"].K)
 
     def _emit_single_bwd(self, p, w, bb, a, mod, x, dJ_out, dJ_in, i, Ld):
         """In: dJ_out = d(block output) [B*S,D], A["dyg_j"] = gate*dJ_out.  Out: dJ_in and A["dyg_j"] = gate_prev*dJ_in
@@ -508,10 +561,15 @@ class _FluxPlan(_QwenPlan):
         ldA2 = A["A2"].stride(0)
         dao2 = A["dao"].view(M, D)
         dq2 = A["dqkv"].view(M, 3 * D)
-        # d[attn | mlp] = (gate*dx) W_out : attention part -> dO, mlp part through gelu' -> A2[:, :4D]
-        self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT, K1=D, M=M, N=D, C_=dao2, ldc=D)
+        # d[attn | mlp] = (gate*dx) W_out : attention part -> dO, mlp part through gelu' -> A2[:, :4D]   (+ proj_out's adapter)
+        kwa, kwm = {}, {}
+        if wo.lora is not None:
+            kwo = self._site_bwd(p, wo, bb["site_out"], A["dyg_j"], D, M, bb["cat"], 5 * D)
+            kwa = dict(kwo, B2=wo.lora.WeT[:D])
+            kwm = dict(kwo, B2=wo.lora.WeT[D:])
+        self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT, K1=D, M=M, N=D, C_=dao2, ldc=D, **kwa)
         self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT[D:], K1=D, M=M, N=4 * D, C_=A["A2"], ldc=ldA2, epi=L.EPI_DGELU, aux=bb["h"],
-                   ldaux=4 * D)
+                   ldaux=4 * D, **kwm)
         q2 = bb["qkv"].view(M, 3 * D)
         p.c(lib.qfx_attn_bwd_dq, C.byref(a))
         p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
@@ -542,6 +600,15 @@ class _FluxPlan(_QwenPlan):
                         sl = slice(sec * Rp, (sec + 1) * Rp)
                         self._grad(p, Vt=(Vth[sl], Vtl[sl]), R=Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1)
             K2 = 4 * D + 3 * Kext
+        if ml.lora is not None:
+            # proj_mlp's adapter: v = d(mlp pre-act) (sB)^T goes into the last K-extension columns of A2; dB / dA as for any site
+            lo = ml.lora
+            sb = bb["site_mlp"]
+            self._down(p, X=A["A2"], ldx=ldA2, M=M, K=4 * D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp, Ut=sb["V"],
+                       ext=A["A2"][:, K2:], ld_ext=ldA2)
+            self._grad(p, Vt=sb["U"], R=lo.Rp, r_valid=lo.r, X=A["A2"], ldx=ldA2, M=M, K=4 * D, G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale)
+            self._grad(p, Vt=sb["V"], R=lo.Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1)
+            K2 += lo.Kext
         # d(norm_x) = [dq|dk|dv] Wqkv + [d mlp | LoRA v] [W_mlp ; A]
         self._gemm(p, A1=dq2, lda1=3 * D, B1=w["qkvT"], K1=3 * D, A2=A["A2"], lda2=ldA2, B2=w["B2"], ldb2=w["B2"].stride(0), K2=K2,
                    M=M, N=D, C_=A["dxm_j"], ldc=D, seg2_plain=1)

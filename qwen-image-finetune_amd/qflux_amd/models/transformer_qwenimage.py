@@ -196,11 +196,11 @@ class QwenImageTransformer2DModel(nn.Module):
     # ------------------------------------------------------------------ reference-surface methods
     @property
     def device(self):
-        return self.proj_out.weight.device
+        return self.norm_out.linear.weight.device if isinstance(self.norm_out.linear, QfxLinear) else next(self.parameters()).device
 
     @property
     def dtype(self):
-        return self.proj_out.weight.dtype
+        return BF      # the frozen trunk is bf16 (adapters are fp32)
 
     def enable_gradient_checkpointing(self):
         """Accepted for API parity (base_trainer.py:324-325); a no-op: activations stay resident in HBM."""
@@ -230,9 +230,9 @@ class QwenImageTransformer2DModel(nn.Module):
         for n in names:
             if not self._lora_supported(n):
                 raise NotImplementedError(
-                    f"LoRA target '{n}': the fused path covers the attention projections (to_q/to_k/to_v/to_out.0/add_*_proj/"
-                    f"to_add_out) and the feed-forward linears (net.0.proj / net.2) of the double-stream blocks; modulation / "
-                    f"embedder targets are not built (DESIGN.md)")
+                    f"LoRA target '{n}': the fused path covers the attention projections, the feed-forward linears, the embedders "
+                    f"and the output projection (FLUX: also the single-block proj_mlp / proj_out); the modulation / timestep-"
+                    f"embedder linears (GEMV sites) are not built (DESIGN.md)")
         for n in names:
             parent_name, _, child = n.rpartition(".")
             parent = self.get_submodule(parent_name)
@@ -254,7 +254,12 @@ class QwenImageTransformer2DModel(nn.Module):
                       "img_mlp.net.0.proj", "img_mlp.net.2", "txt_mlp.net.0.proj", "txt_mlp.net.2",      # Qwen feed-forwards
                       "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2")           # FLUX double blocks
 
+    # embedders / output projection: plain GEMM sites outside the blocks (K-extension + the two rank-r gradient launches)
+    _HEAD_SITES = {"img_in": "img_in", "txt_in": "txt_in", "proj_out": "proj_out"}      # module name -> key in the prepared weights
+
     def _lora_supported(self, name: str) -> bool:
+        if name in self._HEAD_SITES:
+            return True
         return name.startswith("transformer_blocks.") and name.endswith(self._LORA_SUFFIXES)
 
     def set_adapter(self, adapter_name):
@@ -355,12 +360,33 @@ class QwenImageTransformer2DModel(nn.Module):
         max_dim = 1
         for w, blk in zip(P["blocks"], self.transformer_blocks):
             max_dim = max(max_dim, self._prep_double_lora(w, blk.attn, descs))
+        max_dim = max(max_dim, self._prep_head_lora(P, descs))
         prep = dict(n=len(descs), max_dim=max_dim, descs=None)
         if descs:
             arr = (L.LoraPackArgs * len(descs))(*descs)
             prep["descs"] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._lora_prep = prep
         return prep
+
+    def _prep_site_lora(self, lw, descs):
+        """Operand buffers of ONE adapted linear that is not part of a q/k/v group (own A_hi/A_lo and WeT)."""
+        m = lw.mod
+        if not isinstance(m, QfxLoraLinear):
+            lw.lora = None
+            return 1
+        if m.in_features % 32:
+            raise NotImplementedError(f"LoRA on a linear with in_features={m.in_features}: the rank-r kernels contract in 32-wide steps")
+        dev = self.device
+        r = m.r[m.active_adapter]
+        Rp, Kext = _ceil(r, 16), _ceil(3 * _ceil(r, 16), 64)
+        K = m.in_features
+        lw.lora = self._make_lora(m, Rp, Kext, torch.zeros(Rp, K, dtype=BF, device=dev), torch.zeros(Rp, K, dtype=BF, device=dev),
+                                  torch.zeros(K, Kext, dtype=BF, device=dev), dev)
+        descs.append(self._pack_desc(lw.lora))
+        return max(lw.N, K)
+
+    def _prep_head_lora(self, P, descs):
+        return max(self._prep_site_lora(P[key], descs) for key in self._HEAD_SITES.values())
 
     def _prep_qkv_lora(self, w, prefix, mods, descs, WeT=None):
         """LoRA operand buffers of a q/k/v projection group sharing one input: concatenated A_hi/A_lo [3Rp,D] (one fused
@@ -543,6 +569,11 @@ class _QwenPlan:
         A["dpred"] = buf(B * S_i, Cout); A["dxn"] = buf(B * S_i, D)
         A["blk"] = [self._alloc_double_block(w) for w in P["blocks"]]
         self._alloc_double_scratch(P["blocks"])
+        A["site"] = {"img_in": self._site_alloc(P["img_in"], rows["img"]), "txt_in": self._site_alloc(P["txt_in"], rows["txt"]),
+                     "proj_out": self._site_alloc(P["proj_out"], rows["img"])}
+        self.in_grad = P["img_in"].lora is not None or P["txt_in"].lora is not None   # the gradient must reach the block-0 inputs
+        if multires and P["txt_in"].lora is not None:
+            raise NotImplementedError("LoRA on txt_in with the multi-resolution Qwen model (the reference has no training caller for it)")
         self.fwd = _Prog()
         self.bwd = _Prog()
         self._init_side_grads(P["blocks"], type(self) is _QwenPlan)
@@ -798,6 +829,39 @@ class _QwenPlan:
         prog.keep.append(a)
         prog.c(lib.qfx_lora_grad, C.byref(a))
 
+    # ------------------------------------------------------------------ stand-alone adapted linears (embedders, output projection ...)
+    def _site_alloc(self, lw, M):
+        """Private rank-r buffers of one adapted linear with M input rows: K-extension images of the forward (ext) and backward
+        (extb) GEMM, transposed hi/lo splits of u = x A^T (kept for dB) and v = dy (sB)^T (for dA)."""
+        if lw.lora is None:
+            return None
+        lo, buf, mp = lw.lora, self.buf, _ceil(M, 128)
+        return dict(ext=buf(M, lo.Kext, zero=True), extb=buf(M, lo.Kext, zero=True),
+                    U=(buf(lo.Rp, mp, zero=True), buf(lo.Rp, mp, zero=True)), V=(buf(lo.Rp, mp, zero=True), buf(lo.Rp, mp, zero=True)))
+
+    def _site_fwd(self, p, lw, sb, X, ldx, M, rpb=None, x_map=(0, 0)):
+        """u = x A^T (fp32-accurate), returns the K-extension arguments of the site's GEMM."""
+        if lw.lora is None:
+            return {}
+        lo = lw.lora
+        self._down(p, X=X, ldx=ldx, M=M, K=lo.A_hi.shape[1], W_hi=lo.A_hi, W_lo=lo.A_lo, ldw=lo.A_hi.stride(0), R=lo.Rp, Ut=sb["U"],
+                   ext=sb["ext"], ld_ext=sb["ext"].stride(0), rpb=rpb, x_map=x_map)
+        return dict(A2=sb["ext"], lda2=sb["ext"].stride(0), B2=lo.We, ldb2=lo.We.stride(0), K2=lo.Kext)
+
+    def _site_bwd(self, p, lw, sb, dY, ldy, M, Xin, ldxin, rpb=None, dy_map=(0, 0), x_map=(0, 0), WeT=None):
+        """v = dy (sB)^T, dB += dy^T u, dA += v^T x; returns the K-extension arguments of the site's dX GEMM."""
+        if lw.lora is None:
+            return {}
+        lo = lw.lora
+        self._down(p, X=dY, ldx=ldy, M=M, K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp, Ut=sb["V"],
+                   ext=sb["extb"], ld_ext=sb["extb"].stride(0), rpb=rpb, x_map=dy_map)
+        self._grad(p, Vt=sb["U"], R=lo.Rp, r_valid=lo.r, X=dY, ldx=ldy, M=M, K=lw.N, G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale,
+                   rpb=rpb, x_map=dy_map)
+        self._grad(p, Vt=sb["V"], R=lo.Rp, r_valid=lo.r, X=Xin, ldx=ldxin, M=M, K=lo.A_hi.shape[1], G=lo.gA, g_sr=lo.A_hi.shape[1], g_sc=1,
+                   rpb=rpb, x_map=x_map)
+        WeT = lo.WeT if WeT is None else WeT
+        return dict(A2=sb["extb"], lda2=sb["extb"].stride(0), B2=WeT, ldb2=WeT.stride(0), K2=lo.Kext)
+
     # ------------------------------------------------------------------ forward program
     def _build_forward(self, P):
         A, B, D, S, H, dh, T, S_i = self.A, self.B, self.D, self.S, self.H, self.dh, self.T, self.S_i
@@ -815,11 +879,13 @@ class _QwenPlan:
         p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
         p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
         p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["norm_out_Wp"]), _ptr(P["norm_out_bp"]), 1, 2 * D, 1, _ptr(A["mod_out"]))
+        kw = self._site_fwd(p, P["img_in"], A["site"]["img_in"], A["in_img"], cfg.in_channels, rows["img"])
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["img_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
-                   C_=A["X"]["img"][0], ldc=D, bias=P["img_in"].b, row_mask=self.rmask["img"])
+                   C_=A["X"]["img"][0], ldc=D, bias=P["img_in"].b, row_mask=self.rmask["img"], **kw)
         p.c(lib.qfx_rmsnorm_fwd, _ptr(A["in_txt"]), _ptr(model.txt_norm.weight.data), _ptr(A["txt_n"]), rows["txt"], Jd, eps)
+        kw = self._site_fwd(p, P["txt_in"], A["site"]["txt_in"], A["txt_n"], Jd, rows["txt"])
         self._gemm(p, A1=A["txt_n"], lda1=Jd, B1=P["txt_in"].W, K1=Jd, M=rows["txt"], N=D, C_=A["X"]["txt"][0], ldc=D,
-                   bias=P["txt_in"].b, row_mask=self.rm_txt0)
+                   bias=P["txt_in"].b, row_mask=self.rm_txt0, **kw)
         self.attn_args = []
         for i in range(Lyr):
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
@@ -829,8 +895,9 @@ class _QwenPlan:
         p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
             rows["img"], D, rpb["img"], eps)
         po = P["proj_out"]
+        kw = self._site_fwd(p, po, A["site"]["proj_out"], A["xn_out"], D, rows["img"])
         self._gemm(p, A1=A["xn_out"], lda1=D, B1=po.W, K1=D, M=rows["img"], N=po.N, C_=A["out"], ldc=po.N, bias=po.b,
-                   row_mask=self.rmask["img"])
+                   row_mask=self.rmask["img"], **kw)
 
     def _emit_double_fwd(self, p, w, bb, mods, x_in, x_out, last, norm_flags, par=0):
         """One double-stream block (reference: transformer_qwenimage.py:425-494; FLUX: transformer_flux.py:467-523).
@@ -945,9 +1012,10 @@ class _QwenPlan:
         rows, rpb, off = self.rows, self.rpb, self.off
         eps = 1e-6
         po = P["proj_out"]
-        # tail: proj_out dX, norm_out LN backward (+ gate2 of the last block folded in)
+        # tail: proj_out dX (+ its adapter), norm_out LN backward (+ gate2 of the last block folded in)
+        kw = self._site_bwd(p, po, A["site"]["proj_out"], A["dpred"], po.N, rows["img"], A["xn_out"], D)
         self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D,
-                   row_mask=self.rmask["img"])   # backward of the output masked_fill: no gradient enters through padded rows
+                   row_mask=self.rmask["img"], **kw)   # backward of the output masked_fill: no gradient enters through padded rows
         mo = A["mod_out"][0]
         modL = A["mods"][2 * (Lyr - 1)]
         cur = 0
@@ -959,12 +1027,16 @@ class _QwenPlan:
             gate_prev = None if i == 0 else {"img": A["mods"][2 * (i - 1)][:, 5 * D:6 * D], "txt": A["mods"][2 * (i - 1) + 1][:, 5 * D:6 * D]}
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
-                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0), norm_flags=0,
+                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0 and not self.in_grad), norm_flags=0,
                                   prefix=f"transformer_blocks.{i}.", par=i & 1)
             if not self.side_grads:
                 p.mark(f"transformer_blocks.{i}.")
             cur = nxt
         self._side_join(p)
+        # head: the embedders' adapters (their inputs carry no gradient: rank-r launches only); d(block-0 input) = A["dX"][s][cur]
+        if self.in_grad:
+            self._site_bwd(p, P["img_in"], A["site"]["img_in"], A["dX"]["img"][cur], D, rows["img"], A["in_img"], cfg.in_channels)
+            self._site_bwd(p, P["txt_in"], A["site"]["txt_in"], A["dX"]["txt"][cur], D, rows["txt"], A["txt_n"], cfg.joint_attention_dim)
 
     def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None, par=0):
         """Backward of one double-stream block.  In: dx2[s] = d(block output), A["dyg2"][s] = gate2*dx2 (emitted by whoever

@@ -35,7 +35,7 @@ def build_pair(cfg, r=4, lora_alpha=8, adapter="lora_edit", seed=2, device="cuda
             p.data = p.data.to(BF)
     with torch.device(device):
         hip = QwenImageTransformer2DModel(**cfg)
-    hip.add_adapter(LoraConfig(r=r, lora_alpha=lora_alpha, target_modules=list(targets)), adapter)
+    hip.add_adapter(LoraConfig(r=r, lora_alpha=lora_alpha, target_modules=(targets if isinstance(targets, str) else list(targets))), adapter)
     missing, unexpected = hip.load_state_dict(oracle.state_dict(), strict=True)
     assert not missing and not unexpected
     return oracle, hip
@@ -125,7 +125,7 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
             p.data = p.data.to(BF)
     with torch.device(device):
         hip = FluxTransformer2DModel(**cfg)
-    hip.add_adapter(LoraConfig(r=r, lora_alpha=2 * r, target_modules=list(targets)), "lora_edit")
+    hip.add_adapter(LoraConfig(r=r, lora_alpha=2 * r, target_modules=(targets if isinstance(targets, str) else list(targets))), "lora_edit")
     missing, unexpected = hip.load_state_dict(oracle.state_dict(), strict=True)
     assert not missing and not unexpected
     g = torch.Generator().manual_seed(31)

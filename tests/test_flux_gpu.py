@@ -225,3 +225,26 @@ def test_multires_plan_cache_is_bounded_over_20_distinct_ragged_batches():
     assert torch.cuda.memory_allocated() < max(mem)
     samples, txt = batch(100)
     assert abs(step.forward_backward_multires(samples, txt).item() - first[0]) <= 1e-5 * abs(first[0])     # rebuilt on demand
+
+
+# the reference's broad FLUX target regex (configs/face_seg_flux_kontext_fp16.yaml:11) WITHOUT its modulation alternatives
+# ((norm|norm1|norm1_context).linear -- GEMV sites, covered by test_flux_reference_regex_with_modulation_targets)
+_REGEX_GEMM_SITES = (r"(.*x_embedder|.*transformer_blocks\.[0-9]+\.attn\.(to_k|to_q|to_v|to_add_out)|.*transformer_blocks\.[0-9]+\.attn\.to_out\.0|"
+                     r".*single_transformer_blocks\.[0-9]+\.attn\.to_out|.*single_transformer_blocks\.[0-9]+\.(proj_mlp|proj_out)|"
+                     r".*(?<!single_)transformer_blocks\.[0-9]+\.ff\.net\.2|.*(?<!single_)transformer_blocks\.[0-9]+\.ff\.net\.0\.proj|"
+                     r".*(?<!single_)transformer_blocks\.[0-9]+\.ff_context\.net\.0\.proj|.*(?<!single_)transformer_blocks\.[0-9]+\.ff_context\.net\.2|"
+                     r".*(?<!single_)transformer_blocks\.[0-9]+\.attn\.(to_add_out|add_k_proj|add_q_proj|add_v_proj))")
+
+
+def test_flux_reference_regex_gemm_sites():
+    """Embedder, double-block attention + feed-forward of both streams, single-block q/k/v + proj_mlp + proj_out adapters."""
+    res = run_flux_step_parity(DEV, verbose=True, hw=(6, 4), T=9, B=2, r=8, targets=_REGEX_GEMM_SITES)
+    assert res["ok"] and res["n_lora"] == 2 * (1 + 2 * 12 + 2 * 5), res
+
+
+def test_flux_embedders_output_projection_and_single_block_sites():
+    """List-style targets: x_embedder, context_embedder, the output projection and every single-block linear (suffix `proj_out`
+    matches the model's output projection AND the single blocks' proj_out, as peft's suffix matching does)."""
+    res = run_flux_step_parity(DEV, verbose=True, hw=(5, 6), T=8, B=2, r=4,
+                               targets=("x_embedder", "context_embedder", "proj_out", "proj_mlp", "to_q", "to_v"))
+    assert res["ok"] and res["n_lora"] == 2 * (2 + 1 + 2 * 2 + 2 * 2 + 2 * 2), res

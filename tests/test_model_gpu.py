@@ -384,3 +384,13 @@ def test_loss_curve_matches_oracle_training_run():
     print("loss curve: mse", mse, "max |d|", worst, "first/last", lo[0], lo[-1], "adapter drift after", steps, "steps:", drift)
     _dump("loss_curve", dict(steps=steps, mse=mse, max_abs_diff=worst, oracle=lo, hip=lh, adapter_rel_drift=drift))
     assert mse < 1e-3 and sum(lo[-8:]) < 0.97 * sum(lo[:8])     # matched AND actually trained
+
+
+def test_embedder_and_output_projection_lora_targets():
+    """Adapters on img_in / txt_in / proj_out next to the attention targets (part of `all-linear`,
+    configs/example_with_sampling.yaml:9): the gradient has to reach the block-0 inputs, which the default plan skips."""
+    from parity_util import run_tiny_step_parity
+    res = run_tiny_step_parity(DEV, verbose=True, r=8, targets=("to_k", "to_q", "to_v", "to_out.0", "img_in", "txt_in", "proj_out"))
+    assert res["ok"] and res["grads_nonzero"] == 2 * (8 + 3), res
+    res = run_tiny_step_parity(DEV, verbose=True, r=4, targets=("img_in", "proj_out"), fused=False)
+    assert res["ok"], res
