@@ -42,7 +42,7 @@ extern "C" {
 enum {
   QFX_EPI_NONE = 0,      /* C = bf16(acc) */
   QFX_EPI_GELU = 1,      /* C = bf16(acc) (pre-activation), C2 = bf16(gelu_tanh(C)) */
-  QFX_EPI_GATE_RES = 2,  /* C = bf16(aux + bf16(gate[b] * bf16(acc)))  (x + gate*y) */
+  QFX_EPI_GATE_RES = 2,  /* C = bf16(aux + bf16(gate[b] * bf16(acc)))  (x + gate*y); if C2 != NULL also C2[m] = bf16(acc) (pre-gate y, rows unmapped, for d(gate)) */
   QFX_EPI_DGELU = 3      /* C = bf16(bf16(acc) * gelu_tanh'(aux))      (backward through GELU) */
 };
 
@@ -163,6 +163,21 @@ typedef struct qfx_ln_bwd_args {
 } qfx_ln_bwd_args;
 int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n, void* stream);
 int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n, void* stream);
+/* ---- gradients of the AdaLN modulation vectors (needed only when the modulation linears carry adapters:
+ * `img_mod.1` / `norm1.linear` ... in target_modules, configs/face_seg_flux_kontext_fp16.yaml:11, "all-linear").
+ * For xm = bf16(LN(x) * bf16(1 + scale[b])) + shift[b]   (transformer_qwenimage.py:443-448; AdaLayerNormZero)
+ * and  xo = x_res + bf16(gate[b] * y)                     (transformer_qwenimage.py:479-485)
+ *   dshift[b] += sum_rows dy,   dscale[b] += sum_rows dy * bf16(LN(x)),   dgate[b] += sum_rows dxo * y
+ * (fp32 accumulation, atomics into zero-initialised [B, out_bstride] buffers; rows of sample b = rows_per_batch consecutive
+ * rows).  dxo / y / dgate may be NULL together (AdaLayerNormContinuous has no gate).  Row strides are explicit. */
+typedef struct qfx_mod_grad_args {
+  const uint16_t* dy; int64_t ld_dy; const uint16_t* x; int64_t ld_x;
+  const uint16_t* dxo; int64_t ld_dxo; const uint16_t* y; int64_t ld_y;
+  float* dshift; float* dscale; float* dgate; int64_t out_bstride;
+  const float* row_mask; int32_t rows; int32_t D; int32_t rows_per_batch; float eps;
+} qfx_mod_grad_args;
+int qfx_mod_grad(const qfx_mod_grad_args* a, void* stream);
+
 /* dyg = bf16(gate[b] * dx) only (used where no LayerNorm precedes). */
 int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg,
                  int32_t rows, int32_t D, int32_t rows_per_batch, void* stream);

@@ -192,6 +192,93 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   }
 }
 
+// ---------------------------------------------------------------- gradients of the modulation vectors (shift, scale, gate)
+// grid = (row chunks of 32 per sample, B); block = 4 waves; a wave owns 8 consecutive rows (one row at a time in registers, as in
+// the LayerNorm kernels), accumulates its column sums in registers, the four waves combine in LDS and the block issues ONE fp32
+// atomic per column and output.  HBM-bound (reads dy, x [, dxo, y] once).
+template <int NP>
+__global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a) {
+  __shared__ float sacc[3][NP * 512];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int D = a.D;
+  const bool has_gate = a.dgate != nullptr;
+  for (int i = threadIdx.x; i < 3 * NP * 512; i += 256) (&sacc[0][0])[i] = 0.f;
+  __syncthreads();
+  float as[NP][8], ac[NP][8], ag[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { as[p][i] = 0.f; ac[p][i] = 0.f; ag[p][i] = 0.f; }
+  const int r_lo = blockIdx.x * 32 + w * 8;
+  for (int rr = 0; rr < 8; ++rr) {
+    const int rl = r_lo + rr;
+    if (rl >= a.rows_per_batch) break;            // wave-uniform
+    const int64_t row = (int64_t)b * a.rows_per_batch + rl;
+    if (row >= a.rows) break;
+    if (a.row_mask != nullptr && a.row_mask[row] == 0.f) continue;
+    float xv[NP][8], dv[NP][8];
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < D) {
+        ld8(a.x + row * a.ld_x + col, xv[p]);
+        ld8(a.dy + row * a.ld_dy + col, dv[p]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += xv[p][i];
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < D) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = xv[p][i] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + a.eps);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < D) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          as[p][i] += dv[p][i];
+          ac[p][i] += dv[p][i] * rbf((xv[p][i] - mean) * rstd);
+        }
+        if (has_gate) {
+          float gx[8], gy[8];
+          ld8(a.dxo + row * a.ld_dxo + col, gx);
+          ld8(a.y + row * a.ld_y + col, gy);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ag[p][i] += gx[i] * gy[i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int col = (p * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        atomicAdd(&sacc[0][col + i], as[p][i]);
+        atomicAdd(&sacc[1][col + i], ac[p][i]);
+        if (has_gate) atomicAdd(&sacc[2][col + i], ag[p][i]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    unsafeAtomicAdd(a.dshift + (int64_t)b * a.out_bstride + c, sacc[0][c]);
+    unsafeAtomicAdd(a.dscale + (int64_t)b * a.out_bstride + c, sacc[1][c]);
+    if (has_gate) unsafeAtomicAdd(a.dgate + (int64_t)b * a.out_bstride + c, sacc[2][c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void gate_mul_kernel(const bf16_t* __restrict__ dx, const bf16_t* __restrict__ gate,
                                                        int64_t gate_bstride, bf16_t* __restrict__ dyg, int64_t total8,
                                                        int D, int rpb) {
@@ -729,6 +816,27 @@ extern "C" int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const 
   a.dy = dy; a.x = x; a.scale = scale; a.mod_bstride = mod_bstride; a.dres = dres; a.gate = gate; a.gate_bstride = gate_bstride;
   a.dx = dx; a.dyg = dyg; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch; a.eps = eps; a.row_mask = row_mask;
   return qfx_ln_modulate_bwd_batch(&a, 1, stream);
+}
+
+extern "C" int qfx_mod_grad(const qfx_mod_grad_args* a, void* stream) {
+  if (!a || !a->dy || !a->x || !a->dshift || !a->dscale) return QFX_EINVAL;
+  if (a->rows <= 0 || a->D <= 0 || (a->D % 8) || a->D > MAXP * 512 || a->rows_per_batch <= 0) return QFX_EINVAL;
+  if ((a->ld_dy % 8) || (a->ld_x % 8)) return QFX_EINVAL;
+  if ((a->dgate != nullptr) != (a->dxo != nullptr) || (a->dgate != nullptr) != (a->y != nullptr)) return QFX_EINVAL;
+  if (a->dgate && ((a->ld_dxo % 8) || (a->ld_y % 8))) return QFX_EINVAL;
+  const int B = (a->rows + a->rows_per_batch - 1) / a->rows_per_batch;
+  dim3 grid((a->rows_per_batch + 31) / 32, B);
+  hipStream_t s = (hipStream_t)stream;
+  switch ((a->D + 511) / 512) {
+    case 1: hipLaunchKernelGGL(mod_grad_kernel<1>, grid, dim3(256), 0, s, *a); break;
+    case 2: hipLaunchKernelGGL(mod_grad_kernel<2>, grid, dim3(256), 0, s, *a); break;
+    case 3: hipLaunchKernelGGL(mod_grad_kernel<3>, grid, dim3(256), 0, s, *a); break;
+    case 4: hipLaunchKernelGGL(mod_grad_kernel<4>, grid, dim3(256), 0, s, *a); break;
+    case 5: case 6: hipLaunchKernelGGL(mod_grad_kernel<6>, grid, dim3(256), 0, s, *a); break;
+    default: hipLaunchKernelGGL(mod_grad_kernel<8>, grid, dim3(256), 0, s, *a); break;
+  }
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
 }
 
 extern "C" int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg, int32_t rows,

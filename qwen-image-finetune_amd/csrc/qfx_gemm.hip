@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
         const bf16x4 z = {0, 0, 0, 0};
         *(bf16x4*)(p.C + crow * p.ldc + n) = z;
         if constexpr (EPI == QFX_EPI_GELU) *(bf16x4*)(p.C2 + crow * p.ldc2 + n) = z;
+        if constexpr (EPI == QFX_EPI_GATE_RES) { if (p.C2) *(bf16x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = z; }
         continue;
       }
       float v[4];
@@ -182,13 +183,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
       } else if constexpr (EPI == QFX_EPI_GATE_RES) {
         const bf16x4 gt = *(const bf16x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
         const bf16x4 rs = *(const bf16x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+        bf16x4 yo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = rbf(v[r]);
+          yo[r] = (short)f2bf(y);
           const float gy = rbf(bf2f((bf16_t)gt[r]) * y);
           o[r] = (short)f2bf(bf2f((bf16_t)rs[r]) + gy);
         }
         *(bf16x4*)(p.C + crow * p.ldc + n) = o;
+        if (p.C2) *(bf16x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yo;   // pre-gate linear output (rows UNMAPPED), kept for d(gate)
       } else {  // QFX_EPI_DGELU
         const bf16x4 hx = *(const bf16x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
 #pragma unroll
@@ -513,6 +517,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
           const u32x4 z = {0u, 0u, 0u, 0u};
           *(u32x4*)(p.C + crow * p.ldc + n) = z;
           if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
+          if constexpr (EPI == QFX_EPI_GATE_RES) { if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = z; }
           continue;
         }
         float y[8];
@@ -542,6 +547,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
             o[q] = pack2bf(r0 + rbf(gt[2 * q] * y[2 * q]), r1 + rbf(gt[2 * q + 1] * y[2 * q + 1]));
           }
           *(u32x4*)(p.C + crow * p.ldc + n) = o;
+          if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yv;   // pre-gate linear output (rows UNMAPPED), kept for d(gate)
         } else {  // QFX_EPI_DGELU
           const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
           u32x4 o;
@@ -560,6 +566,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 bool ok256(const qfx_gemm_args* a) {
   if ((a->N % 8) || (a->ldc % 8)) return false;
   if (a->epi == QFX_EPI_GELU && (a->ldc2 % 8)) return false;
+  if (a->epi == QFX_EPI_GATE_RES && a->C2 && (a->ldc2 % 8)) return false;
   if ((a->epi == QFX_EPI_GATE_RES || a->epi == QFX_EPI_DGELU) && (a->ldaux % 8)) return false;
   if (a->epi == QFX_EPI_GATE_RES && (a->gate_bstride % 8)) return false;
   return true;

@@ -62,6 +62,13 @@ class LnBwdArgs(C.Structure):
                 ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
 
 
+class ModGradArgs(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("ld_dy", C.c_int64), ("x", C.c_void_p), ("ld_x", C.c_int64),
+                ("dxo", C.c_void_p), ("ld_dxo", C.c_int64), ("y", C.c_void_p), ("ld_y", C.c_int64),
+                ("dshift", C.c_void_p), ("dscale", C.c_void_p), ("dgate", C.c_void_p), ("out_bstride", C.c_int64),
+                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
+
+
 class LoraPackArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("r", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("scale", C.c_float),
@@ -116,6 +123,7 @@ SYMBOLS = {
     "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
     "qfx_ln_modulate_fwd_batch": (C.c_int, [C.POINTER(LnFwdArgs), C.c_int32, _vp]),
     "qfx_ln_modulate_bwd_batch": (C.c_int, [C.POINTER(LnBwdArgs), C.c_int32, _vp]),
+    "qfx_mod_grad": (C.c_int, [C.POINTER(ModGradArgs), _vp]),
     "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "qfx_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -128,8 +128,23 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
 
     _HEAD_SITES = {"x_embedder": "x_in", "context_embedder": "c_in", "proj_out": "proj_out"}
 
+    _COND_SUFFIXES = ("timestep_embedder.linear_1", "timestep_embedder.linear_2", "guidance_embedder.linear_1", "guidance_embedder.linear_2",
+                      "text_embedder.linear_1", "text_embedder.linear_2", "norm1.linear", "norm1_context.linear", "norm.linear",
+                      "norm_out.linear")
+
+    def _cond_modules(self):
+        te = self.time_text_embed
+        mods = [te.timestep_embedder.linear_1, te.timestep_embedder.linear_2, te.text_embedder.linear_1, te.text_embedder.linear_2,
+                self.norm_out.linear]
+        if self.config.guidance_embeds:
+            mods += [te.guidance_embedder.linear_1, te.guidance_embedder.linear_2]
+        for blk in self.transformer_blocks:
+            mods += [blk.norm1.linear, blk.norm1_context.linear]
+        mods += [blk.norm.linear for blk in self.single_transformer_blocks]
+        return mods
+
     def _lora_supported(self, name: str) -> bool:
-        if name in self._HEAD_SITES:
+        if name in self._HEAD_SITES or name.endswith(self._COND_SUFFIXES):
             return True
         if name.startswith("transformer_blocks."):
             return name.endswith(self._LORA_SUFFIXES)
@@ -358,11 +373,24 @@ class _FluxPlan(_QwenPlan):
             A["sblk"].append(b)
         A["xm_j"] = buf(B * S, D); A["g_j"] = buf(B * S, 4 * D)
         A["A2"] = buf(B * S, 4 * D + 3 * kext_s + kext_m, zero=True)   # [d(mlp pre-act) | LoRA v ext (q,k,v) | LoRA v ext (proj_mlp)] : A operand, segment 2 of the dX GEMM
+        self.cond = model.cond_lora
+        if self.cond:
+            from ..cond_torch import CondHead
+            self.cond_head = CondHead()
+            A["dmods"] = buf(max(2 * Ld, 1), B, 6 * D, dtype=F32, zero=True)
+            A["dsmods"] = buf(max(Ls, 1), B, 3 * D, dtype=F32, zero=True)
+            A["dmod_out"] = buf(1, B, 2 * D, dtype=F32, zero=True)
+            for bb in A["blk"]:
+                bb["y1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+                bb["y2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+            for bb in A["sblk"]:
+                bb["y"] = buf(B * S, D)
         A["site"] = {"x_in": self._site_alloc(P["x_in"], rows["img"]), "c_in": self._site_alloc(P["c_in"], rows["txt"]),
                      "proj_out": self._site_alloc(P["proj_out"], rows["img"])}
         self.in_grad = P["x_in"].lora is not None or P["c_in"].lora is not None
-        if self.in_grad and Ld == 0:
-            raise NotImplementedError("LoRA on the embedders of a FLUX model without double-stream blocks")
+        self.full_bwd = self.in_grad or self.cond
+        if self.full_bwd and Ld == 0:
+            raise NotImplementedError("LoRA on the embedders / conditioning head of a FLUX model without double-stream blocks")
         if kext_s:
             A["ext3_j"] = buf(B * S, 3 * kext_s, zero=True)
             A["Vt_j"] = (buf(3 * rp_s, mpj, zero=True), buf(3 * rp_s, mpj, zero=True))
@@ -390,6 +418,21 @@ class _FluxPlan(_QwenPlan):
         eps = 1e-6
         # ---- temb = time_emb(+ guidance_emb) + pooled text emb   (CombinedTimestep(Guidance)TextProjEmbeddings)
         p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1.0, 1000.0, _ptr(A["tproj"]))
+        if self.cond:   # adapters on the conditioning head: library GEMVs under autograd (cond_torch.py)
+            from ..cond_torch import flux_head
+            if cfg.guidance_embeds:
+                p.c(lib.qfx_timestep_embed, _ptr(A["gd"]), B, 256, 1.0, 1000.0, _ptr(A["gproj"]))
+            p.py(lambda: self.cond_head.run(
+                lambda: flux_head(model, A["tproj"], A["gproj"] if cfg.guidance_embeds else None, A["pooled"]),
+                [A["mods"] if Ld else None, A["smods"] if Ls else None, A["mod_out"]]))
+        else:
+            self._cond_hip(p, P)
+        self._build_forward_body(P)
+
+    def _cond_hip(self, p, P):
+        A, B, D = self.A, self.B, self.D
+        cfg = self.model.config
+        Ld, Ls = cfg.num_layers, cfg.num_single_layers
         self._gemv(p, P, "t1", A["tproj"], 256, D, 0, A["t1"])
         self._gemv(p, P, "t2", A["t1"], D, D, 1, A["t2"])
         self._gemv(p, P, "p1", A["pooled"], cfg.pooled_projection_dim, D, 0, A["p1"])
@@ -407,6 +450,16 @@ class _FluxPlan(_QwenPlan):
         if Ls:
             p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["smod_W"]), _ptr(P["smod_b"]), Ls, 3 * D, 1, _ptr(A["smods"]))
         self._gemv(p, P, "norm_out", A["temb"], D, 2 * D, 1, A["mod_out"])
+
+    def _build_forward_body(self, P):
+        A, B, D, S, H, dh, T, S_i = self.A, self.B, self.D, self.S, self.H, self.dh, self.T, self.S_i
+        S_pad = self.S_pad
+        p = self.fwd
+        model = self.model
+        cfg = model.config
+        Ld, Ls = cfg.num_layers, cfg.num_single_layers
+        rows, rpb, off = self.rows, self.rpb, self.off
+        eps = 1e-6
         # ---- embedders; with no double blocks the embeddings go straight into the joint buffer
         if Ld == 0 and Ls == 0:
             raise NotImplementedError("FLUX model without any transformer block")
@@ -488,13 +541,16 @@ class _FluxPlan(_QwenPlan):
         if cat is not None:
             # adapted proj_out: ONE contraction over the kept [attn | gelu(mlp)] buffer + the LoRA K-extension (base rounded first)
             kw = self._site_fwd(p, wo, bb["site_out"], cat, 5 * D, M)
+            if "y" in bb:
+                kw.update(C2=bb["y"], ldc2=D)
             self._gemm(p, A1=cat, lda1=5 * D, B1=wo.W, ldb1=5 * D, K1=5 * D, M=M, N=D, C_=x_next, ldc=D, bias=wo.b, epi=L.EPI_GATE_RES,
                        aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D], gate_bs=3 * D, rpb=S, row_mask=self.rmask["joint"], **kw)
             return
         # proj_out([attn | gelu(mlp)]) as a two-segment contraction, epilogue x + gate * y
+        kw = dict(C2=bb["y"], ldc2=D) if "y" in bb else {}
         self._gemm(p, A1=bb["ao"].view(M, D), lda1=D, B1=wo.W, ldb1=5 * D, K1=D, A2=A["g_j"], lda2=4 * D, B2=wo.W[:, D:], ldb2=5 * D,
                    K2=4 * D, M=M, N=D, C_=x_next, ldc=D, bias=wo.b, epi=L.EPI_GATE_RES, aux=x, ldaux=D, gate=mod[:, 2 * D:3 * D],
-                   gate_bs=3 * D, rpb=S, seg2_plain=1, row_mask=self.rmask["joint"])
+                   gate_bs=3 * D, rpb=S, seg2_plain=1, row_mask=self.rmask["joint"], **kw)
 
     # ------------------------------------------------------------------ backward
     def _build_backward(self, P):
@@ -509,6 +565,10 @@ class _FluxPlan(_QwenPlan):
         self._gemm(p, A1=A["dpred"], lda1=po.N, B1=po.WT, K1=po.N, M=rows["img"], N=D, C_=A["dxn"], ldc=D, **kw)
         mo = A["mod_out"][0]
         cur = 0
+        if self.cond:
+            for k in ("dmods", "dsmods", "dmod_out"):
+                p.py(A[k].zero_)
+            dmo = A["dmod_out"][0]
         if Ls:
             # tail LayerNorm backward per sample into the joint gradient; text rows of d(joint) are zero (dead text tail)
             dJ, dyg = A["dJ"][cur], A["dyg_j"]
@@ -517,6 +577,10 @@ class _FluxPlan(_QwenPlan):
             p.py(dyg.view(B, S, D)[:, :T].zero_)
             for b in range(B):
                 r0 = b * S + T
+                if self.cond:
+                    self._mod_grad(p, dy=A["dxn"][b * S_i:], x=A["J"][Ls][r0:], rows=S_i, rpb=S_i, dshift=dmo[b:b + 1, D:2 * D],
+                                   dscale=dmo[b:b + 1, 0:D], out_bs=2 * D,
+                                   row_mask=self.rmask["img"][b * S_i:] if self.rmask["img"] is not None else None)
                 p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"][b * S_i:]), _ptr(A["J"][Ls][r0:]), _ptr(mo[b:b + 1, 0:D]), 2 * D, None,
                     _ptr(gl[b:b + 1, 2 * D:3 * D]), 3 * D, _ptr(dJ[r0:]), _ptr(dyg[r0:]), S_i, D, S_i, eps,
                     _ptr(self.rmask["img"][b * S_i:]) if self.rmask["img"] is not None else None)
@@ -532,6 +596,9 @@ class _FluxPlan(_QwenPlan):
         else:
             dcur = 0
             modL = A["mods"][2 * (Ld - 1)]
+            if self.cond:
+                self._mod_grad(p, dy=A["dxn"], x=A["X"]["img"][Ld], rows=rows["img"], rpb=rpb["img"], dshift=dmo[:, D:2 * D],
+                               dscale=dmo[:, 0:D], out_bs=2 * D, row_mask=self.rmask["img"])
             p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"]), _ptr(A["X"]["img"][Ld]), _ptr(mo[:, 0:D]), 2 * D, None,
                 _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][dcur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps, None)
         for i in range(Ld - 1, -1, -1):
@@ -540,13 +607,16 @@ class _FluxPlan(_QwenPlan):
             gate_prev = None if i == 0 else {"img": A["mods"][2 * (i - 1)][:, 5 * D:6 * D], "txt": A["mods"][2 * (i - 1) + 1][:, 5 * D:6 * D]}
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][dcur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
-                                  gate_prev=gate_prev, last=(i + 1 == Ld and Ls == 0), first=(i == 0 and not self.in_grad),
-                                  norm_flags=self.NORM_FLAGS)
+                                  gate_prev=gate_prev, last=(i + 1 == Ld and Ls == 0), first=(i == 0 and not self.full_bwd),
+                                  norm_flags=self.NORM_FLAGS,
+                                  dmods=({"img": A["dmods"][2 * i], "txt": A["dmods"][2 * i + 1]} if self.cond else None))
             p.mark(f"transformer_blocks.{i}.")
             dcur = nxt
         if self.in_grad:   # the embedders' adapters: d(block-0 input) = A["dX"][s][dcur]; their own inputs carry no gradient
             self._site_bwd(p, P["x_in"], A["site"]["x_in"], A["dX"]["img"][dcur], D, rows["img"], A["in_img"], cfg.in_channels)
             self._site_bwd(p, P["c_in"], A["site"]["c_in"], A["dX"]["txt"][dcur], D, rows["txt"], A["in_txt"], P["c_in"].K)
+        if self.cond:
+            p.py(lambda: self.cond_head.backward([A["dmods"] if Ld else None, A["dsmods"] if Ls else None, A["dmod_out"]]))
 
     def _emit_single_bwd(self, p, w, bb, a, mod, x, dJ_out, dJ_in, i, Ld):
         """In: dJ_out = d(block output) [B*S,D], A["dyg_j"] = gate*dJ_out.  Out: dJ_in and A["dyg_j"] = gate_prev*dJ_in
@@ -612,6 +682,10 @@ class _FluxPlan(_QwenPlan):
         # d(norm_x) = [dq|dk|dv] Wqkv + [d mlp | LoRA v] [W_mlp ; A]
         self._gemm(p, A1=dq2, lda1=3 * D, B1=w["qkvT"], K1=3 * D, A2=A["A2"], lda2=ldA2, B2=w["B2"], ldb2=w["B2"].stride(0), K2=K2,
                    M=M, N=D, C_=A["dxm_j"], ldc=D, seg2_plain=1)
+        if self.cond:   # d(shift, scale, gate) of the single block's AdaLayerNormZeroSingle
+            dm = A["dsmods"][i]
+            self._mod_grad(p, dy=A["dxm_j"], x=x, rows=M, rpb=S, dshift=dm[:, 0:D], dscale=dm[:, D:2 * D], dgate=dm[:, 2 * D:3 * D],
+                           dxo=dJ_out, y=bb["y"], out_bs=3 * D, row_mask=self.rmask["joint"])
         if i > 0:
             gp = A["smods"][i - 1][:, 2 * D:3 * D]
             p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm_j"]), _ptr(x), _ptr(mod[:, D:2 * D]), 3 * D, _ptr(dJ_out), _ptr(gp), 3 * D,

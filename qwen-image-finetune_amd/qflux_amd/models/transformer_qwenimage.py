@@ -231,8 +231,8 @@ class QwenImageTransformer2DModel(nn.Module):
             if not self._lora_supported(n):
                 raise NotImplementedError(
                     f"LoRA target '{n}': the fused path covers the attention projections, the feed-forward linears, the embedders "
-                    f"and the output projection (FLUX: also the single-block proj_mlp / proj_out); the modulation / timestep-"
-                    f"embedder linears (GEMV sites) are not built (DESIGN.md)")
+                    f"and the output projection (FLUX: also the single-block proj_mlp / proj_out) and the conditioning head "
+                    f"(timestep / guidance / text embedders, AdaLN modulation linears)")
         for n in names:
             parent_name, _, child = n.rpartition(".")
             parent = self.get_submodule(parent_name)
@@ -257,10 +257,25 @@ class QwenImageTransformer2DModel(nn.Module):
     # embedders / output projection: plain GEMM sites outside the blocks (K-extension + the two rank-r gradient launches)
     _HEAD_SITES = {"img_in": "img_in", "txt_in": "txt_in", "proj_out": "proj_out"}      # module name -> key in the prepared weights
 
+    # conditioning head (M = batch rows): timestep embedder, AdaLN modulation linears -- evaluated by cond_torch when adapted
+    _COND_SUFFIXES = ("timestep_embedder.linear_1", "timestep_embedder.linear_2", "img_mod.1", "txt_mod.1", "norm_out.linear")
+
     def _lora_supported(self, name: str) -> bool:
-        if name in self._HEAD_SITES:
+        if name in self._HEAD_SITES or name.endswith(self._COND_SUFFIXES):
             return True
         return name.startswith("transformer_blocks.") and name.endswith(self._LORA_SUFFIXES)
+
+    def _cond_modules(self):
+        te = self.time_text_embed.timestep_embedder
+        mods = [te.linear_1, te.linear_2, self.norm_out.linear]
+        for blk in self.transformer_blocks:
+            mods += [blk.img_mod[1], blk.txt_mod[1]]
+        return mods
+
+    @property
+    def cond_lora(self) -> bool:
+        """True when a linear of the conditioning head carries an adapter (the head then runs through cond_torch)."""
+        return any(isinstance(m, QfxLoraLinear) for m in self._cond_modules())
 
     def set_adapter(self, adapter_name):
         self._adapter_name = adapter_name
@@ -569,9 +584,19 @@ class _QwenPlan:
         A["dpred"] = buf(B * S_i, Cout); A["dxn"] = buf(B * S_i, D)
         A["blk"] = [self._alloc_double_block(w) for w in P["blocks"]]
         self._alloc_double_scratch(P["blocks"])
+        self.cond = model.cond_lora
+        if self.cond:
+            from ..cond_torch import CondHead
+            self.cond_head = CondHead()
+            A["dmods"] = buf(2 * Lyr, B, 6 * D, dtype=F32, zero=True)
+            A["dmod_out"] = buf(1, B, 2 * D, dtype=F32, zero=True)
+            for bb in A["blk"]:    # pre-gate outputs of the two gated linears of a block (d gate = sum_rows dx_out * y)
+                bb["y1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
+                bb["y2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["site"] = {"img_in": self._site_alloc(P["img_in"], rows["img"]), "txt_in": self._site_alloc(P["txt_in"], rows["txt"]),
                      "proj_out": self._site_alloc(P["proj_out"], rows["img"])}
         self.in_grad = P["img_in"].lora is not None or P["txt_in"].lora is not None   # the gradient must reach the block-0 inputs
+        self.full_bwd = self.in_grad or self.cond      # block 0 runs its complete backward (d xm1 feeds d shift1 / d scale1)
         if multires and P["txt_in"].lora is not None:
             raise NotImplementedError("LoRA on txt_in with the multi-resolution Qwen model (the reference has no training caller for it)")
         self.fwd = _Prog()
@@ -829,6 +854,17 @@ class _QwenPlan:
         prog.keep.append(a)
         prog.c(lib.qfx_lora_grad, C.byref(a))
 
+    def _mod_grad(self, prog, *, dy, x, rows, rpb, dshift, dscale, out_bs, dgate=None, dxo=None, y=None, row_mask=None, ld=None):
+        a = L.ModGradArgs()
+        D = self.D
+        ld = D if ld is None else ld
+        a.dy, a.ld_dy, a.x, a.ld_x = _ptr(dy), ld, _ptr(x), ld
+        a.dxo, a.ld_dxo, a.y, a.ld_y = _ptr(dxo), ld, _ptr(y), ld
+        a.dshift, a.dscale, a.dgate, a.out_bstride = _ptr(dshift), _ptr(dscale), _ptr(dgate), out_bs
+        a.row_mask, a.rows, a.D, a.rows_per_batch, a.eps = _ptr(row_mask), rows, D, rpb, 1e-6
+        prog.keep.append(a)
+        prog.c(lib.qfx_mod_grad, C.byref(a))
+
     # ------------------------------------------------------------------ stand-alone adapted linears (embedders, output projection ...)
     def _site_alloc(self, lw, M):
         """Private rank-r buffers of one adapted linear with M input rows: K-extension images of the forward (ext) and backward
@@ -875,10 +911,14 @@ class _QwenPlan:
         eps = 1e-6
         # head: timestep embedding -> temb ; img_in ; txt_norm + txt_in ; all modulation vectors in one GEMV launch
         p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1000.0, 1.0, _ptr(A["tproj"]))
-        p.c(lib.qfx_mod_gemv, _ptr(A["tproj"]), B, 256, _ptr(P["t1_Wp"]), _ptr(P["t1_bp"]), 1, D, 0, _ptr(A["t1"]))
-        p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
-        p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
-        p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["norm_out_Wp"]), _ptr(P["norm_out_bp"]), 1, 2 * D, 1, _ptr(A["mod_out"]))
+        if self.cond:   # adapters on the conditioning head: library GEMVs under autograd (cond_torch.py)
+            from ..cond_torch import qwen_head
+            p.py(lambda: self.cond_head.run(lambda: qwen_head(model, A["tproj"]), [A["mods"], A["mod_out"]]))
+        else:
+            p.c(lib.qfx_mod_gemv, _ptr(A["tproj"]), B, 256, _ptr(P["t1_Wp"]), _ptr(P["t1_bp"]), 1, D, 0, _ptr(A["t1"]))
+            p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
+            p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
+            p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["norm_out_Wp"]), _ptr(P["norm_out_bp"]), 1, 2 * D, 1, _ptr(A["mod_out"]))
         kw = self._site_fwd(p, P["img_in"], A["site"]["img_in"], A["in_img"], cfg.in_channels, rows["img"])
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["img_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
                    C_=A["X"]["img"][0], ldc=D, bias=P["img_in"].b, row_mask=self.rmask["img"], **kw)
@@ -966,6 +1006,8 @@ class _QwenPlan:
                                Ut=bb["Uo." + s], ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0),
                                rpb=rpb[s], x_map=(S, off[s]))
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
+                if "y1" in bb:
+                    kw.update(C2=bb["y1"][s], ldc2=D)
                 groups.append(self._gargs(A1=ao2, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=bb["x1"][s], ldc=D, bias=lw.b,
                                           epi=L.EPI_GATE_RES, aux=x_in[s], ldaux=D, gate=mods[s][:, 2 * D:3 * D], gate_bs=6 * D,
                                           rpb=rpb[s], a_map=(S, off[s]), **kw))
@@ -997,6 +1039,8 @@ class _QwenPlan:
             for s, sidx in live:
                 f2 = w[s + ".fc2"]
                 kw = lora_ext(s, f2, gact[s], 4 * D, "Uf2.")
+                if "y2" in bb:
+                    kw.update(C2=bb["y2"][s], ldc2=D)
                 groups.append(self._gargs(A1=gact[s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
                                           bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
                                           gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1, row_mask=self.rmask[s], **kw))
@@ -1019,6 +1063,12 @@ class _QwenPlan:
         mo = A["mod_out"][0]
         modL = A["mods"][2 * (Lyr - 1)]
         cur = 0
+        if self.cond:
+            p.py(A["dmods"].zero_)
+            p.py(A["dmod_out"].zero_)
+            dmo = A["dmod_out"][0]       # [B, 2D] = d scale | d shift (AdaLayerNormContinuous chunk order)
+            self._mod_grad(p, dy=A["dxn"], x=A["X"]["img"][Lyr], rows=rows["img"], rpb=rpb["img"], dshift=dmo[:, D:2 * D],
+                           dscale=dmo[:, 0:D], out_bs=2 * D, row_mask=self.rmask["img"])
         p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxn"]), _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, 0:D]), 2 * D, None,
             _ptr(modL[:, 5 * D:6 * D]), 6 * D, _ptr(A["dX"]["img"][cur]), _ptr(A["dyg2"]["img"]), rows["img"], D, rpb["img"], eps, None)
         for i in range(Lyr - 1, -1, -1):
@@ -1027,8 +1077,9 @@ class _QwenPlan:
             gate_prev = None if i == 0 else {"img": A["mods"][2 * (i - 1)][:, 5 * D:6 * D], "txt": A["mods"][2 * (i - 1) + 1][:, 5 * D:6 * D]}
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
-                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0 and not self.in_grad), norm_flags=0,
-                                  prefix=f"transformer_blocks.{i}.", par=i & 1)
+                                  gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0 and not self.full_bwd), norm_flags=0,
+                                  prefix=f"transformer_blocks.{i}.", par=i & 1,
+                                  dmods=({"img": A["dmods"][2 * i], "txt": A["dmods"][2 * i + 1]} if self.cond else None))
             if not self.side_grads:
                 p.mark(f"transformer_blocks.{i}.")
             cur = nxt
@@ -1037,8 +1088,10 @@ class _QwenPlan:
         if self.in_grad:
             self._site_bwd(p, P["img_in"], A["site"]["img_in"], A["dX"]["img"][cur], D, rows["img"], A["in_img"], cfg.in_channels)
             self._site_bwd(p, P["txt_in"], A["site"]["txt_in"], A["dX"]["txt"][cur], D, rows["txt"], A["txt_n"], cfg.joint_attention_dim)
+        if self.cond:
+            p.py(lambda: self.cond_head.backward([A["dmods"], A["dmod_out"]]))
 
-    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None, par=0):
+    def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None, par=0, dmods=None):
         """Backward of one double-stream block.  In: dx2[s] = d(block output), A["dyg2"][s] = gate2*dx2 (emitted by whoever
         produced dx2).  Out: out_dx[s] = d(block input) and A["dyg2"][s] = gate_prev*out_dx (for the previous block)."""
         A, B, D, S, H, dh, T = self.A, self.B, self.D, self.S, self.H, self.dh, self.T
@@ -1091,6 +1144,12 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             if ge:
                 self._flush_batch(p, ge, L.LoraGradArgs, lib.qfx_lora_grad_batch)
+            if dmods is not None:   # d(shift2, scale2, gate2): dy = d(xm2) (fc1 dX output), LN input x1, gate side dx2 * y2
+                for s, _ in live:
+                    dm = dmods[s]
+                    self._mod_grad(p, dy=A["dxm"][s], x=bb["x1"][s], rows=rows[s], rpb=rpb[s], dshift=dm[:, 3 * D:4 * D],
+                                   dscale=dm[:, 4 * D:5 * D], dgate=dm[:, 5 * D:6 * D], dxo=dx2[s], y=bb["y2"][s], out_bs=6 * D,
+                                   row_mask=self.rmask[s])
             self._side_join(p, keep=1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
@@ -1161,6 +1220,13 @@ class _QwenPlan:
             self._flush_batch(p, dl, L.LoraDownArgs, lib.qfx_lora_down_batch)
             if i > 0:
                 self._gemm_group(p, groups)
+                if dmods is not None:   # d(shift1, scale1, gate1): dy = d(xm1) (q/k/v dX output), LN input x_in, gate side dx1 * y1
+                    for s, sidx in STREAMS:
+                        dm = dmods[s]
+                        dead = last and s == "txt"     # no out-projection / residual gradient on the last block's text tail
+                        self._mod_grad(p, dy=A["dxm"][s], x=x_in[s], rows=rows[s], rpb=rpb[s], dshift=dm[:, 0:D], dscale=dm[:, D:2 * D],
+                                       dgate=None if dead else dm[:, 2 * D:3 * D], dxo=None if dead else A["dx1"][s],
+                                       y=None if dead else bb["y1"][s], out_bs=6 * D, row_mask=self.rmask[s])
                 lnl = []
                 for s, sidx in STREAMS:
                     dres = None if (last and s == "txt") else A["dx1"][s]

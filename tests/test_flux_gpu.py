@@ -248,3 +248,25 @@ def test_flux_embedders_output_projection_and_single_block_sites():
     res = run_flux_step_parity(DEV, verbose=True, hw=(5, 6), T=8, B=2, r=4,
                                targets=("x_embedder", "context_embedder", "proj_out", "proj_mlp", "to_q", "to_v"))
     assert res["ok"] and res["n_lora"] == 2 * (2 + 1 + 2 * 2 + 2 * 2 + 2 * 2), res
+
+
+# configs/face_seg_flux_kontext_fp16.yaml:11, verbatim
+_REFERENCE_REGEX = (r"(.*x_embedder|.*transformer_blocks\.[0-9]+\.(norm|norm1)\.linear|.*transformer_blocks\.[0-9]+\.attn\.(to_k|to_q|to_v|to_add_out)|"
+                    r".*transformer_blocks\.[0-9]+\.attn\.to_out\.0|.*single_transformer_blocks\.[0-9]+\.attn\.to_out|"
+                    r".*single_transformer_blocks\.[0-9]+\.(proj_mlp|proj_out)|.*(?<!single_)transformer_blocks\.[0-9]+\.ff\.net\.2|"
+                    r".*(?<!single_)transformer_blocks\.[0-9]+\.ff\.net\.0\.proj|.*(?<!single_)transformer_blocks\.[0-9]+\.norm1_context\.linear|"
+                    r".*(?<!single_)transformer_blocks\.[0-9]+\.ff_context\.net\.0\.proj|.*(?<!single_)transformer_blocks\.[0-9]+\.ff_context\.net\.2|"
+                    r".*(?<!single_)transformer_blocks\.[0-9]+\.attn\.(to_add_out|add_k_proj|add_q_proj|add_v_proj))")
+
+
+def test_flux_reference_regex_with_modulation_targets():
+    """The reference's shipped broad regex as is: GEMM sites + norm1 / norm1_context / single-block norm linears."""
+    res = run_flux_step_parity(DEV, verbose=True, hw=(6, 4), T=9, B=2, r=8, targets=_REFERENCE_REGEX)
+    assert res["ok"] and res["n_lora"] == 2 * (1 + 2 * 14 + 2 * 6), res
+
+
+def test_flux_all_linear_targets():
+    res = run_flux_step_parity(DEV, verbose=True, hw=(4, 6), T=7, B=2, r=4, targets="all-linear")
+    assert res["ok"], res
+    res = run_flux_step_parity(DEV, verbose=True, hw=(4, 6), T=7, B=1, r=4, targets="all-linear", guidance=False, fused=False)
+    assert res["ok"], res

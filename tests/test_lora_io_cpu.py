@@ -28,11 +28,15 @@ def test_adapter_names_and_trainable_filter():
     # regex target (peft full-match) on the FLUX model: single-block projections too
     names = f.add_adapter(LoraConfig(r=8, lora_alpha=8, target_modules=".*attn[.]to_[qkv]"), "a")
     assert len(names) == 3 * (FLUX_TINY["num_layers"] + FLUX_TINY["num_single_layers"])
-    try:
-        q.add_adapter(LoraConfig(r=4, target_modules=["img_mod.1"]), "b")   # modulation linears are not built
-        raise AssertionError("expected NotImplementedError for an unsupported target")
-    except NotImplementedError:
-        pass
+    # every Linear of the DiT can carry an adapter (target_modules "all-linear", configs/example_with_sampling.yaml:9): the
+    # conditioning-head linears switch the head to the autograd evaluation (cond_torch.py)
+    q2, f2 = _models()
+    assert not q2.cond_lora
+    names = q2.add_adapter(LoraConfig(r=4, target_modules="all-linear"), "b")
+    n_lin = 2 + 2 + 1 + 1 + TINY["num_layers"] * (2 + 8 + 4)     # timestep embedder, embedders, norm_out, proj_out, per block mod/attn/ff
+    assert len(names) == n_lin and q2.cond_lora
+    names = f2.add_adapter(LoraConfig(r=4, target_modules=["norm1.linear", "norm.linear", "proj_mlp"]), "b")
+    assert len(names) == FLUX_TINY["num_layers"] + 2 * FLUX_TINY["num_single_layers"] and f2.cond_lora
 
 
 @pytest.mark.parametrize("targets", [("to_k", "to_q", "to_v", "to_out.0"), ("to_k", "to_q", "to_v", "to_out.0", "net.0.proj", "net.2")])

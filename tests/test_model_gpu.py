@@ -394,3 +394,15 @@ def test_embedder_and_output_projection_lora_targets():
     assert res["ok"] and res["grads_nonzero"] == 2 * (8 + 3), res
     res = run_tiny_step_parity(DEV, verbose=True, r=4, targets=("img_in", "proj_out"), fused=False)
     assert res["ok"], res
+
+
+def test_all_linear_targets_match_oracle():
+    """target_modules: "all-linear" (configs/example_with_sampling.yaml:9): every nn.Linear of the DiT carries an adapter --
+    attention, feed-forward, embedders, output projection AND the conditioning head (timestep embedder, img_mod / txt_mod,
+    norm_out.linear), whose gradients need d(shift, scale, gate) from the HIP backward (qfx_mod_grad)."""
+    from parity_util import run_tiny_step_parity
+    res = run_tiny_step_parity(DEV, verbose=True, r=4, targets="all-linear")
+    # 2 blocks x (8 attention + 4 feed-forward + 2 modulation) + img_in, txt_in, proj_out, norm_out.linear, 2 timestep linears
+    assert res["ok"] and res["grads_nonzero"] >= 2 * (2 * 14 + 6) - 8, res
+    res = run_tiny_step_parity(DEV, verbose=True, r=4, targets=("img_mod.1", "txt_mod.1", "norm_out.linear", "to_q"), fused=False)
+    assert res["ok"], res
