@@ -194,6 +194,64 @@ class QwenImageTransformer2DModel(nn.Module):
         self._version = 0
 
     # ------------------------------------------------------------------ reference-surface methods
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder: str | None = None, torch_dtype=BF, device_map=None,
+                        variant: str | None = None, use_safetensors: bool = True, **unused):
+        """diffusers ModelMixin.from_pretrained for a LOCAL checkpoint folder (the reference's loader calls it with
+        subfolder="transformer", torch_dtype=weight_dtype, device_map="cpu": src/qflux/models/load_model.py:34-47,
+        flux_kontext_loader.py:145-181): `config.json` -> constructor arguments (unknown keys ignored), weights from
+        `diffusion_pytorch_model[.<variant>].safetensors` or its sharded form (`...safetensors.index.json` -> weight_map).
+        Hub ids are not resolved here (no network on the training nodes: pass the snapshot directory).  Extra keyword
+        arguments of the reference's call sites (attn_implementation, ...) are accepted and ignored."""
+        import inspect
+        import json
+        import os
+        from safetensors import safe_open
+        root = str(pretrained_model_name_or_path)
+        if subfolder:
+            root = os.path.join(root, subfolder)
+        if not os.path.isdir(root):
+            raise FileNotFoundError(f"{root}: from_pretrained needs a local checkpoint directory (hub ids are not resolved offline)")
+        if not use_safetensors:
+            raise NotImplementedError("only safetensors checkpoints are read")
+        with open(os.path.join(root, "config.json")) as f:
+            cfg = json.load(f)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        kwargs = {k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items() if k in accepted}
+        dtype = torch_dtype or BF
+        if dtype != BF:
+            raise NotImplementedError("the MI355X path keeps the frozen trunk in bf16 (weight_dtype of the reference's configs)")
+        device = torch.device("cpu")
+        if isinstance(device_map, (str, torch.device)) and str(device_map) not in ("cpu", "auto"):
+            device = torch.device(device_map)
+        with torch.device(device):
+            model = cls(**kwargs)
+        stem = "diffusion_pytorch_model" + (f".{variant}" if variant else "")
+        index = os.path.join(root, stem + ".safetensors.index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+        else:
+            files = [stem + ".safetensors"]
+        own = dict(model.named_parameters())
+        seen = set()
+        with torch.no_grad():
+            for fn in files:
+                with safe_open(os.path.join(root, fn), framework="pt", device=str(device)) as sf:
+                    for key in sf.keys():
+                        if key not in own:
+                            raise KeyError(f"unexpected key {key!r} in {fn}")
+                        t = sf.get_tensor(key)
+                        if tuple(t.shape) != tuple(own[key].shape):
+                            raise ValueError(f"{key}: checkpoint shape {tuple(t.shape)} != model shape {tuple(own[key].shape)}")
+                        own[key].copy_(t.to(own[key].dtype))
+                        seen.add(key)
+        missing = sorted(set(own) - seen)
+        if missing:
+            raise KeyError(f"{len(missing)} parameters missing from the checkpoint, e.g. {missing[:3]}")
+        model._invalidate()
+        return model
+
     @property
     def device(self):
         return self.norm_out.linear.weight.device if isinstance(self.norm_out.linear, QfxLinear) else next(self.parameters()).device

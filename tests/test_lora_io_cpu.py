@@ -68,3 +68,39 @@ def test_lora_checkpoint_roundtrip_both_styles(tmp_path, targets):
         assert set(got) == set(ref)
         for n in ref:
             assert torch.equal(got[n], ref[n]), n
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_from_pretrained_reads_a_diffusers_layout_checkpoint(tmp_path, sharded):
+    """ModelMixin.from_pretrained as the reference's loaders call it (load_model.py:34-47, flux_kontext_loader.py:168-175):
+    <root>/transformer/config.json + diffusion_pytorch_model.safetensors (or the sharded index form)."""
+    import json
+    from safetensors.torch import save_file
+    from common import fill_weights
+    from qflux_amd.models import FluxTransformer2DModel, QwenImageTransformer2DModel
+    for cls, cfg in ((QwenImageTransformer2DModel, TINY), (FluxTransformer2DModel, dict(FLUX_TINY, guidance_embeds=True))):
+        src = cls(**cfg)
+        fill_weights(src, seed=4)
+        root = tmp_path / cls.__name__ / ("s" if sharded else "m")
+        os.makedirs(root / "transformer")
+        conf = dict(cfg, _class_name=cls.__name__, _diffusers_version="0.36.0", axes_dims_rope=list(cfg["axes_dims_rope"]))
+        with open(root / "transformer" / "config.json", "w") as f:
+            json.dump(conf, f)
+        sd = {k: v.detach().clone().contiguous() for k, v in src.state_dict().items()}
+        if sharded:
+            keys = sorted(sd)
+            half = len(keys) // 2
+            parts = {"diffusion_pytorch_model-00001-of-00002.safetensors": keys[:half], "diffusion_pytorch_model-00002-of-00002.safetensors": keys[half:]}
+            for fn, ks in parts.items():
+                save_file({k: sd[k] for k in ks}, str(root / "transformer" / fn))
+            with open(root / "transformer" / "diffusion_pytorch_model.safetensors.index.json", "w") as f:
+                json.dump({"metadata": {}, "weight_map": {k: fn for fn, ks in parts.items() for k in ks}}, f)
+        else:
+            save_file(sd, str(root / "transformer" / "diffusion_pytorch_model.safetensors"))
+        m = cls.from_pretrained(str(root), subfolder="transformer", torch_dtype=torch.bfloat16, use_safetensors=True,
+                                attn_implementation="flash_attention_2", device_map="cpu")
+        assert type(m) is cls and m.config.num_layers == cfg["num_layers"]
+        for (n, a), (_, b) in zip(sorted(src.state_dict().items()), sorted(m.state_dict().items())):
+            assert torch.equal(a, b), n
+    with pytest.raises(FileNotFoundError):
+        QwenImageTransformer2DModel.from_pretrained("Qwen/Qwen-Image-Edit", subfolder="transformer")
