@@ -75,6 +75,29 @@ int qfx_gemm_bf16(const qfx_gemm_args* args, void* stream);
 #define QFX_MAX_GROUPS 6
 int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream);
 
+/* ---- low-precision trunk: MX-FP8 base GEMM (reference: src/qflux/models/quantize.py -- TE fp8 / bnb int8 / NF4 --
+ * whose MI355X analogue is the block-scaled FP8 MFMA, v_mfma_scale_f32_16x16x128_f8f6f4, at twice the bf16 matrix rate).
+ * OCP MX format: elements fp8 e4m3 (OCP e4m3fn), one shared E8M0 scale per 32 consecutive K elements,
+ *   scale exponent = floor(log2(max|v|)) - 8 (e4m3 emax), elements = RNE(v / 2^e) saturated to +-448.
+ * qfx_quant_mxfp8: X[M,K] bf16 (row stride ldx, optional joint-buffer row remap) -> Q[M,K] fp8 bytes (row stride ldq) and
+ *   S[M,K/32] E8M0 bytes (row stride lds).  K % 128 == 0.
+ * qfx_gemm_mxfp8: same contract as qfx_gemm_bf16 (bias, bf16 mid-rounding of the base output, bf16 LoRA K-extension segment
+ *   A2/B2, all four epilogues, row maps of C / aux) except that A1 / B1 are MX-FP8: g.A1 / g.B1 point at fp8 BYTES, lda1 / ldb1
+ *   are byte strides, K1 % 128 == 0, A1 rows are NOT remapped; sa / sb are the scale arrays of A1 [M, K1/32] and B1 [N, K1/32].
+ *   The product of two e4m3 values and a power-of-two scale is exact in fp32; accumulation is fp32 as in the bf16 kernel. */
+typedef struct qfx_quant_args {
+  const uint16_t* X; int64_t ldx; int32_t M; int32_t K;
+  uint8_t* Q; int64_t ldq; uint8_t* S; int64_t lds;
+  int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off;
+} qfx_quant_args;
+int qfx_quant_mxfp8(const qfx_quant_args* a, void* stream);
+typedef struct qfx_gemm_fp8_args {
+  qfx_gemm_args g;
+  const uint8_t* sa; int64_t ldsa;
+  const uint8_t* sb; int64_t ldsb;
+} qfx_gemm_fp8_args;
+int qfx_gemm_mxfp8(const qfx_gemm_fp8_args* a, void* stream);
+
 /* ---- LoRA rank-r down projection ("skinny" GEMM, HBM-bound) ----------------------------------
  * U[M,R] (fp32) = X[M,K] (bf16) * (W_hi + W_lo)[R,K]^T   (W = fp32 LoRA weight split in two bf16)
  * and its packed bf16 image EXT[M, 3R] = [U_hi | U_lo | U_hi] written at ext + m*ld_ext

@@ -29,6 +29,16 @@ class GemmArgs(C.Structure):
     ]
 
 
+class QuantArgs(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
+                ("Q", C.c_void_p), ("ldq", C.c_int64), ("S", C.c_void_p), ("lds", C.c_int64),
+                ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32)]
+
+
+class GemmFp8Args(C.Structure):
+    _fields_ = [("g", GemmArgs), ("sa", C.c_void_p), ("ldsa", C.c_int64), ("sb", C.c_void_p), ("ldsb", C.c_int64)]
+
+
 class LoraDownArgs(C.Structure):
     _fields_ = [
         ("X", C.c_void_p), ("ldx", C.c_int64), ("M", C.c_int32), ("K", C.c_int32),
@@ -114,6 +124,8 @@ _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "qfx_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "qfx_gemm_grouped": (C.c_int, [C.POINTER(GemmArgs), _i32, _vp]),
+    "qfx_quant_mxfp8": (C.c_int, [C.POINTER(QuantArgs), _vp]),
+    "qfx_gemm_mxfp8": (C.c_int, [C.POINTER(GemmFp8Args), _vp]),
     "qfx_lora_down": (C.c_int, [C.POINTER(LoraDownArgs), _vp]),
     "qfx_lora_down_batch": (C.c_int, [C.POINTER(LoraDownArgs), C.c_int32, _vp]),
     "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),

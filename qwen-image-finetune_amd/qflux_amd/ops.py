@@ -277,3 +277,57 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_n
     bc2 = 1.0 - beta2 ** step
     L.check(lib.qfx_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2, _p(gnorm_sq), max_norm,
                                grad_scale, stream_ptr()), "qfx_adamw_step")
+
+
+# ---------------------------------------------------------------------------------------------- MX-FP8 (low-precision trunk)
+def quant_mxfp8(x, M=None, rows_per_batch=None, x_map=(0, 0), out=None):
+    """x [*, K] bf16 (row stride x.stride(0)) -> (q uint8 [M, K], s uint8 [M, K/32]) in the OCP MX-FP8 format (qfx.h)."""
+    _bf(x, "x")
+    M = x.shape[0] if M is None else M
+    K = x.shape[1]
+    q, s = out if out is not None else (torch.empty(M, K, dtype=torch.uint8, device=x.device),
+                                        torch.empty(M, K // 32, dtype=torch.uint8, device=x.device))
+    a = L.QuantArgs()
+    a.X, a.ldx, a.M, a.K = _p(x), x.stride(0), M, K
+    a.Q, a.ldq, a.S, a.lds = _p(q), q.stride(0), _p(s), s.stride(0)
+    a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
+    a.x_batch_rows, a.x_row_off = x_map
+    L.check(lib.qfx_quant_mxfp8(C.byref(a), stream_ptr()), "qfx_quant_mxfp8")
+    return q, s
+
+
+def mxfp8_dequant(q, s):
+    """Host/torch view of an MX-FP8 operand as fp32 (test helper; not on the product path)."""
+    v = q.view(torch.float8_e4m3fn).float().view(q.shape[0], -1, 32)
+    sc = torch.pow(2.0, s.float() - 127.0).unsqueeze(-1)
+    return (v * sc).view(q.shape[0], -1)
+
+
+def gemm_mxfp8(aq, asc, bq, bsc, *, bias=None, a2=None, b2=None, out=None, epi=L.EPI_NONE, out2=None, aux=None, gate=None,
+               rows_per_batch=None, c_map=(0, 0), c_rows=None, row_mask=None):
+    """C = dequant(aq, asc) @ dequant(bq, bsc).T (+ a2 @ b2.T in bf16) + bias -> epilogue (same contract as ops.gemm)."""
+    M, K1 = aq.shape
+    N = bq.shape[0]
+    if out is None:
+        out = torch.empty(M if c_rows is None else c_rows, N, dtype=BF, device=aq.device)
+    f = L.GemmFp8Args()
+    g = f.g
+    g.A1, g.B1, g.lda1, g.ldb1, g.K1 = _p(aq), _p(bq), aq.stride(0), bq.stride(0), K1
+    if a2 is not None:
+        g.A2, g.B2, g.lda2, g.ldb2, g.K2 = _p(a2), _p(b2), a2.stride(0), b2.stride(0), b2.shape[1]
+    g.M, g.N = M, N
+    g.bias = _p(bias)
+    g.C, g.ldc = _p(out), out.stride(0)
+    if out2 is not None:
+        g.C2, g.ldc2 = _p(out2), out2.stride(0)
+    if aux is not None:
+        g.aux, g.ldaux = _p(aux), aux.stride(0)
+    if gate is not None:
+        g.gate, g.gate_bstride = _p(gate), gate.stride(0)
+    g.rows_per_batch = M if rows_per_batch is None else rows_per_batch
+    g.c_batch_rows, g.c_row_off = c_map
+    g.epi = epi
+    g.row_mask = _p(row_mask)
+    f.sa, f.ldsa, f.sb, f.ldsb = _p(asc), asc.stride(0), _p(bsc), bsc.stride(0)
+    L.check(lib.qfx_gemm_mxfp8(C.byref(f), stream_ptr()), "qfx_gemm_mxfp8")
+    return out
