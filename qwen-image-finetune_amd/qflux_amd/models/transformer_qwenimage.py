@@ -268,6 +268,7 @@ class QwenImageTransformer2DModel(nn.Module):
         self._prepared = None
         self._lora_prep = None
         self._plans = PlanCache()
+        self.__dict__.pop("_wq_cache", None)      # quantised copies of the frozen weights (low-precision trunk)
         self._version += 1
 
     def _apply(self, fn, *a, **k):
@@ -365,6 +366,19 @@ class QwenImageTransformer2DModel(nn.Module):
         names = load_lora_adapter(self, path, adapter_name, lora_alpha)
         self._invalidate()
         return names
+
+    def quantize_trunk(self, mode: str | None = "mxfp8"):
+        """Low-precision trunk switch (the reference's `model.quantize: true`, base_trainer.py:617-621,919-927 ->
+        quantize_model_to_fp8): "mxfp8" runs the forward GEMMs of the block linears on the block-scaled FP8 MFMA
+        (OCP MX-FP8: e4m3 elements, E8M0 scale per 32 K elements; weights quantised once, activations per launch); None
+        restores the bf16 trunk.  Adapters, biases, norms, attention and the whole backward stay bf16 / fp32."""
+        if mode not in (None, "mxfp8"):
+            raise ValueError(f"unknown trunk quantisation {mode!r} (supported: 'mxfp8')")
+        self._quant = mode
+        self.__dict__.pop("_wq_cache", None)
+        self._plans = PlanCache()
+        self._version += 1
+        return self
 
     def lora_parameters(self):
         return [p for n, p in self.named_parameters() if "lora_" in n]
@@ -811,15 +825,16 @@ class _QwenPlan:
         g.seg2_plain = seg2_plain
         g.aux_unmapped = aux_unmapped
         g.row_mask = _ptr(row_mask)
+        g._src = (A1, lda1, a_map, g.rows_per_batch, B1)     # python-side operand identities (low-precision forward re-targets them)
         return g
 
     def _gemm(self, prog, **kw):
-        g = self._gargs(**kw)
-        prog.keep.append(g)
-        prog.c(lib.qfx_gemm_bf16, C.byref(g))
+        self._gemm_group(prog, [self._gargs(**kw)])
 
     def _gemm_group(self, prog, groups):
         """One grid for several independent GEMMs with the same epilogue (image+text streams, q/k/v)."""
+        if prog is self.fwd and getattr(self.model, "_quant", None) == "mxfp8" and all(self._fp8_ok(g) for g in groups):
+            return self._gemm_group_mxfp8(prog, groups)
         if len(groups) == 1:
             prog.keep.append(groups[0])
             prog.c(lib.qfx_gemm_bf16, C.byref(groups[0]))
@@ -827,6 +842,51 @@ class _QwenPlan:
         arr = (L.GemmArgs * len(groups))(*groups)
         prog.keep.append(arr)
         prog.c(lib.qfx_gemm_grouped, arr, len(groups))
+
+    # ------------------------------------------------------------------ low-precision trunk (MX-FP8 forward GEMMs)
+    @staticmethod
+    def _fp8_ok(g):
+        A1, lda1, a_map, rpb, B1 = g._src
+        return (isinstance(B1, torch.Tensor) and B1.dim() == 2 and B1.is_contiguous() and g.K1 % 128 == 0 and g.K1 >= 1024 and g.N >= 1024
+                and B1.shape == (g.N, g.K1) and not g.seg2_plain)
+
+    def _gemm_group_mxfp8(self, prog, groups):
+        """Forward GEMMs of the block linears on the block-scaled FP8 MFMA (model.quantize = "mxfp8", the MI355X analogue of
+        the reference's quantized trunk, src/qflux/models/quantize.py): the frozen weight is quantised ONCE (cached on the model),
+        the activation operand once per distinct input of the group; bias, bf16 mid-rounding, the bf16 LoRA K-extension and the
+        epilogue are unchanged.  The backward stays on the bf16 operands (dX = dY W in bf16, adapters on the bf16 activations)."""
+        from .. import ops
+        cache = self.model.__dict__.setdefault("_wq_cache", {})
+        scratch = self.__dict__.setdefault("_q8", {})
+        quantised = {}
+        for g in groups:
+            A1, lda1, a_map, rpb, B1 = g._src
+            key = (B1.data_ptr(), tuple(B1.shape))
+            if key not in cache:
+                cache[key] = ops.quant_mxfp8(B1)
+            wq, ws = cache[key]
+            akey = (A1.data_ptr(), lda1, a_map, g.M)
+            if akey not in quantised:
+                slot = (g.M, g.K1, len(quantised))
+                if slot not in scratch:
+                    scratch[slot] = (self.buf(g.M, g.K1, dtype=torch.uint8), self.buf(g.M, g.K1 // 32, dtype=torch.uint8))
+                xq, xs = scratch[slot]
+                qa = L.QuantArgs()
+                qa.X, qa.ldx, qa.M, qa.K = _ptr(A1), lda1, g.M, g.K1
+                qa.Q, qa.ldq, qa.S, qa.lds = _ptr(xq), g.K1, _ptr(xs), g.K1 // 32
+                qa.rows_per_batch, qa.x_batch_rows, qa.x_row_off = rpb, a_map[0], a_map[1]
+                prog.keep.append(qa)
+                prog.c(lib.qfx_quant_mxfp8, C.byref(qa))
+                quantised[akey] = (xq, xs)
+            xq, xs = quantised[akey]
+            f = L.GemmFp8Args()
+            C.memmove(C.byref(f.g), C.byref(g), C.sizeof(L.GemmArgs))
+            f.g.A1, f.g.lda1, f.g.a_batch_rows, f.g.a_row_off = _ptr(xq), g.K1, 0, 0
+            f.g.B1, f.g.ldb1 = _ptr(wq), g.K1
+            f.sa, f.ldsa, f.sb, f.ldsb = _ptr(xs), g.K1 // 32, _ptr(ws), g.K1 // 32
+            prog.keep.append(f)
+            prog.keep.append((wq, ws))
+            prog.c(lib.qfx_gemm_mxfp8, C.byref(f))
 
     def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
               group_stride=0, rpb=None, x_map=(0, 0), defer=None):

@@ -97,3 +97,82 @@ def test_gemm_mxfp8_epilogues_and_lora_segment():
     torch.nn.functional.gelu(xg, approximate="tanh").sum().backward()
     want = ((ops.mxfp8_dequant(aq, asc) @ ops.mxfp8_dequant(bq, bsc).t() + bias.float()).to(BF).float() * xg.grad)
     assert ((o.float() - want).abs().max() / want.abs().max()).item() < 1e-2
+
+
+FULLW = dict(patch_size=2, in_channels=64, out_channels=16, attention_head_dim=128, num_attention_heads=8, joint_attention_dim=1024,
+             axes_dims_rope=(16, 56, 56))
+
+
+def test_mxfp8_trunk_step_matches_fp8_emulating_oracle():
+    """model.quantize_trunk("mxfp8"): forward GEMMs of the block linears in MX-FP8, backward in bf16 -- one LoRA training step of a
+    2-block DiT of width 1024 (the narrowest width whose linears are eligible: K % 128 == 0, K >= 1024) against the oracle with
+    fp8-emulated linears (oracle/mxfp8.py); and against the un-quantised bf16 oracle to show the size of the fp8 effect."""
+    import os
+    import sys
+    from oracle import mxfp8 as QX
+    from oracle import qwen_dit as O
+    from qflux_amd.models import QwenImageTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import QwenLoraTrainStep
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    with torch.device(DEV):
+        hip = QwenImageTransformer2DModel(num_layers=2, **FULLW)
+    g = torch.Generator(device=DEV).manual_seed(21)
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if p.ndim == 1 and "norm" in n:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=DEV) * 0.03).to(p.dtype))
+    hip.add_adapter(LoraConfig(r=8, lora_alpha=8), "default", generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(7)).to(p.device) * 1e-2)
+    gg = torch.Generator().manual_seed(4)
+    side, T = 12, 40
+    S_t = side * side
+    emb = dict(image_latents=torch.randn(2, S_t, 64, generator=gg).half().float(), control_latents=torch.randn(2, S_t, 64, generator=gg).half().float(),
+               prompt_embeds=(torch.randn(2, T, 1024, generator=gg) * 4).half().float(), prompt_embeds_mask=torch.ones(2, T, dtype=torch.int64),
+               img_shapes=[[(1, side, side), (1, side, side)]] * 2)
+    noise, u = torch.randn(2, S_t, 64, generator=gg), torch.tensor([0.7109, 0.1611])
+    sd = {k: v.cpu() for k, v in hip.state_dict().items()}
+    res = {}
+    for tag in ("fp8", "bf16"):
+        oracle = O.OracleQwenDiT(num_layers=2, **FULLW)
+        O.add_lora(oracle, r=8, lora_alpha=8, adapter_name="default")
+        oracle.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+        for n, p in oracle.named_parameters():
+            if "lora" not in n:
+                p.data = p.data.to(BF)
+        if tag == "fp8":
+            nq = QX.quantize_oracle(oracle)
+            assert nq == 2 * 12 + 1        # 12 block linears per block + txt_in (K = 1024); img_in / proj_out / modulation stay bf16
+        loss_o, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+        loss_o.float().backward()
+        res[tag] = (loss_o.item(), pred_o.detach().float(), {n: p.grad.float() for n, p in oracle.named_parameters() if "lora" in n and p.grad is not None})
+    hip.quantize_trunk("mxfp8")
+    step = QwenLoraTrainStep(hip)
+    loss_h = step.forward_backward(emb, noise=noise, u=u).item()
+    plan = list(hip._plans.values())[0]
+    names = [c[0].__name__ for c in plan.fwd.calls if c[0] is not None]
+    assert names.count("qfx_gemm_mxfp8") == 2 * 12 + 1 - 3 and "qfx_quant_mxfp8" in names     # last block: text out-proj + text MLP are dead compute
+    assert all(c[0].__name__ != "qfx_gemm_mxfp8" for c in plan.bwd.calls if c[0] is not None)
+    pred_h = plan.A["out"].view(2, -1, 64)[:, :S_t].float().cpu()
+    hg = {n: p.grad.float().cpu() for n, p in hip.named_parameters() if "lora" in n}
+
+    def rel(a, b):
+        return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+    e8, e16 = rel(pred_h, res["fp8"][1]), rel(pred_h, res["bf16"][1])
+    gap = rel(res["fp8"][1], res["bf16"][1])
+    gw = max(rel(hg[n], gr) for n, gr in res["fp8"][2].items())
+    print(f"mxfp8 trunk: loss hip {loss_h:.5f} oracle-fp8 {res['fp8'][0]:.5f} oracle-bf16 {res['bf16'][0]:.5f}; pred rel hip~fp8 {e8:.4f} "
+          f"hip~bf16 {e16:.4f} fp8~bf16 {gap:.4f}; worst LoRA grad rel vs fp8 oracle {gw:.4f}")
+    assert abs(loss_h - res["fp8"][0]) / abs(res["fp8"][0]) < 1e-2
+    assert e8 < 3e-2 and gw < 6e-2
+    assert e8 < gap      # the HIP path sits closer to the fp8-emulating oracle than the bf16 one: the quantisation is really applied
+    # switching back restores the bf16 trunk bit-exactly
+    hip.quantize_trunk(None)
+    step.zero_grad()
+    l2 = step.forward_backward(emb, noise=noise, u=u).item()
+    assert abs(l2 - res["bf16"][0]) / abs(res["bf16"][0]) < 5e-3
