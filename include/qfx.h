@@ -186,6 +186,21 @@ typedef struct qfx_ln_bwd_args {
 } qfx_ln_bwd_args;
 int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n, void* stream);
 int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n, void* stream);
+/* ---- fused LayerNorm+modulate forward AND the LoRA down projection of its output ("AdaLN fused into the projection
+ * prologue", BASELINE north_star): y = bf16(LN(x) * bf16(1 + scale[b])) + shift[b] as qfx_ln_modulate_fwd, and in the same pass over
+ * the row block u = y (W_hi + W_lo)^T with the K-extension image `ext` and the transposed split image `Ut` exactly as
+ * qfx_lora_down writes them (same rounding points and MFMA order; the fp32 row statistics are summed in a different order than
+ * in the one-wave-per-row kernel, so y may differ from it in the last bf16 ulp on rare elements).  Problems with
+ * W_hi == NULL are plain LayerNorm+modulate rows (the un-adapted stream of a block rides in the same launch).
+ * D % 256 == 0, D <= 3072, R in {16, 32, 48} and equal for all adapted problems of one call; n <= 2. */
+typedef struct qfx_ln_down_args {
+  qfx_ln_fwd_args ln;
+  const uint16_t* W_hi; const uint16_t* W_lo; int64_t ldw; int32_t R;
+  uint16_t* ext; int64_t ld_ext; uint16_t* Ut_hi; uint16_t* Ut_lo; int64_t ld_ut;
+  int32_t group_R; int32_t group_stride;
+} qfx_ln_down_args;
+int qfx_ln_down_fwd(const qfx_ln_down_args* list, int32_t n, void* stream);
+
 /* ---- gradients of the AdaLN modulation vectors (needed only when the modulation linears carry adapters:
  * `img_mod.1` / `norm1.linear` ... in target_modules, configs/face_seg_flux_kontext_fp16.yaml:11, "all-linear").
  * For xm = bf16(LN(x) * bf16(1 + scale[b])) + shift[b]   (transformer_qwenimage.py:443-448; AdaLayerNormZero)

@@ -65,27 +65,34 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) xs[i][rb] = ks < nks ? *(const bf16x8*)(xrow[rb] + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
-    bf16x8 hcur[NF], lcur[NF], hnext[NF], lnext[NF];
+    // weight fragments: L2 hits streamed through a register ring DEPTH k-steps deep (all of the chunk for one fragment column:
+    // with a single step of look-ahead the CHK dependent L2 round trips were most of the launch)
+    constexpr int DEPTH = (NF == 1 ? CHK : (NF == 2 ? 6 : 3)) < CHK ? (NF == 1 ? CHK : (NF == 2 ? 6 : 3)) : CHK;
+    bf16x8 rh[DEPTH][NF], rl[DEPTH][NF];
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) { hcur[nf] = *(const bf16x8*)(wh[nf] + base * 32); lcur[nf] = *(const bf16x8*)(wl[nf] + base * 32); }
+    for (int d = 0; d < DEPTH; ++d) {
+      const int ks = base + d * NW;
+      if (ks < nks) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) { rh[d][nf] = *(const bf16x8*)(wh[nf] + ks * 32); rl[d][nf] = *(const bf16x8*)(wl[nf] + ks * 32); }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < CHK; ++i) {
-      const int ksn = base + (i + 1) * NW;
-      if (i + 1 < CHK && ksn < nks) {
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) { hnext[nf] = *(const bf16x8*)(wh[nf] + ksn * 32); lnext[nf] = *(const bf16x8*)(wl[nf] + ksn * 32); }
-      }
       if (base + i * NW < nks) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
           for (int rb = 0; rb < RB; ++rb) {
-            acc[rb][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i][rb], hcur[nf], acc[rb][nf], 0, 0, 0);
-            acc[rb][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i][rb], lcur[nf], acc[rb][nf], 0, 0, 0);
+            acc[rb][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i][rb], rh[i % DEPTH][nf], acc[rb][nf], 0, 0, 0);
+            acc[rb][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i][rb], rl[i % DEPTH][nf], acc[rb][nf], 0, 0, 0);
           }
       }
+      const int ksn = base + (i + DEPTH) * NW;
+      if (i + DEPTH < CHK && ksn < nks) {
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) { hcur[nf] = hnext[nf]; lcur[nf] = lnext[nf]; }
+        for (int nf = 0; nf < NF; ++nf) { rh[i % DEPTH][nf] = *(const bf16x8*)(wh[nf] + ksn * 32); rl[i % DEPTH][nf] = *(const bf16x8*)(wl[nf] + ksn * 32); }
+      }
     }
   }
 #pragma unroll
@@ -105,6 +112,159 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
     const int j = nf * 16 + (ln & 15);
     if (m >= p.M) continue;
     if (p.U) p.U[(int64_t)m * p.ldu + j] = v;
+    const bf16_t hi = f2bf(v);
+    const bf16_t lo = f2bf(v - bf2f(hi));
+    if (p.ext) {
+      bf16_t* e0 = p.ext + (int64_t)m * p.ld_ext + (j / p.group_R) * p.group_stride + (j % p.group_R);
+      e0[0] = hi;
+      e0[p.group_R] = lo;
+      e0[2 * p.group_R] = hi;
+    }
+    if (p.Ut_hi) {
+      p.Ut_hi[(int64_t)j * p.ld_ut + m] = hi;
+      p.Ut_lo[(int64_t)j * p.ld_ut + m] = lo;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused LayerNorm+modulate forward + LoRA down projection.  Block = 16 rows x 8 waves; wave w owns the 32-column k-steps
+// w, w+8, ... of the 16 rows as MFMA A fragments (lane (g, li): row li, columns 32 ks + 8 g .. +8), so the normalised, modulated
+// row block never leaves the registers between the LayerNorm and the rank-r contraction: one pass over x instead of
+// LayerNorm (read x, write y) + lora_down (read y).  Row statistics: per-lane partial sums -> the 4 lane groups of a row by
+// shuffles -> the 8 waves through LDS (two rounds: mean, then centred second moment, as the stand-alone kernel).
+struct LnDownBatch { qfx_ln_down_args a[2]; int start[3]; int n; };
+
+template <int NF>
+__global__ __launch_bounds__(512) void ln_down_kernel(const LnDownBatch batch_by_value) {
+  constexpr int NW = 8, CH = 12;              // CH k-steps per wave: D <= 8 * 12 * 32 = 3072
+  __shared__ float red[NW][NF * 256];
+  __shared__ float stat[2][NW][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const QFX_AS4 LnDownBatch& kb = *(const QFX_AS4 LnDownBatch*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int pi = (kb.n > 1 && (int)blockIdx.x >= kb.start[1]) ? 1 : 0;
+  const QFX_AS4 qfx_ln_down_args& p = kb.a[pi];
+  const int m0 = ((int)blockIdx.x - kb.start[pi]) * 16;
+  const int D = p.ln.D, rows = p.ln.rows;
+  const int nks = D / 32;
+  int mr = m0 + li;
+  const bool row_ok = mr < rows;
+  mr = row_ok ? mr : rows - 1;
+  const int b = mr / p.ln.rows_per_batch;
+  const bf16_t* xrow = p.ln.x + (int64_t)mr * D + 8 * g;
+  const bf16_t* scr = p.ln.scale + (int64_t)b * p.ln.mod_bstride + 8 * g;
+  const bf16_t* shr = p.ln.shift + (int64_t)b * p.ln.mod_bstride + 8 * g;
+
+  // ---- the wave's slice of the 16 rows, requested up front (one HBM latency)
+  bf16x8 xs[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int ks = w + i * NW;
+    xs[i] = ks < nks ? *(const bf16x8*)(xrow + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f((bf16_t)xs[i][j]);        // absent k-steps contribute zeros
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if (g == 0) stat[0][w][li] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < NW; ++ww) mean += stat[0][ww][li];
+  mean /= (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (w + i * NW < nks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = bf2f((bf16_t)xs[i][j]) - mean; q += d * d; }
+    }
+  }
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  if (g == 0) stat[1][w][li] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < NW; ++ww) var += stat[1][ww][li];
+  const float rstd = rsqrtf(var / (float)D + p.ln.eps);
+
+  // ---- modulate (rounding points of the stand-alone kernel), store y, keep the bf16 fragments for the MFMAs
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int ks = w + i * NW;
+    if (ks < nks) {
+      const bf16x8 sc = *(const bf16x8*)(scr + ks * 32);
+      const bf16x8 sh = *(const bf16x8*)(shr + ks * 32);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ln = rbf((bf2f((bf16_t)xs[i][j]) - mean) * rstd);
+        const float t1 = rbf(1.0f + bf2f((bf16_t)sc[j]));
+        o[j] = (short)f2bf(rbf(ln * t1) + bf2f((bf16_t)sh[j]));
+      }
+      xs[i] = o;
+      if (row_ok) *(bf16x8*)(p.ln.y + (int64_t)mr * D + 8 * g + ks * 32) = o;
+    }
+  }
+  if (p.W_hi == nullptr) return;             // plain LayerNorm rows (block-uniform)
+
+  // ---- rank-r contraction of the wave's k-steps (weights are L2 hits, double-buffered one step ahead)
+  const bf16_t* wh[NF];
+  const bf16_t* wl[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    wh[nf] = p.W_hi + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
+    wl[nf] = p.W_lo + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
+  }
+  f32x4 acc[NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // weight fragments stream from L2 through a 3-deep register ring (three k-steps in flight: with one step of look-ahead the
+  // twelve dependent L2 round trips were most of the kernel)
+  constexpr int DEPTH = 3;
+  bf16x8 wr_h[DEPTH][NF], wr_l[DEPTH][NF];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int ks = w + d * NW;
+    if (ks < nks) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) { wr_h[d][nf] = *(const bf16x8*)(wh[nf] + ks * 32); wr_l[d][nf] = *(const bf16x8*)(wl[nf] + ks * 32); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (w + i * NW < nks) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i], wr_h[i % DEPTH][nf], acc[nf], 0, 0, 0);
+        acc[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xs[i], wr_l[i % DEPTH][nf], acc[nf], 0, 0, 0);
+      }
+    }
+    const int ksn = w + (i + DEPTH) * NW;
+    if (i + DEPTH < CH && ksn < nks) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) { wr_h[i % DEPTH][nf] = *(const bf16x8*)(wh[nf] + ksn * 32); wr_l[i % DEPTH][nf] = *(const bf16x8*)(wl[nf] + ksn * 32); }
+    }
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][(nf * 64 + lane) * 4 + r] = acc[nf][r];
+  __syncthreads();
+  for (int e = tid; e < NF * 256; e += 512) {
+    float v = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) v += red[ww][e];
+    const int r = e & 3, ln = (e >> 2) & 63, nf = e >> 8;
+    const int m = m0 + 4 * (ln >> 4) + r;   // D[i = 4g+r][j = lane&15]
+    const int j = nf * 16 + (ln & 15);
+    if (m >= rows) continue;
     const bf16_t hi = f2bf(v);
     const bf16_t lo = f2bf(v - bf2f(hi));
     if (p.ext) {
@@ -359,6 +519,38 @@ extern "C" int qfx_lora_down_batch(const qfx_lora_down_args* list, int32_t n, vo
     default: return QFX_EUNSUPPORTED;
   }
 #undef QFX_DOWN
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_ln_down_fwd(const qfx_ln_down_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 2) return QFX_EINVAL;
+  LnDownBatch b;
+  int blocks = 0, R = 0;
+  for (int i = 0; i < n; ++i) {
+    const qfx_ln_down_args& a = list[i];
+    if (!a.ln.x || !a.ln.shift || !a.ln.scale || !a.ln.y || a.ln.rows <= 0 || a.ln.rows_per_batch <= 0) return QFX_EINVAL;
+    if (a.ln.D <= 0 || (a.ln.D % 256) || a.ln.D > 3072 || (a.ln.mod_bstride % 8)) return QFX_EUNSUPPORTED;
+    if (a.W_hi) {
+      if (!a.W_lo || (a.ldw % 8) || a.R <= 0 || (a.R % 16) || a.R > 48) return QFX_EUNSUPPORTED;
+      if (R && a.R != R) return QFX_EINVAL;
+      R = a.R;
+      if (a.ext && (a.group_R <= 0 || (a.R % a.group_R))) return QFX_EINVAL;
+      if (a.Ut_hi && (!a.Ut_lo || a.ld_ut < a.ln.rows)) return QFX_EINVAL;
+    }
+    b.a[i] = a;
+    b.start[i] = blocks;
+    blocks += (a.ln.rows + 15) / 16;
+  }
+  for (int i = n; i <= 2; ++i) b.start[i] = blocks;
+  if (n == 1) b.a[1] = list[0];
+  b.n = n;
+  hipStream_t s = (hipStream_t)stream;
+  switch (R / 16) {
+    case 0: case 1: hipLaunchKernelGGL(ln_down_kernel<1>, dim3(blocks), dim3(512), 0, s, b); break;
+    case 2: hipLaunchKernelGGL(ln_down_kernel<2>, dim3(blocks), dim3(512), 0, s, b); break;
+    default: hipLaunchKernelGGL(ln_down_kernel<3>, dim3(blocks), dim3(512), 0, s, b); break;
+  }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -66,6 +66,12 @@ class LnFwdArgs(C.Structure):
                 ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
 
 
+class LnDownArgs(C.Structure):
+    _fields_ = [("ln", LnFwdArgs), ("W_hi", C.c_void_p), ("W_lo", C.c_void_p), ("ldw", C.c_int64), ("R", C.c_int32),
+                ("ext", C.c_void_p), ("ld_ext", C.c_int64), ("Ut_hi", C.c_void_p), ("Ut_lo", C.c_void_p), ("ld_ut", C.c_int64),
+                ("group_R", C.c_int32), ("group_stride", C.c_int32)]
+
+
 class LnBwdArgs(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("scale", C.c_void_p), ("mod_bstride", C.c_int64),
                 ("dres", C.c_void_p), ("gate", C.c_void_p), ("gate_bstride", C.c_int64), ("dx", C.c_void_p), ("dyg", C.c_void_p),
@@ -134,6 +140,7 @@ SYMBOLS = {
     "qfx_ln_modulate_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f, _vp]),
     "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),
     "qfx_ln_modulate_fwd_batch": (C.c_int, [C.POINTER(LnFwdArgs), C.c_int32, _vp]),
+    "qfx_ln_down_fwd": (C.c_int, [C.POINTER(LnDownArgs), C.c_int32, _vp]),
     "qfx_ln_modulate_bwd_batch": (C.c_int, [C.POINTER(LnBwdArgs), C.c_int32, _vp]),
     "qfx_mod_grad": (C.c_int, [C.POINTER(ModGradArgs), _vp]),
     "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),

@@ -503,11 +503,16 @@ class _FluxPlan(_QwenPlan):
         M = B * S
         grp = w["qkv_lora"]
         xm = bb.get("xm", A["xm_j"])
-        p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 3 * D, _ptr(xm), M, D, S, eps)
         q2 = bb["qkv"].view(M, 3 * D)
-        if grp is not None:
-            self._down(p, X=xm, ldx=D, M=M, K=D, W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"], Ut=bb["Uqkv"],
-                       ext=A["ext3_j"], ld_ext=A["ext3_j"].stride(0), group_R=grp["Rp"], group_stride=grp["Kext"])
+        fused = grp is not None and self._ln_down(p, [(self._ln_fwd_args(x, mod[:, 0:D], mod[:, D:2 * D], 3 * D, xm, M, D, S, eps),
+                                                       dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"], Ut=bb["Uqkv"],
+                                                            ext=A["ext3_j"], ld_ext=A["ext3_j"].stride(0), group_R=grp["Rp"],
+                                                            group_stride=grp["Kext"]))])
+        if not fused:
+            p.c(lib.qfx_ln_modulate_fwd, _ptr(x), _ptr(mod[:, 0:D]), _ptr(mod[:, D:2 * D]), 3 * D, _ptr(xm), M, D, S, eps)
+            if grp is not None:
+                self._down(p, X=xm, ldx=D, M=M, K=D, W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"], Ut=bb["Uqkv"],
+                           ext=A["ext3_j"], ld_ext=A["ext3_j"].stride(0), group_R=grp["Rp"], group_stride=grp["Kext"])
         groups = []
         for sec in range(3):
             lw = w["qkv"][sec]

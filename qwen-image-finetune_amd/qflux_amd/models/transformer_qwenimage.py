@@ -922,6 +922,30 @@ class _QwenPlan:
         a.row_mask, a.rows, a.D, a.rows_per_batch, a.eps = _ptr(row_mask), rows, D, rpb, eps
         return a
 
+    def _ln_down(self, prog, entries):
+        """LayerNorm+modulate of up to two streams with the LoRA down projection of the adapted ones fused in (qfx_ln_down_fwd).
+        entries: [(LnFwdArgs, None | dict(W_hi, W_lo, ldw, R, Ut, ext, ld_ext, group_R, group_stride))].  Returns False when the
+        shape is outside the fused kernel's range (caller falls back to the two separate launches)."""
+        import os
+        D = entries[0][0].D
+        rs = {d["R"] for _, d in entries if d is not None}
+        # (streams without adapters take the same kernel as plain LayerNorm rows, so that a zero adapter reproduces the frozen
+        # model bit for bit: one LayerNorm arithmetic per site, adapted or not)
+        if os.environ.get("QFX_FUSE_LN_DOWN", "1") == "0" or len(rs) > 1 or (rs and max(rs) > 48) or D % 256 or D > 3072 or len(entries) > 2:
+            return False
+        arr = (L.LnDownArgs * len(entries))()
+        for i, (ln, d) in enumerate(entries):
+            C.memmove(C.byref(arr[i].ln), C.byref(ln), C.sizeof(L.LnFwdArgs))
+            if d is not None:
+                a = arr[i]
+                a.W_hi, a.W_lo, a.ldw, a.R = _ptr(d["W_hi"]), _ptr(d["W_lo"]), d["ldw"], d["R"]
+                a.ext, a.ld_ext = _ptr(d["ext"]), d["ld_ext"]
+                a.Ut_hi, a.Ut_lo, a.ld_ut = _ptr(d["Ut"][0]), _ptr(d["Ut"][1]), d["Ut"][0].stride(0)
+                a.group_R, a.group_stride = d.get("group_R", d["R"]), d.get("group_stride", 0)
+        prog.keep.append(arr)
+        prog.c(lib.qfx_ln_down_fwd, arr, len(entries))
+        return True
+
     @staticmethod
     def _flush_ln(prog, pending, struct, fn):
         """One launch for the LayerNorm problems of both streams (ragged row counts go last: only the last problem of a batch
@@ -1073,17 +1097,28 @@ class _QwenPlan:
             # ---- LN1 + modulate, LoRA down-projections, then ONE grouped launch for the 6 q/k/v projections
             groups = []
             lnl = []
+            ents = []
             for s, sidx in STREAMS:
                 mod = mods[s]
-                xm1 = bb["xm1." + s] if w[s + ".qkv_lora"] is not None else A["xm"][s]
-                lnl.append(self._ln_fwd_args(x_in[s], mod[:, 0:D], mod[:, D:2 * D], 6 * D, xm1, rows[s], D, rpb[s], eps))
-            self._flush_ln(p, lnl, L.LnFwdArgs, lib.qfx_ln_modulate_fwd_batch)
+                grp = w[s + ".qkv_lora"]
+                xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
+                ln = self._ln_fwd_args(x_in[s], mod[:, 0:D], mod[:, D:2 * D], 6 * D, xm1, rows[s], D, rpb[s], eps)
+                lnl.append(ln)
+                ents.append((ln, None if grp is None else dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
+                                                               Ut=bb["Uqkv." + s], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
+                                                               group_R=grp["Rp"], group_stride=grp["Kext"])))
+            # LayerNorm+modulate and the q/k/v down projection of its output in ONE pass over the row block (qfx_ln_down_fwd)
+            fused = self._ln_down(p, ents)
+            if fused:
+                lnl.clear()
+            else:
+                self._flush_ln(p, lnl, L.LnFwdArgs, lib.qfx_ln_modulate_fwd_batch)
             for s, sidx in STREAMS:
                 mod = mods[s]
                 x = x_in[s]
                 grp = w[s + ".qkv_lora"]
                 xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
-                if grp is not None:
+                if grp is not None and not fused:
                     self._down(p, X=xm1, ldx=D, M=rows[s], K=D, W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
                                Ut=bb["Uqkv." + s], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
                                group_R=grp["Rp"], group_stride=grp["Kext"])

@@ -605,3 +605,54 @@ def test_adamw_matches_torch():
         ops.sumsq(gd, nsq)
         ops.adamw_step(p, gd, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, gnorm_sq=nsq, max_norm=1.0)
     check("adamw", p, p_ref.detach(), 1e-5)
+
+
+@pytest.mark.parametrize("D,rows,R,rpb", [(256, 100, 16, 50), (1024, 77, 48, 77), (3072, 2048, 48, 2048), (3072, 2432, 16, 1216)])
+def test_ln_down_fused_matches_the_two_separate_launches(D, rows, R, rpb):
+    """qfx_ln_down_fwd == qfx_ln_modulate_fwd followed by qfx_lora_down (K-extension image, transposed split image, y)."""
+    import ctypes as C
+    from qflux_amd import _lib as L
+    ops = _ops()
+    B = rows // rpb
+    x = randn(rows, D, seed=1, scale=2.0).to(BF).to(DEV)
+    mod = (randn(B, 2 * D, seed=2) * 0.3).to(BF).to(DEV)
+    A = randn(R, D, seed=3, scale=0.05)
+    a_hi, a_lo = _split(A)
+    a_hi, a_lo = a_hi.to(DEV), a_lo.to(DEV)
+    gR, gS = (16, 64) if R == 48 else (R, 0)
+    mp = (rows + 127) // 128 * 128
+    outs = []
+    for fused in (False, True):
+        y = torch.empty(rows, D, dtype=BF, device=DEV)
+        ext = torch.zeros(rows, 3 * 64, dtype=BF, device=DEV)
+        ut = (torch.zeros(R, mp, dtype=BF, device=DEV), torch.zeros(R, mp, dtype=BF, device=DEV))
+        if not fused:
+            L.check(ops.lib.qfx_ln_modulate_fwd(x.data_ptr(), mod[:, :D].data_ptr(), mod[:, D:].data_ptr(), 2 * D, y.data_ptr(), rows, D, rpb, 1e-6,
+                                                ops.stream_ptr()), "ln")
+            ops.lora_down(y, a_hi, a_lo, ext=ext, Ut=ut, group_R=gR, group_stride=gS)
+        else:
+            arr = (L.LnDownArgs * 2)()
+            # problem 0: adapted rows; problem 1: the same rows again as a plain LayerNorm problem (W_hi = NULL) into a scratch output
+            y2 = torch.empty(rows, D, dtype=BF, device=DEV)
+            for i, (yy, adapted) in enumerate(((y, True), (y2, False))):
+                a = arr[i]
+                a.ln.x, a.ln.shift, a.ln.scale, a.ln.mod_bstride, a.ln.y = x.data_ptr(), mod[:, :D].data_ptr(), mod[:, D:].data_ptr(), 2 * D, yy.data_ptr()
+                a.ln.rows, a.ln.D, a.ln.rows_per_batch, a.ln.eps = rows, D, rpb, 1e-6
+                if adapted:
+                    a.W_hi, a.W_lo, a.ldw, a.R = a_hi.data_ptr(), a_lo.data_ptr(), D, R
+                    a.ext, a.ld_ext = ext.data_ptr(), ext.stride(0)
+                    a.Ut_hi, a.Ut_lo, a.ld_ut = ut[0].data_ptr(), ut[1].data_ptr(), mp
+                    a.group_R, a.group_stride = gR, gS
+            L.check(ops.lib.qfx_ln_down_fwd(arr, 2, ops.stream_ptr()), "ln_down")
+            torch.cuda.synchronize()
+            assert torch.equal(y, y2)
+        torch.cuda.synchronize()
+        outs.append((y.float().cpu(), ext.float().cpu(), ut[0].float().cpu() + ut[1].float().cpu()))
+    (y0, e0, u0), (y1, e1, u1) = outs
+    # y: same rounding points; the fp32 row statistics are summed in another order -> at most one bf16 ulp on rare elements
+    ny = (y0 != y1).float().mean().item()
+    assert ny < 2e-3 and ((y0 - y1).abs().max() / y0.abs().max()).item() < 1e-2, ny
+    # u (hi + lo ~ fp32): relative to its scale
+    assert ((u0 - u1).abs().max() / u0.abs().max()).item() < 2e-3
+    assert ((e0 - e1).abs().max() / e0.abs().max()).item() < 8e-3
+    assert mp == rows or u1[:, rows:].abs().max().item() == 0.0
