@@ -61,13 +61,43 @@ def read_pass(folder: str, counter: str):
     return acc
 
 
+def mfma_summary(folder, out, cmd):
+    """--pmc MfmaUtil VALUBusy pass -> per kernel INSTANTIATION averages (derived metrics use the gfx94x formulas: ROCm 7.2 ships none
+    for gfx950).  python tools/pmc_to_json.py --mfma gpurun_out/pmc_mfma -o profiles/r02_pmc_mfma.json"""
+    files = glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True)
+    acc = {}
+    for path in files:
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                k = short_name(row["Kernel_Name"])
+                if k is None:
+                    continue
+                m = re.search(re.escape(k) + r"(<[^(]*>)?", row["Kernel_Name"])
+                name = m.group(0) if m else k
+                rec = acc.setdefault(name, {})
+                c = rec.setdefault(row["Counter_Name"], [0, 0.0])
+                c[0] += 1
+                c[1] += float(row["Counter_Value"])
+    res = {"source": f"rocprofv3 --pmc MfmaUtil VALUBusy --kernel-trace -- {cmd} (own pass; kernels are serialised by the counter collection)",
+           "generator": "tools/pmc_to_json.py --mfma", "kernels": {}}
+    for name, rec in sorted(acc.items()):
+        res["kernels"][name] = {"launches": max(v[0] for v in rec.values()),
+                                **{cn + "_pct": round(v[1] / v[0], 2) for cn, v in rec.items()}}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: v for k, v in res["kernels"].items() if "gemm" in k or "attn" in k}))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("fetch_dir")
-    ap.add_argument("write_dir")
+    ap.add_argument("fetch_dir", nargs="?")
+    ap.add_argument("write_dir", nargs="?")
     ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("--mfma", default=None, help="folder of a --pmc MfmaUtil VALUBusy pass: write the MFMA-utilisation summary instead")
     ap.add_argument("--cmd", default="python bench.py --steps 2 --warmup 1 --no-cpu-baseline")
     args = ap.parse_args(argv)
+    if args.mfma:
+        return mfma_summary(args.mfma, args.out, args.cmd)
     fetch = read_pass(args.fetch_dir, "FETCH_SIZE")
     write = read_pass(args.write_dir, "WRITE_SIZE")
     out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- {args.cmd}",
