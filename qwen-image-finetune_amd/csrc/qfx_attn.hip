@@ -138,19 +138,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
   const int tr1 = 4 * g + (li >> 2);
   const int toff0 = tr1 * (DH * 2) + ((((li & 3) >> 1) ^ swz_row<DH>(tr1)) << 4) + (li & 1) * 8;
   const int ntiles = (S + 63) / 64;
-  stage_rows_n<DH, NW>(smem, Kb, a.ldk, 0, S, w, lane);
-  stage_rows_n<DH, NW>(smem + TB, Vb, a.ldv, 0, S, w, lane);
-  __syncthreads();
-  for (int jt = 0; jt < ntiles; ++jt) {
-    const char* sK = smem + (jt & 1) * 2 * TB;
-    const char* sV = sK + TB;
-    if (jt + 1 < ntiles) {
-      char* nK = smem + ((jt + 1) & 1) * 2 * TB;
-      stage_rows_n<DH, NW>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
-      stage_rows_n<DH, NW>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
-    }
-    const int j0 = jt * 64;
-    f32x4 sacc[4][2];
+  f32x4 sacc[4][2];
+  auto qk = [&](const char* sK) {
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) { sacc[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sacc[kf][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     // k-chunk outer, key fragment inner: 8 independent accumulators between two MFMAs of the same chain
@@ -163,6 +152,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         sacc[kf][1] = MFMA(kfr, qf[1][kk], sacc[kf][1]);
       }
     }
+  };
+  auto sm_pv = [&](const char* sV, int j0) {
     // online softmax in the log2 domain (lane owns query column li of each q-fragment; keys 16kf+4g+r).
     // Masking work only where it can matter: the ragged last tile or an additive key mask.
     const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);   // wave-uniform
@@ -238,6 +229,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         oacc[d][0] = MFMA(vfr, pb[0][t], oacc[d][0]);
         oacc[d][1] = MFMA(vfr, pb[1][t], oacc[d][1]);
       }
+  };
+  stage_rows_n<DH, NW>(smem, Kb, a.ldk, 0, S, w, lane);
+  stage_rows_n<DH, NW>(smem + TB, Vb, a.ldv, 0, S, w, lane);
+  __syncthreads();
+  for (int jt = 0; jt < ntiles; ++jt) {
+    const char* sK = smem + (jt & 1) * 2 * TB;
+    const char* sV = sK + TB;
+    if (jt + 1 < ntiles) {
+      char* nK = smem + ((jt + 1) & 1) * 2 * TB;
+      stage_rows_n<DH, NW>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
+      stage_rows_n<DH, NW>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
+    }
+    qk(sK);
+    sm_pv(sV, jt * 64);
     __syncthreads();
   }
 #pragma unroll

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqfx.so")
+LIB_PATH = os.environ.get("QFX_LIB_PATH") or os.path.join(_HERE, "libqfx.so")   # QFX_LIB_PATH: lab builds (tools/build_variants.py)
 
 c_u16p = C.c_void_p
 c_f32p = C.c_void_p
