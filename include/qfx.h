@@ -79,11 +79,14 @@ int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream);
  * whose MI355X analogue is the block-scaled FP8 MFMA, v_mfma_scale_f32_16x16x128_f8f6f4, at twice the bf16 matrix rate).
  * OCP MX format: elements fp8 e4m3 (OCP e4m3fn), one shared E8M0 scale per 32 consecutive K elements,
  *   scale exponent = floor(log2(max|v|)) - 8 (e4m3 emax), elements = RNE(v / 2^e) saturated to +-448.
- * qfx_quant_mxfp8: X[M,K] bf16 (row stride ldx, optional joint-buffer row remap) -> Q[M,K] fp8 bytes (row stride ldq) and
- *   S[M,K/32] E8M0 bytes (row stride lds).  K % 128 == 0.
+ * qfx_quant_mxfp8: X[M,K] bf16 (row stride ldx, optional joint-buffer row remap) -> Q[M,K] fp8 bytes (row stride ldq) and the
+ *   E8M0 scale bytes S in TILE-MAJOR order [K/128][M][4]: the scale of row m, 32-element block kb sits at byte
+ *   ((kb/4)*M + m)*4 + kb%4, so that the 16 rows of an MFMA fragment read one contiguous 64-byte line per K tile.  K % 128 == 0.
+ *   (`lds` / `ldsa` / `ldsb` are unused, kept for ABI stability.)
  * qfx_gemm_mxfp8: same contract as qfx_gemm_bf16 (bias, bf16 mid-rounding of the base output, bf16 LoRA K-extension segment
  *   A2/B2, all four epilogues, row maps of C / aux) except that A1 / B1 are MX-FP8: g.A1 / g.B1 point at fp8 BYTES, lda1 / ldb1
- *   are byte strides, K1 % 128 == 0, A1 rows are NOT remapped; sa / sb are the scale arrays of A1 [M, K1/32] and B1 [N, K1/32].
+ *   are byte strides, K1 % 128 == 0, A1 rows are NOT remapped; sa / sb are the tile-major scale arrays of A1 ([K1/128][M][4]) and
+ *   B1 ([K1/128][N][4]).
  *   The product of two e4m3 values and a power-of-two scale is exact in fp32; accumulation is fp32 as in the bf16 kernel. */
 typedef struct qfx_quant_args {
   const uint16_t* X; int64_t ldx; int32_t M; int32_t K;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const qfx_quant_args a
     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
     u32x2 o = {w0, w1};
     *(u32x2*)(a.Q + (int64_t)m * a.ldq + kb * 32 + sub * 8) = o;
-    if (sub == 0) a.S[(int64_t)m * a.lds + kb] = (uint8_t)(e + 127);
+    if (sub == 0) a.S[((int64_t)(kb >> 2) * a.M + m) * 4 + (kb & 3)] = (uint8_t)(e + 127);   // tile-major: [K/128][M][4]
   }
 }
 
@@ -118,13 +118,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const qfx_gemm_fp8_arg
   for (int i = 0; i < 4; ++i) {
     int gm = m0 + wr * 64 + i * 16 + li; gm = gm < p.M ? gm : p.M - 1;
     int gn = n0 + wc * 64 + i * 16 + li; gn = gn < p.N ? gn : p.N - 1;
-    sap[i] = q.sa + (int64_t)gm * q.ldsa;
-    sbp[i] = q.sb + (int64_t)gn * q.ldsb;
+    sap[i] = q.sa + (int64_t)gm * 4;
+    sbp[i] = q.sb + (int64_t)gn * 4;
   }
+  const int64_t sa_tile = (int64_t)p.M * 4, sb_tile = (int64_t)p.N * 4;      // bytes between K tiles of the tile-major scale arrays
   uint32_t sca[4], scbv[4], scan[4], scbn[4];
   auto load_scales = [&](int t, uint32_t (&sa_)[4], uint32_t (&sb_)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { sa_[i] = ((const uint32_t*)sap[i])[t]; sb_[i] = ((const uint32_t*)sbp[i])[t]; }
+    for (int i = 0; i < 4; ++i) { sa_[i] = *(const uint32_t*)(sap[i] + t * sa_tile); sb_[i] = *(const uint32_t*)(sbp[i] + t * sb_tile); }
   };
 
   stage(0);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const qfx_gemm_fp8_arg
 
 extern "C" int qfx_quant_mxfp8(const qfx_quant_args* a, void* stream) {
   if (!a || !a->X || !a->Q || !a->S) return QFX_EINVAL;
-  if (a->M <= 0 || a->K <= 0 || (a->K % 128) || (a->ldx % 8) || (a->ldq % 16) || (a->lds % 4) || a->rows_per_batch <= 0) return QFX_EINVAL;
+  if (a->M <= 0 || a->K <= 0 || (a->K % 128) || (a->ldx % 8) || (a->ldq % 16) || a->rows_per_batch <= 0) return QFX_EINVAL;
   const int64_t nblocks = (int64_t)a->M * (a->K / 32);
   int64_t grid = (nblocks * 4 + 255) / 256;
   if (grid > 16384) grid = 16384;
@@ -289,7 +290,7 @@ extern "C" int qfx_gemm_mxfp8(const qfx_gemm_fp8_args* a, void* stream) {
   const qfx_gemm_args& g = a->g;
   if (!g.A1 || !g.B1 || !g.C || !a->sa || !a->sb) return QFX_EINVAL;
   if (g.M <= 0 || g.N <= 0 || g.K1 <= 0 || (g.K1 % 128) || (g.K2 % 64) || g.K2 < 0) return QFX_EINVAL;
-  if ((g.N % 4) || (g.lda1 % 16) || (g.ldb1 % 16) || (g.ldc % 4) || (a->ldsa % 4) || (a->ldsb % 4)) return QFX_EINVAL;
+  if ((g.N % 4) || (g.lda1 % 16) || (g.ldb1 % 16) || (g.ldc % 4)) return QFX_EINVAL;
   if (g.K2 > 0 && (!g.A2 || !g.B2 || (g.lda2 % 8) || (g.ldb2 % 8))) return QFX_EINVAL;
   if (g.rows_per_batch <= 0 || g.a_batch_rows != 0) return QFX_EINVAL;
   if (g.epi == QFX_EPI_GELU && (!g.C2 || (g.ldc2 % 4))) return QFX_EINVAL;

@@ -869,11 +869,11 @@ class _QwenPlan:
             if akey not in quantised:
                 slot = (g.M, g.K1, len(quantised))
                 if slot not in scratch:
-                    scratch[slot] = (self.buf(g.M, g.K1, dtype=torch.uint8), self.buf(g.M, g.K1 // 32, dtype=torch.uint8))
+                    scratch[slot] = (self.buf(g.M, g.K1, dtype=torch.uint8), self.buf(g.K1 // 128, g.M, 4, dtype=torch.uint8))
                 xq, xs = scratch[slot]
                 qa = L.QuantArgs()
                 qa.X, qa.ldx, qa.M, qa.K = _ptr(A1), lda1, g.M, g.K1
-                qa.Q, qa.ldq, qa.S, qa.lds = _ptr(xq), g.K1, _ptr(xs), g.K1 // 32
+                qa.Q, qa.ldq, qa.S, qa.lds = _ptr(xq), g.K1, _ptr(xs), 0
                 qa.rows_per_batch, qa.x_batch_rows, qa.x_row_off = rpb, a_map[0], a_map[1]
                 prog.keep.append(qa)
                 prog.c(lib.qfx_quant_mxfp8, C.byref(qa))
@@ -883,7 +883,7 @@ class _QwenPlan:
             C.memmove(C.byref(f.g), C.byref(g), C.sizeof(L.GemmArgs))
             f.g.A1, f.g.lda1, f.g.a_batch_rows, f.g.a_row_off = _ptr(xq), g.K1, 0, 0
             f.g.B1, f.g.ldb1 = _ptr(wq), g.K1
-            f.sa, f.ldsa, f.sb, f.ldsb = _ptr(xs), g.K1 // 32, _ptr(ws), g.K1 // 32
+            f.sa, f.ldsa, f.sb, f.ldsb = _ptr(xs), 0, _ptr(ws), 0
             prog.keep.append(f)
             prog.keep.append((wq, ws))
             prog.c(lib.qfx_gemm_mxfp8, C.byref(f))

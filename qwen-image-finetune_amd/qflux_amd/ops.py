@@ -281,25 +281,31 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_n
 
 # ---------------------------------------------------------------------------------------------- MX-FP8 (low-precision trunk)
 def quant_mxfp8(x, M=None, rows_per_batch=None, x_map=(0, 0), out=None):
-    """x [*, K] bf16 (row stride x.stride(0)) -> (q uint8 [M, K], s uint8 [M, K/32]) in the OCP MX-FP8 format (qfx.h)."""
+    """x [*, K] bf16 (row stride x.stride(0)) -> (q uint8 [M, K], s uint8 [K/128, M, 4] tile-major scales) in the OCP MX-FP8
+    format (qfx.h)."""
     _bf(x, "x")
     M = x.shape[0] if M is None else M
     K = x.shape[1]
     q, s = out if out is not None else (torch.empty(M, K, dtype=torch.uint8, device=x.device),
-                                        torch.empty(M, K // 32, dtype=torch.uint8, device=x.device))
+                                        torch.empty(K // 128, M, 4, dtype=torch.uint8, device=x.device))
     a = L.QuantArgs()
     a.X, a.ldx, a.M, a.K = _p(x), x.stride(0), M, K
-    a.Q, a.ldq, a.S, a.lds = _p(q), q.stride(0), _p(s), s.stride(0)
+    a.Q, a.ldq, a.S, a.lds = _p(q), q.stride(0), _p(s), 0
     a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
     a.x_batch_rows, a.x_row_off = x_map
     L.check(lib.qfx_quant_mxfp8(C.byref(a), stream_ptr()), "qfx_quant_mxfp8")
     return q, s
 
 
+def mxfp8_scales_rowmajor(s):
+    """tile-major scale bytes [K/128, M, 4] -> [M, K/32]."""
+    return s.permute(1, 0, 2).reshape(s.shape[1], -1)
+
+
 def mxfp8_dequant(q, s):
     """Host/torch view of an MX-FP8 operand as fp32 (test helper; not on the product path)."""
     v = q.view(torch.float8_e4m3fn).float().view(q.shape[0], -1, 32)
-    sc = torch.pow(2.0, s.float() - 127.0).unsqueeze(-1)
+    sc = torch.pow(2.0, mxfp8_scales_rowmajor(s).float() - 127.0).unsqueeze(-1)
     return (v * sc).view(q.shape[0], -1)
 
 
@@ -328,6 +334,6 @@ def gemm_mxfp8(aq, asc, bq, bsc, *, bias=None, a2=None, b2=None, out=None, epi=L
     g.c_batch_rows, g.c_row_off = c_map
     g.epi = epi
     g.row_mask = _p(row_mask)
-    f.sa, f.ldsa, f.sb, f.ldsb = _p(asc), asc.stride(0), _p(bsc), bsc.stride(0)
+    f.sa, f.ldsa, f.sb, f.ldsb = _p(asc), 0, _p(bsc), 0
     L.check(lib.qfx_gemm_mxfp8(C.byref(f), stream_ptr()), "qfx_gemm_mxfp8")
     return out

@@ -36,7 +36,8 @@ def test_quant_mxfp8_is_bit_exact(M, K, scale):
         x[2, 64:96] = 2.0 ** -120       # tiny values: exponent clamps at the E8M0 minimum
     q, s = ops.quant_mxfp8(x.to(DEV))
     qr, sr = mx_quant_ref(x)
-    assert torch.equal(s.cpu(), sr), (s.cpu().int() - sr.int()).abs().max()
+    s_rm = ops.mxfp8_scales_rowmajor(s).cpu()          # the library keeps the scales tile-major [K/128, M, 4]
+    assert torch.equal(s_rm, sr), (s_rm.int() - sr.int()).abs().max()
     assert torch.equal(q.cpu(), qr), ((q.cpu() != qr).sum().item(), q.numel())
     # dequantised error stays within the e4m3 half-ulp of the block's scale
     d = ops.mxfp8_dequant(q.cpu(), s.cpu())
