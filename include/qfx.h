@@ -100,6 +100,9 @@ typedef struct qfx_gemm_fp8_args {
   const uint8_t* sb; int64_t ldsb;
 } qfx_gemm_fp8_args;
 int qfx_gemm_mxfp8(const qfx_gemm_fp8_args* a, void* stream);
+/* n <= QFX_MAX_GROUPS problems with the same epilogue in ONE persistent grid (image + text stream, q/k/v), as qfx_gemm_grouped;
+ * no seg2_plain.  qfx_gemm_mxfp8 routes large single problems here and keeps the 128x128 kernel for small ones. */
+int qfx_gemm_mxfp8_grouped(const qfx_gemm_fp8_args* list, int32_t n, void* stream);
 
 /* ---- LoRA rank-r down projection ("skinny" GEMM, HBM-bound) ----------------------------------
  * U[M,R] (fp32) = X[M,K] (bf16) * (W_hi + W_lo)[R,K]^T   (W = fp32 LoRA weight split in two bf16)

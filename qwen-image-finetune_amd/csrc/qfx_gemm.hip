@@ -239,6 +239,11 @@ struct GroupedArgs {
   qfx_gemm_args g[QFX_MAX_GROUPS];
   int tile_start[QFX_MAX_GROUPS + 1];
   int n;
+  // MX-FP8 instantiation only: tile-major E8M0 scale arrays of A1 / B1 per group ([K/128][M][4] / [K/128][N][4]); the fp8 operands
+  // themselves travel through the SAME loader code as bf16 ones (g.A1 / g.B1 are byte pointers, lda1 / ldb1 / K1 are given in
+  // 2-byte units: a 128-byte fp8 K tile is indistinguishable from a 64-element bf16 K tile until it reaches the matrix pipe)
+  const uint8_t* sa[QFX_MAX_GROUPS];
+  const uint8_t* sb[QFX_MAX_GROUPS];
 };
 
 // The argument block is read straight from the kernarg segment (constant address space, scalar loads): indexing the
@@ -268,8 +273,11 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
   n0 = (in / gsz) * TN;
 }
 
-template <int EPI, int TN>
+typedef __attribute__((ext_vector_type(8))) int v8i32;
+
+template <int EPI, int TN, bool FP8 = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArgs ga_by_value) {
+  static_assert(!(FP8 && TN != 128), "the MX-FP8 instantiation uses the 256x128 tile (the wide tile's streaming loop has no registers for 8-VGPR operands)");
   using TC = TileCfg<TN>;
   constexpr int STAGE_BYTES = TC::STAGE, NSTAGE = TC::NST, MI = TC::MI;
   __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];  // 160 KiB (TN=128) / 144 KiB
@@ -398,7 +406,91 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     };
     const bool mid_round = nt2 > 0 && !p.seg2_plain;
-    if constexpr (TN == 128) {
+    if constexpr (FP8) {
+      // ---- MX-FP8 base segment: per K tile (128 fp8 per row) the four B operands (chunks g and g+4 of their rows = the two halves
+      // of one scaled-MFMA operand) stay resident, the A operands stream one fragment row ahead; scales (one dword = the 4 MX
+      // blocks of a row and K tile, tile-major: 16 rows = one 64-byte line) are fetched one K tile ahead.
+      const char* sap = (const char*)ga.sa[gi];
+      const char* sbp = (const char*)ga.sb[gi];
+      const int64_t sa_tile = (int64_t)p.M * 4, sb_tile = (int64_t)p.N * 4;
+      // 32-bit lane offsets into the (wave-uniform) scale arrays; rows beyond M / N clamp to the last row (their results are never stored)
+      const int ar0 = m0 + wr * WROWS + li, br0 = n0 + wc * 64 + li;
+      auto aoff = [&](int i) { const int r = ar0 + 16 * i; return (unsigned)((r < p.M ? r : p.M - 1) * 4); };
+      auto boff = [&](int i) { const int r = br0 + 16 * i; return (unsigned)((r < p.N ? r : p.N - 1) * 4); };
+      uint32_t sca[MI], scb[4];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) sca[i] = *(const uint32_t*)(sap + aoff(i));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) scb[i] = *(const uint32_t*)(sbp + boff(i));
+      const int swl = (li >> 1) & 7;
+      const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
+      const int offB0 = BM2 * BK * 2 + (wc * 64 + li) * (BK * 2) + ((g ^ swl) << 4);
+      for (int t = 0; t < nt1; ++t) {
+        // this lane group's scale bytes of tile t; the dwords of tile t+1 are requested right away into the same registers
+        int sav[MI], sbv[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) sav[i] = (int)((sca[i] >> (8 * g)) & 0xffu);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sbv[i] = (int)((scb[i] >> (8 * g)) & 0xffu);
+        if (t + 1 < nt1) {
+          const char* na = sap + (t + 1) * sa_tile;
+          const char* nb = sbp + (t + 1) * sb_tile;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) sca[i] = *(const uint32_t*)(na + aoff(i));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) scb[i] = *(const uint32_t*)(nb + boff(i));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + buf * STAGE_BYTES;
+        v8i32 b[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const u32x4 lo = *(const u32x4*)(st + offB0 + ni * (16 * BK * 2)), hi = *(const u32x4*)(st + ((offB0 + ni * (16 * BK * 2)) ^ 64));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { b[ni][j] = (int)lo[j]; b[ni][4 + j] = (int)hi[j]; }
+        }
+        u32x4 alo = *(const u32x4*)(st + offA0), ahi = *(const u32x4*)(st + (offA0 ^ 64));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          v8i32 av;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { av[j] = (int)alo[j]; av[4 + j] = (int)ahi[j]; }
+          if (mi + 1 < MI) {
+            alo = *(const u32x4*)(st + offA0 + (mi + 1) * (16 * BK * 2));
+            ahi = *(const u32x4*)(st + ((offA0 + (mi + 1) * (16 * BK * 2)) ^ 64));
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[ni], av, acc[mi][ni], 0, 0, 0, sbv[ni], 0, sav[mi]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (mid_round && t == nt1 - 1) round_base();
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+      }
+      // ---- bf16 LoRA K-extension tiles (plain loop: they are 1-3 K tiles)
+      for (int t = nt1; t < nt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 a[MI], b[4];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(st + ((offA0 + i * (16 * BK * 2)) ^ (kk << 6)));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) b[i] = *(const bf16x8*)(st + ((offB0 + i * (16 * BK * 2)) ^ (kk << 6)));
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+      }
+    } else if constexpr (TN == 128) {
       bf16x8 a0[4], b0[4], a1[4], b1[4];
       for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of tile t-1 has returned: its stage may be refilled
@@ -632,6 +724,43 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
     default: QFX_LAUNCH256(QFX_EPI_DGELU); break;
   }
 #undef QFX_LAUNCH256
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+// MX-FP8 operands on the warp-specialised persistent kernel (256x128 tiles): see GroupedArgs for how they reach the loaders.
+extern "C" int qfx_gemm_mxfp8_grouped(const qfx_gemm_fp8_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > QFX_MAX_GROUPS) return QFX_EINVAL;
+  GroupedArgs ga;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    qfx_gemm_args g = list[i].g;
+    if (!g.A1 || !g.B1 || !g.C || !list[i].sa || !list[i].sb) return QFX_EINVAL;
+    if (g.M <= 0 || g.N <= 0 || g.K1 <= 0 || (g.K1 % 128) || (g.K2 % 64) || g.K2 < 0) return QFX_EINVAL;
+    if ((g.lda1 % 16) || (g.ldb1 % 16) || g.a_batch_rows != 0 || g.seg2_plain) return QFX_EINVAL;
+    g.lda1 /= 2; g.ldb1 /= 2; g.K1 /= 2;          // 2-byte units: the loaders see a bf16 operand of half the K extent
+    const int rc = validate(&g);
+    if (rc) return rc;
+    if (g.epi != list[0].g.epi || !ok256(&g)) return QFX_EINVAL;
+    ga.g[i] = g;
+    ga.sa[i] = list[i].sa; ga.sb[i] = list[i].sb;
+    ga.tile_start[i] = tiles;
+    tiles += ((g.M + BM2 - 1) / BM2) * ((g.N + 127) / 128);
+  }
+  for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
+  for (int i = n; i < QFX_MAX_GROUPS; ++i) { ga.sa[i] = nullptr; ga.sb[i] = nullptr; }
+  ga.n = n;
+  hipStream_t s = (hipStream_t)stream;
+  const int rounds = (tiles + QFX_NUM_CU - 1) / QFX_NUM_CU;
+  int grid = (((tiles + rounds - 1) / rounds) + 7) & ~7;
+  if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
+  if (grid > tiles) grid = tiles;
+  switch (list[0].g.epi) {
+    case QFX_EPI_NONE: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_NONE, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    case QFX_EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_GELU, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    case QFX_EPI_GATE_RES: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_GATE_RES, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    default: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_DGELU, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+  }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -298,6 +298,11 @@ extern "C" int qfx_gemm_mxfp8(const qfx_gemm_fp8_args* a, void* stream) {
   if (g.epi == QFX_EPI_DGELU && (!g.aux || (g.ldaux % 4))) return QFX_EINVAL;
   if (g.epi < 0 || g.epi > 3) return QFX_EUNSUPPORTED;
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  // large problems: warp-specialised persistent kernel (256x128 tiles); small ones keep the 128x128 kernel
+  if (((g.M + 255) / 256) * ((g.N + 127) / 128) >= 160 && !g.seg2_plain && (g.N % 8) == 0 && (g.ldc % 8) == 0 &&
+      !(g.epi == QFX_EPI_GELU && (g.ldc2 % 8)) && !((g.epi == QFX_EPI_GATE_RES || g.epi == QFX_EPI_DGELU) && (g.ldaux % 8)) &&
+      !(g.epi == QFX_EPI_GATE_RES && ((g.gate_bstride % 8) || (g.C2 && (g.ldc2 % 8)))))
+    return qfx_gemm_mxfp8_grouped(a, 1, stream);
   hipStream_t s = (hipStream_t)stream;
   switch (g.epi) {
     case QFX_EPI_NONE: hipLaunchKernelGGL(gemm_fp8_kernel<QFX_EPI_NONE>, dim3(tiles), dim3(256), 0, s, *a); break;

@@ -132,6 +132,7 @@ SYMBOLS = {
     "qfx_gemm_grouped": (C.c_int, [C.POINTER(GemmArgs), _i32, _vp]),
     "qfx_quant_mxfp8": (C.c_int, [C.POINTER(QuantArgs), _vp]),
     "qfx_gemm_mxfp8": (C.c_int, [C.POINTER(GemmFp8Args), _vp]),
+    "qfx_gemm_mxfp8_grouped": (C.c_int, [C.POINTER(GemmFp8Args), C.c_int32, _vp]),
     "qfx_lora_down": (C.c_int, [C.POINTER(LoraDownArgs), _vp]),
     "qfx_lora_down_batch": (C.c_int, [C.POINTER(LoraDownArgs), C.c_int32, _vp]),
     "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),

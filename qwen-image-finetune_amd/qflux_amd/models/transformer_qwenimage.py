@@ -859,6 +859,7 @@ class _QwenPlan:
         cache = self.model.__dict__.setdefault("_wq_cache", {})
         scratch = self.__dict__.setdefault("_q8", {})
         quantised = {}
+        fp8 = []
         for g in groups:
             A1, lda1, a_map, rpb, B1 = g._src
             key = (B1.data_ptr(), tuple(B1.shape))
@@ -884,9 +885,18 @@ class _QwenPlan:
             f.g.A1, f.g.lda1, f.g.a_batch_rows, f.g.a_row_off = _ptr(xq), g.K1, 0, 0
             f.g.B1, f.g.ldb1 = _ptr(wq), g.K1
             f.sa, f.ldsa, f.sb, f.ldsb = _ptr(xs), 0, _ptr(ws), 0
-            prog.keep.append(f)
+            fp8.append(f)
             prog.keep.append((wq, ws))
-            prog.c(lib.qfx_gemm_mxfp8, C.byref(f))
+        # one persistent grid for the whole group (image + text stream, q/k/v) when it is large enough, else one launch each
+        tiles = sum(((f.g.M + 255) // 256) * ((f.g.N + 127) // 128) for f in fp8)
+        if tiles >= 160 and len(fp8) <= 6:
+            arr = (L.GemmFp8Args * len(fp8))(*fp8)
+            prog.keep.append(arr)
+            prog.c(lib.qfx_gemm_mxfp8_grouped, arr, len(fp8))
+        else:
+            for f in fp8:
+                prog.keep.append(f)
+                prog.c(lib.qfx_gemm_mxfp8, C.byref(f))
 
     def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
               group_stride=0, rpb=None, x_map=(0, 0), defer=None):

@@ -156,9 +156,16 @@ def test_mxfp8_trunk_step_matches_fp8_emulating_oracle():
     step = QwenLoraTrainStep(hip)
     loss_h = step.forward_backward(emb, noise=noise, u=u).item()
     plan = list(hip._plans.values())[0]
+    from qflux_amd import _lib as L
+    n_fp8 = 0
+    for c in plan.fwd.calls:
+        if c[0] is not None and c[0].__name__ == "qfx_gemm_mxfp8":
+            n_fp8 += 1
+        elif c[0] is not None and c[0].__name__ == "qfx_gemm_mxfp8_grouped":
+            n_fp8 += c[1][1]
     names = [c[0].__name__ for c in plan.fwd.calls if c[0] is not None]
-    assert names.count("qfx_gemm_mxfp8") == 2 * 12 + 1 - 3 and "qfx_quant_mxfp8" in names     # last block: text out-proj + text MLP are dead compute
-    assert all(c[0].__name__ != "qfx_gemm_mxfp8" for c in plan.bwd.calls if c[0] is not None)
+    assert n_fp8 == 2 * 12 + 1 - 3 and "qfx_quant_mxfp8" in names     # last block: text out-proj + text MLP are dead compute
+    assert all("mxfp8" not in c[0].__name__ for c in plan.bwd.calls if c[0] is not None)
     pred_h = plan.A["out"].view(2, -1, 64)[:, :S_t].float().cpu()
     hg = {n: p.grad.float().cpu() for n, p in hip.named_parameters() if "lora" in n}
 
@@ -177,3 +184,80 @@ def test_mxfp8_trunk_step_matches_fp8_emulating_oracle():
     step.zero_grad()
     l2 = step.forward_backward(emb, noise=noise, u=u).item()
     assert abs(l2 - res["bf16"][0]) / abs(res["bf16"][0]) < 5e-3
+
+
+def test_gemm_mxfp8_grouped_persistent_all_epilogues():
+    """The warp-specialised persistent kernel with MX-FP8 operands: grouped image + text problems, every epilogue, LoRA K-extension,
+    C row map -- against the 128x128 reference kernel of the same library on the same operands (and the fp8 emulation)."""
+    import ctypes as C
+    from qflux_amd import _lib as L
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    Mi, Mt, N, K, R = 2048, 384, 3072, 1024, 64
+    out = {}
+    for epi in (L.EPI_NONE, L.EPI_GELU, L.EPI_GATE_RES, L.EPI_DGELU):
+        res = []
+        for persistent in (True, False):
+            fs, keep, outs = [], [], []
+            for M in (Mi, Mt):
+                gg = torch.Generator().manual_seed(M + epi)
+                a = torch.randn(M, K, generator=gg).to(BF).to(DEV)
+                b = (torch.randn(N, K, generator=gg) * 0.03).to(BF).to(DEV)
+                a2 = (torch.randn(M, R, generator=gg) * 0.1).to(BF).to(DEV)
+                b2 = (torch.randn(N, R, generator=gg) * 0.1).to(BF).to(DEV)
+                bias = torch.randn(N, generator=gg).to(BF).to(DEV)
+                aux = torch.randn(M, N, generator=gg).to(BF).to(DEV)
+                gate = torch.randn(1, N, generator=gg).to(BF).to(DEV)
+                aq, asc = ops.quant_mxfp8(a)
+                bq, bsc = ops.quant_mxfp8(b)
+                y = torch.zeros(M, N, dtype=BF, device=DEV)
+                y2 = torch.zeros(M, N, dtype=BF, device=DEV)
+                f = L.GemmFp8Args()
+                q = f.g
+                q.A1, q.B1, q.lda1, q.ldb1, q.K1 = aq.data_ptr(), bq.data_ptr(), K, K, K
+                q.A2, q.B2, q.lda2, q.ldb2, q.K2 = a2.data_ptr(), b2.data_ptr(), R, R, R
+                q.M, q.N, q.bias, q.C, q.ldc = M, N, bias.data_ptr(), y.data_ptr(), N
+                q.rows_per_batch, q.epi = M, epi
+                if epi == L.EPI_GELU:
+                    q.C2, q.ldc2 = y2.data_ptr(), N
+                if epi in (L.EPI_GATE_RES, L.EPI_DGELU):
+                    q.aux, q.ldaux = aux.data_ptr(), N
+                if epi == L.EPI_GATE_RES:
+                    q.gate, q.gate_bstride = gate.data_ptr(), N
+                f.sa, f.sb = asc.data_ptr(), bsc.data_ptr()
+                fs.append(f); keep.append((a, b, a2, b2, bias, aux, gate, aq, asc, bq, bsc)); outs.append((y, y2))
+            if persistent:
+                arr = (L.GemmFp8Args * 2)(*fs)
+                L.check(L.lib.qfx_gemm_mxfp8_grouped(arr, 2, ops.stream_ptr()), "grouped")
+            else:
+                # force the 128x128 kernel: problems below the persistent threshold are routed there; split the rows to stay below it
+                for f, (y, y2) in zip(fs, outs):
+                    f.g.seg2_plain = 0
+                    rows = f.g.M
+                    for r0 in range(0, rows, 256):
+                        sub = L.GemmFp8Args()
+                        C.memmove(C.byref(sub), C.byref(f), C.sizeof(L.GemmFp8Args))
+                        n = min(256, rows - r0)
+                        sub.g.M, sub.g.rows_per_batch = n, n
+                        sub.g.A1 = f.g.A1 + r0 * K
+                        sub.g.A2 = f.g.A2 + r0 * R * 2
+                        sub.g.C = f.g.C + r0 * N * 2
+                        if f.g.C2:
+                            sub.g.C2 = f.g.C2 + r0 * N * 2
+                        if f.g.aux:
+                            sub.g.aux = f.g.aux + r0 * N * 2
+                        # tile-major scales cannot be sliced by rows: re-quantise the row block
+                        blk = keep[fs.index(f)][0][r0:r0 + n]
+                        sq = ops.quant_mxfp8(blk.contiguous())
+                        sub.g.A1, sub.sa = sq[0].data_ptr(), sq[1].data_ptr()
+                        L.check(L.lib.qfx_gemm_mxfp8(C.byref(sub), ops.stream_ptr()), "single")
+                        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            res.append([(y.float().cpu(), y2.float().cpu()) for y, y2 in outs])
+        for (ya, y2a), (yb, y2b) in zip(res[0], res[1]):
+            e = ((ya - yb).abs().max() / yb.abs().max()).item()
+            assert e < 1e-2, (epi, e)
+            if epi == L.EPI_GELU:
+                assert ((y2a - y2b).abs().max() / y2b.abs().max()).item() < 1e-2
+        out[epi] = True
+    assert len(out) == 4
