@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--rank", type=int, default=16, help="LoRA rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch2", action="store_true", help="skip the secondary per-GPU-batch-2 measurement")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the secondary MX-FP8 trunk measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args.gpus))
@@ -373,6 +374,23 @@ def main():
         dt2 = time.perf_counter() - t1
         out["per_gpu_batch_2"] = {"value": round(2 * n2 / dt2, 4), "unit": "images/s", "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2,
                                   "note": "same workload at the reference's default micro-batch (batch_size: 2); `value` above stays B=1"}
+    if world == 1 and B == 1 and not args.no_fp8:
+        # secondary line: the low-precision trunk (the reference's `model.quantize: true` analogue): forward + dX GEMMs of the block
+        # linears in MX-FP8 on the block-scaled MFMA; NOT the headline precision (`dtype` above stays bf16)
+        dit.quantize_trunk("mxfp8-fb")
+        for _ in range(3):
+            step.train_step(emb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n8 = max(4, min(args.steps, 10))
+        for _ in range(n8):
+            step.train_step(emb)
+        torch.cuda.synchronize()
+        dt8 = time.perf_counter() - t1
+        dit.quantize_trunk(None)
+        out["mxfp8_trunk"] = {"value": round(n8 / dt8, 4), "unit": "images/s", "ms_per_step": round(dt8 / n8 * 1e3, 3), "steps": n8,
+                              "mode": "quantize_trunk('mxfp8-fb'): MX-FP8 forward + dX GEMMs, bf16 everywhere else",
+                              "note": "reduced-precision option, reported beside the bf16 headline, never as `value`"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline((cfgd.attention_head_dim, cfgd.num_attention_heads, Jd, S_t, T))

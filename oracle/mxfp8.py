@@ -26,6 +26,8 @@ def mx_qdq(x: torch.Tensor) -> torch.Tensor:
 
 
 class _QLinearFn(torch.autograd.Function):
+    quant_backward = False      # "mxfp8-fb": the dX GEMM contracts MX-FP8 operands too (dY and W^T quantised along out_features)
+
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
@@ -37,7 +39,12 @@ class _QLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dx = (dy.to(w.dtype) @ w) if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        if _QLinearFn.quant_backward and w.shape[0] % 128 == 0 and w.shape[0] >= 1024 and w.shape[1] >= 1024:
+            dx = (mx_qdq(dy) @ mx_qdq(w.t().contiguous()).t()).to(dy.dtype)
+        else:
+            dx = dy.to(w.dtype) @ w
         return dx, None, None
 
 
@@ -53,8 +60,9 @@ def eligible(name: str, lin: nn.Linear) -> bool:
     return lin.in_features % 128 == 0 and lin.in_features >= 1024 and lin.out_features >= 1024
 
 
-def quantize_oracle(model: nn.Module, predicate=eligible):
+def quantize_oracle(model: nn.Module, predicate=eligible, backward: bool = False):
     """Patch the forward of every eligible frozen nn.Linear (the base layers of adapted linears included)."""
+    _QLinearFn.quant_backward = bool(backward)
     n = 0
     for name, m in model.named_modules():
         if isinstance(m, nn.Linear) and "lora_" not in name and predicate(name, m):

@@ -370,10 +370,11 @@ class QwenImageTransformer2DModel(nn.Module):
     def quantize_trunk(self, mode: str | None = "mxfp8"):
         """Low-precision trunk switch (the reference's `model.quantize: true`, base_trainer.py:617-621,919-927 ->
         quantize_model_to_fp8): "mxfp8" runs the forward GEMMs of the block linears on the block-scaled FP8 MFMA
-        (OCP MX-FP8: e4m3 elements, E8M0 scale per 32 K elements; weights quantised once, activations per launch); None
-        restores the bf16 trunk.  Adapters, biases, norms, attention and the whole backward stay bf16 / fp32."""
-        if mode not in (None, "mxfp8"):
-            raise ValueError(f"unknown trunk quantisation {mode!r} (supported: 'mxfp8')")
+        (OCP MX-FP8: e4m3 elements, E8M0 scale per 32 K elements; weights quantised once, activations per launch);
+        "mxfp8-fb" also the dX GEMMs of the backward (dY and the transposed weight copy quantised along the contraction);
+        None restores the bf16 trunk.  Adapters, biases, norms, attention, the rank-r gradient kernels stay bf16 / fp32."""
+        if mode not in (None, "mxfp8", "mxfp8-fb"):
+            raise ValueError(f"unknown trunk quantisation {mode!r} (supported: 'mxfp8' = forward GEMMs, 'mxfp8-fb' = forward + dX GEMMs)")
         self._quant = mode
         self.__dict__.pop("_wq_cache", None)
         self._plans = PlanCache()
@@ -833,7 +834,8 @@ class _QwenPlan:
 
     def _gemm_group(self, prog, groups):
         """One grid for several independent GEMMs with the same epilogue (image+text streams, q/k/v)."""
-        if prog is self.fwd and getattr(self.model, "_quant", None) == "mxfp8" and all(self._fp8_ok(g) for g in groups):
+        q = getattr(self.model, "_quant", None)
+        if q and (prog is self.fwd or (q == "mxfp8-fb" and prog is self.bwd)) and all(self._fp8_ok(g) for g in groups):
             return self._gemm_group_mxfp8(prog, groups)
         if len(groups) == 1:
             prog.keep.append(groups[0])
