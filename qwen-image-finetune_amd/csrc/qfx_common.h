@@ -54,6 +54,7 @@ __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
 // row remap for joint [text|image] buffers: row(m) = (m / rpb) * batch_rows + off + m % rpb
 __device__ __forceinline__ int64_t remap_row(int m, int rpb, int batch_rows, int off) {
   if (batch_rows == 0) return (int64_t)m;
+  if (m < rpb) return (int64_t)(off + m);      // first sample (all rows when B = 1): no integer division on the launch's critical path
   int b = m / rpb;
   return (int64_t)b * batch_rows + off + (m - b * rpb);
 }
