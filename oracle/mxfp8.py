@@ -26,11 +26,12 @@ def mx_qdq(x: torch.Tensor) -> torch.Tensor:
 
 
 class _QLinearFn(torch.autograd.Function):
-    quant_backward = False      # "mxfp8-fb": the dX GEMM contracts MX-FP8 operands too (dY and W^T quantised along out_features)
+    """qb: "mxfp8-fb" -- the dX GEMM contracts MX-FP8 operands too (dY and W^T quantised along out_features)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, qb=False):
         ctx.save_for_backward(x, w)
+        ctx.qb = qb
         y = F.linear(mx_qdq(x), mx_qdq(w)).to(torch.float32)
         if b is not None:
             y = y + b.float()
@@ -40,16 +41,15 @@ class _QLinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
-            return None, None, None
-        if _QLinearFn.quant_backward and w.shape[0] % 128 == 0 and w.shape[0] >= 1024 and w.shape[1] >= 1024:
+            return None, None, None, None
+        if ctx.qb and w.shape[0] % 128 == 0 and w.shape[0] >= 1024 and w.shape[1] >= 1024:
             dx = (mx_qdq(dy) @ mx_qdq(w.t().contiguous()).t()).to(dy.dtype)
         else:
             dx = dy.to(w.dtype) @ w
-        return dx, None, None
+        return dx, None, None, None
 
 
-_COND_HEAD = ("_mod.", "timestep_embedder", "guidance_embedder", "text_embedder", "norm_out", "norm1.linear", "norm1_context.linear",
-              "norm.linear")
+_COND_HEAD = ("_mod.", "time_text_embed.", "norm_out", "norm1.linear", "norm1_context.linear", "norm.linear")
 
 
 def eligible(name: str, lin: nn.Linear) -> bool:
@@ -61,11 +61,12 @@ def eligible(name: str, lin: nn.Linear) -> bool:
 
 
 def quantize_oracle(model: nn.Module, predicate=eligible, backward: bool = False):
-    """Patch the forward of every eligible frozen nn.Linear (the base layers of adapted linears included)."""
-    _QLinearFn.quant_backward = bool(backward)
+    """Patch the forward of every eligible frozen nn.Linear (the base layers of adapted linears included).  backward=True: the dX
+    GEMMs of the double-stream blocks contract MX-FP8 operands as well (the FLUX single blocks' fused dX contraction stays bf16)."""
     n = 0
     for name, m in model.named_modules():
         if isinstance(m, nn.Linear) and "lora_" not in name and predicate(name, m):
-            m.forward = (lambda x, m=m: _QLinearFn.apply(x, m.weight, m.bias))
+            qb = bool(backward) and not name.startswith("single_transformer_blocks")
+            m.forward = (lambda x, m=m, qb=qb: _QLinearFn.apply(x, m.weight, m.bias, qb))
             n += 1
     return n

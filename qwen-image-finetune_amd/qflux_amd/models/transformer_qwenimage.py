@@ -849,8 +849,9 @@ class _QwenPlan:
     @staticmethod
     def _fp8_ok(g):
         A1, lda1, a_map, rpb, B1 = g._src
-        return (isinstance(B1, torch.Tensor) and B1.dim() == 2 and B1.is_contiguous() and g.K1 % 128 == 0 and g.K1 >= 1024 and g.N >= 1024
-                and B1.shape == (g.N, g.K1) and not g.seg2_plain)
+        # whole weight tensors only (a row slice of the FLUX single block's proj_out^T stays bf16 like the rest of that block's backward)
+        return (isinstance(B1, torch.Tensor) and B1.dim() == 2 and B1.is_contiguous() and B1.storage_offset() == 0 and g.K1 % 128 == 0
+                and g.K1 >= 1024 and g.N >= 1024 and B1.shape == (g.N, g.K1) and not g.seg2_plain)
 
     def _gemm_group_mxfp8(self, prog, groups):
         """Forward GEMMs of the block linears on the block-scaled FP8 MFMA (model.quantize = "mxfp8", the MI355X analogue of

@@ -263,3 +263,85 @@ def test_gemm_mxfp8_grouped_persistent_all_epilogues():
                 assert ((y2a - y2b).abs().max() / y2b.abs().max()).item() < 1e-2
         out[epi] = True
     assert len(out) == 4
+
+
+def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
+    """FLUX double + single block of width 1024 with the MX-FP8 trunk (forward + dX GEMMs): the single block's two-segment
+    proj_out contraction stays bf16 in the HIP path, so the oracle keeps that linear un-quantised too."""
+    import os
+    from oracle import flux_dit as FO
+    from oracle import mxfp8 as QX
+    from oracle import qwen_dit as O
+    from qflux_amd.models import FluxTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import FluxKontextTrainStep
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = dict(patch_size=1, in_channels=64, out_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=8,
+               joint_attention_dim=1024, pooled_projection_dim=64, guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    with torch.device(DEV):
+        hip = FluxTransformer2DModel(**cfg)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if p.ndim == 1 and "norm" in n:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=DEV) * 0.03).to(p.dtype))
+    hip.add_adapter(LoraConfig(r=8, lora_alpha=8), "default", generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(7)).to(p.device) * 1e-2)
+    oracle = FO.OracleFluxDiT(**cfg)
+    O.add_lora(oracle, r=8, lora_alpha=8, adapter_name="default")
+    oracle.load_state_dict({k: v.float().cpu() for k, v in hip.state_dict().items()}, strict=True)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    gg = torch.Generator().manual_seed(3)
+    B, h, w, T = 2, 10, 12, 24
+    S_t = h * w
+    ctl = FO.prepare_latent_image_ids(h, w)
+    ctl[:, 0] = 1
+    emb = dict(image_latents=torch.randn(B, S_t, 64, generator=gg).half(), control_latents=torch.randn(B, S_t, 64, generator=gg).half(),
+               control_ids=ctl, text_ids=torch.zeros(T, 3), latent_hw=(h, w), pooled_prompt_embeds=torch.randn(B, 64, generator=gg).half(),
+               prompt_embeds=torch.randn(B, T, 1024, generator=gg).half())
+    noise = torch.randn(B, S_t, 64, generator=gg).to(BF)
+    t = torch.tensor([0.7109, 0.1611]).to(BF)
+    emb_o = dict(emb, control_latents=emb["control_latents"].to(BF))
+    rel = lambda a, b: ((a.float() - b.float()).abs().max() / b.float().abs().max()).item()
+    with torch.no_grad():
+        _, pred_b = FO.flux_compute_loss(oracle, emb_o, noise, t, BF, return_pred=True)          # bf16 oracle
+    step = FluxKontextTrainStep(hip)
+    step.forward_backward(emb, noise=noise, t=t)
+    plan = list(hip._plans.values())[0]
+    e_bf = rel(plan.A["out"].view(B, -1, 64)[:, :S_t].float().cpu(), pred_b)                     # bf16 HIP path vs bf16 oracle
+    step.zero_grad()
+    nq = QX.quantize_oracle(oracle, predicate=lambda name, m: QX.eligible(name, m) and not (name.startswith("single_") and "proj_out" in name),
+                            backward=True)
+    assert nq == 12 + 1 + 4      # double block linears, context_embedder, single-block q/k/v + proj_mlp
+    loss_o, pred_o = FO.flux_compute_loss(oracle, emb_o, noise, t, BF, return_pred=True)
+    loss_o.float().backward()
+    gap = rel(pred_o, pred_b)
+    hip.quantize_trunk("mxfp8-fb")
+    loss_h = step.forward_backward(emb, noise=noise, t=t).item()
+    plan = list(hip._plans.values())[0]
+    pred_h = plan.A["out"].view(B, -1, 64)[:, :S_t].float().cpu()
+    e = rel(pred_h, pred_o)
+    print(f"flux: bf16 hip~oracle {e_bf:.4f}, fp8~bf16 oracle gap {gap:.4f}, hip fp8 ~ bf16 oracle {rel(pred_h, pred_b):.4f}")
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    gw = max(((p.grad.float().cpu() - og[n].float()).abs().max() / (og[n].float().abs().max() + 1e-12)).item()
+             for n, p in hip.named_parameters() if "lora" in n and og[n] is not None)
+    n_fp8 = 0
+    for c in plan.fwd.calls:
+        if c[0] is not None and c[0].__name__ == "qfx_gemm_mxfp8":
+            n_fp8 += 1
+        elif c[0] is not None and c[0].__name__ == "qfx_gemm_mxfp8_grouped":
+            n_fp8 += c[1][1]
+    assert n_fp8 == nq       # the same 17 linears run on the scaled MFMA in the HIP forward
+    print(f"flux mxfp8-fb: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, worst LoRA grad rel {gw:.4f}")
+    # width-1024 weights of std 0.03 make this a noisy net: the fp8 trunk moves the prediction by `gap` (8 % of its maximum, the
+    # bf16 paths agree to 1 %).  The HIP path must sit well inside that distance from the fp8-emulating oracle -- element flips at
+    # fp8 rounding boundaries (bf16 inputs that differ in the last bit) are the residual.
+    assert e_bf < 2e-2 and abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2
+    assert e < 0.6 * gap and e < rel(pred_h, pred_b) and gw < 6e-2
