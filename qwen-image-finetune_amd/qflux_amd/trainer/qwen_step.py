@@ -145,6 +145,63 @@ class QwenLoraTrainStep:
         plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
         return loss
 
+    # ------------------------------------------------------------------ hipGraph replay of the DiT part of the step
+    def capture_graph(self, embeddings):
+        """Capture [LoRA operand refresh, forward program, loss, backward program] -- every launch of the step except the
+        flow-match preparation (host RNG) and the 3 optimizer launches (host-side step count / lr) -- into ONE hipGraph for the
+        shape of `embeddings`, side-stream gradient launches and their fork / join events included.  Returns
+        step(embeddings, noise=None, u=None) -> loss, a full optimisation step that replays the graph: the ~1.45k ctypes calls
+        of the Python replay become one hipGraphLaunch.  Inputs are staged through static buffers; all arena pointers are baked
+        in, so the graph is valid until the plan is rebuilt (adapter set / quantisation / shape change -> capture again).
+        Data-parallel: the gradient exchange runs as one all-reduce after the graph (the bucketed overlap needs the eager
+        replay)."""
+        if self.criterion == "mask_edit":
+            raise NotImplementedError("capture_graph: the mask_edit criterion takes per-step token weights; use train_step")
+        dit = self.dit
+        packed, target, pe, t_in, S_t = self._prepare(embeddings)
+        plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
+        dit.lora_store
+        version = dit._version
+        static = [torch.empty_like(t) for t in (packed, target, pe, t_in)]
+        for d, s_ in zip(static, (packed, target, pe, t_in)):
+            d.copy_(s_)
+
+        def body():
+            pred = plan.run_forward(static[0], static[2], static[3])
+            loss, dpred = ops.mse_loss_fwd_bwd(pred, static[1], S_t)
+            plan.run_backward(dpred)
+            return loss
+
+        warm = torch.cuda.Stream(device=dit.device)     # one eager pass on a non-default stream (lazy module loads, pool warm-up)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            body()
+        torch.cuda.current_stream().wait_stream(warm)
+        self.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_static = body()
+        self.zero_grad()
+        shapes = [tuple(t.shape) for t in static]
+
+        def step(emb, noise=None, u=None):
+            if dit._version != version or not any(p is plan for p in dit._plans.values()):
+                raise RuntimeError("capture_graph: the plan this graph was captured on is gone (adapters / quantisation changed "
+                                   "or it was evicted); capture again")
+            ins = self._prepare(emb, noise, u)
+            if [tuple(t.shape) for t in ins[:4]] != shapes:
+                raise ValueError("capture_graph: batch shape differs from the captured one")
+            for d, s_ in zip(static, ins[:4]):
+                d.copy_(s_)
+            graph.replay()
+            self._finish_buckets = None
+            self.optimizer_step(grad_scale=self.allreduce_grads())
+            self.zero_grad()
+            return loss_static
+
+        step.graph = graph
+        return step
+
     # ------------------------------------------------------------------ bucketed all-reduce behind the backward
     def _bucket_hook(self):
         st = self.dit.lora_store

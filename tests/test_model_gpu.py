@@ -406,3 +406,30 @@ def test_all_linear_targets_match_oracle():
     assert res["ok"] and res["grads_nonzero"] >= 2 * (2 * 14 + 6) - 8, res
     res = run_tiny_step_parity(DEV, verbose=True, r=4, targets=("img_mod.1", "txt_mod.1", "norm_out.linear", "to_q"), fused=False)
     assert res["ok"], res
+
+
+def test_hipgraph_replay_of_the_step_equals_the_eager_replay():
+    """capture_graph: the DiT part of the step (operand refresh, forward program, loss, backward program with its side-stream
+    gradient launches) replayed from one hipGraph gives the losses and LoRA parameters of the Python replay, step after step,
+    with new inputs / noise / timesteps staged through the static buffers; a rebuilt plan invalidates the graph loudly."""
+    from common import TINY
+    from parity_util import build_pair, tiny_embeddings
+    from qflux_amd.trainer import QwenLoraTrainStep
+    _, a = build_pair(dict(TINY), device=DEV)
+    _, b = build_pair(dict(TINY), device=DEV)
+    sa, sb = QwenLoraTrainStep(a, lr=1e-2), QwenLoraTrainStep(b, lr=1e-2)
+    batches = [tiny_embeddings(seed=s) for s in (11, 12, 13)]
+    gstep = sb.capture_graph(batches[0][0])
+    assert float(b.lora_store.gflat.abs().max()) == 0.0 and sb.global_step == 0        # capturing is not a step
+    for (e, n, u) in batches:
+        la = sa.train_step(e, noise=n, u=u).item()
+        lb = gstep(e, noise=n, u=u).item()
+        assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)     # the loss sum is an fp32 atomic reduction
+    rel = ((a.lora_store.pflat - b.lora_store.pflat).abs().max() / a.lora_store.pflat.abs().max()).item()
+    assert rel < 1e-6, rel
+    e2, n2, u2 = tiny_embeddings(seed=14, T=9)
+    with pytest.raises(ValueError):
+        gstep(e2, noise=n2, u=u2)
+    b.quantize_trunk(None)          # drops the plans
+    with pytest.raises(RuntimeError):
+        gstep(*batches[0][:1])
