@@ -23,7 +23,8 @@ def main():
         flags = [f for f in fl.split(",") if f]
         objs = []
         for src in SOURCES:
-            text = open(os.path.join(CSRC, src)).read() + open(os.path.join(CSRC, "qfx_common.h")).read()
+            text = (open(os.path.join(CSRC, src)).read() + open(os.path.join(CSRC, "qfx_common.h")).read() +
+                    open(os.path.join(ROOT, "include", "qfx.h")).read())
             rel = [f for f in flags if re.sub(r"^-D", "", f).split("=")[0] in text]
             key = hashlib.sha1((src + "|" + " ".join(rel) + "|" + hashlib.sha1(text.encode()).hexdigest()).encode()).hexdigest()[:16]
             obj = os.path.join(OUT, f"{src[:-4]}_{key}.o")
