@@ -406,6 +406,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     };
     const bool mid_round = nt2 > 0 && !p.seg2_plain;
+    const bool wave_dead = m0 + wr * WROWS >= p.M;   // wave-uniform
     if constexpr (FP8) {
       // ---- MX-FP8 base segment: per K tile (128 fp8 per row) the four B operands (chunks g and g+4 of their rows = the two halves
       // of one scaled-MFMA operand) stay resident, the A operands stream one fragment row ahead; scales (one dword = the 4 MX
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* st = smem + buf * STAGE_BYTES;
+        if (wave_dead) { buf = buf + 1 == NSTAGE ? 0 : buf + 1; continue; }   // see the bf16 narrow-tile loop
         v8i32 b[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -475,6 +477,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* st = smem + buf * STAGE_BYTES;
+        if (wave_dead) { buf = buf + 1 == NSTAGE ? 0 : buf + 1; continue; }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           bf16x8 a[MI], b[4];
@@ -506,6 +509,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
           const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
           return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
         };
+        // a compute wave whose rows all lie past M (the text stream's half-empty second tile: 128 of 2560 rows per launch) keeps
+        // the barrier protocol but issues no fragment reads / MFMAs: nothing of it is ever stored, and under the package power
+        // cap the saved energy is time (sustained step 99.79 -> 99.25 ms, tools/step_lib_ab.py; invisible in burst timings)
+        if (wave_dead) { buf = buf + 1 == NSTAGE ? 0 : buf + 1; continue; }
   #pragma unroll
         for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
         __builtin_amdgcn_sched_barrier(0);
@@ -528,6 +535,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         }
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
       }
+      if (!wave_dead)
   #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
   #pragma unroll
@@ -544,6 +552,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* st = smem + buf * STAGE_BYTES;
+        if (wave_dead) { buf ^= 1; continue; }   // see the narrow-tile loop
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const char* pA = st + (offA0 ^ (kk << 6));
