@@ -262,7 +262,9 @@ int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float* rope,
                          int32_t B, int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bstride,
                          void* stream);
 /* flags bit0: torch.nn.RMSNorm rounding (FLUX, transformer_flux.py:342-343: one rounding after x*rstd*w) instead of the
- * diffusers RMSNorm double rounding (Qwen). */
+ * diffusers RMSNorm double rounding (Qwen).
+ * flags bit1 (forward only): OUT OF PLACE -- the pre-norm q,k are read from `saved` ([B,S,2*H*dh], where the q/k projections
+ * wrote them) and the normalised, rotated q,k go to the q,k sections of qkv: no copy pass (one 2*B*S*H*dh*2-byte write less). */
 /* in place on the q,k sections of dqkv (v section untouched): un-rotate, RMSNorm backward. */
 int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope,
                          const uint16_t* wq_txt, const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img,

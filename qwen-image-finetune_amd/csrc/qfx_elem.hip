@@ -420,8 +420,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   }
   if constexpr (!BWD) {
     float x[8];
-    ld8(px, x);
-    if (ps && valid) st8(ps, x);
+    if (flags & 2) {                 // out of place: the producer wrote the pre-norm q,k straight into `saved`
+      ld8(ps, x);
+    } else {
+      ld8(px, x);
+      if (ps && valid) st8(ps, x);
+    }
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
@@ -898,6 +902,7 @@ extern "C" int qfx_qk_norm_rope_fwd(uint16_t* qkv, uint16_t* saved, const float*
                                     const uint16_t* wk_txt, const uint16_t* wq_img, const uint16_t* wk_img, int32_t B,
                                     int32_t S, int32_t T, int32_t H, int32_t dh, float eps, int32_t flags, int64_t rope_bstride,
                                     void* stream) {
+  if ((flags & 2) && !saved) return QFX_EINVAL;
   return launch_qk(false, qkv, saved, rope, wq_txt, wk_txt, wq_img, wk_img, B, S, T, H, dh, eps, flags, rope_bstride, stream);
 }
 extern "C" int qfx_qk_norm_rope_bwd(uint16_t* dqkv, const uint16_t* saved, const float* rope, const uint16_t* wq_txt,

@@ -504,6 +504,7 @@ class _FluxPlan(_QwenPlan):
         grp = w["qkv_lora"]
         xm = bb.get("xm", A["xm_j"])
         q2 = bb["qkv"].view(M, 3 * D)
+        sqk2 = bb["sqk"].view(M, 2 * D)
         fused = grp is not None and self._ln_down(p, [(self._ln_fwd_args(x, mod[:, 0:D], mod[:, D:2 * D], 3 * D, xm, M, D, S, eps),
                                                        dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"], Ut=bb["Uqkv"],
                                                             ext=A["ext3_j"], ld_ext=A["ext3_j"].stride(0), group_R=grp["Rp"],
@@ -520,7 +521,8 @@ class _FluxPlan(_QwenPlan):
             if lw.lora is not None:
                 kw = dict(A2=A["ext3_j"][:, sec * grp["Kext"]:], lda2=A["ext3_j"].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0),
                           K2=lw.lora.Kext)
-            groups.append(self._gargs(A1=xm, lda1=D, B1=lw.W, K1=D, M=M, N=D, C_=q2[:, sec * D:], ldc=3 * D, bias=lw.b, **kw))
+            c_, ldc = (sqk2[:, sec * D:], 2 * D) if sec < 2 else (q2[:, 2 * D:], 3 * D)    # q,k: see the Qwen double block
+            groups.append(self._gargs(A1=xm, lda1=D, B1=lw.W, K1=D, M=M, N=D, C_=c_, ldc=ldc, bias=lw.b, **kw))
         self._gemm_group(p, groups)
         ml, wo = w["mlp"], w["out"]
         cat = bb.get("cat")                       # [M, 5D] = [attn | gelu(mlp)] when proj_out carries an adapter
@@ -529,7 +531,7 @@ class _FluxPlan(_QwenPlan):
         self._gemm(p, A1=xm, lda1=D, B1=ml.W, K1=D, M=M, N=4 * D, C_=bb["h"], ldc=4 * D, bias=ml.b, epi=L.EPI_GELU, C2=gact, ldc2=ldg, **kw)
         nq, nk = w["norms"]
         p.c(lib.qfx_qk_norm_rope_fwd, _ptr(bb["qkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
-            B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
+            B, S, T, H, dh, eps, self.NORM_FLAGS | 2, self.rope_bs)
         a = L.AttnArgs()
         a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, 1.0 / math.sqrt(dh)
         a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])

@@ -1106,6 +1106,7 @@ class _QwenPlan:
         if True:
             qkv = bb["qkv"]
             q2 = qkv.view(B * S, 3 * D)
+            sqk2 = bb["sqk"].view(B * S, 2 * D)
             ao2 = bb["ao"].view(B * S, D)
             # ---- LN1 + modulate, LoRA down-projections, then ONE grouped launch for the 6 q/k/v projections
             groups = []
@@ -1141,12 +1142,15 @@ class _QwenPlan:
                     if lw.lora is not None:
                         kw = dict(A2=A["ext3"][s][:, sec * grp["Kext"]:], lda2=A["ext3"][s].stride(0), B2=lw.lora.We,
                                   ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
-                    groups.append(self._gargs(A1=xm1, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=q2[:, sec * D:], ldc=3 * D,
+                    # q and k go straight into the block's saved pre-norm copy (what the backward of the QK norm needs); the
+                    # norm+RoPE pass reads them there and writes the joint buffer (out-of-place mode: no copy pass)
+                    c_, ldc = (sqk2[:, sec * D:], 2 * D) if sec < 2 else (q2[:, 2 * D:], 3 * D)
+                    groups.append(self._gargs(A1=xm1, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=c_, ldc=ldc,
                                               bias=lw.b, rpb=rpb[s], c_map=(S, off[s]), **kw))
             self._gemm_group(p, groups)
             nq_t, nk_t, nq_i, nk_i = w["norms"]
             p.c(lib.qfx_qk_norm_rope_fwd, _ptr(qkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i),
-                B, S, T, H, dh, eps, norm_flags, self.rope_bs)
+                B, S, T, H, dh, eps, norm_flags | 2, self.rope_bs)
             a = L.AttnArgs()
             a.B, a.S, a.S_pad, a.H, a.dh, a.scale = B, S, S_pad, H, dh, scale
             a.Q, a.K, a.V = _ptr(q2[:, 0:]), _ptr(q2[:, D:]), _ptr(q2[:, 2 * D:])

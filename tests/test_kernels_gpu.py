@@ -471,6 +471,11 @@ def test_qk_norm_rope_fwd_bwd(dh):
     check(f"qk_fwd_k_{dh}", buf[:, :, D:2 * D], k_ref.float(), 1.5e-2)
     assert torch.equal(buf[:, :, 2 * D:].cpu(), qkv[:, :, 2 * D:])
     assert torch.equal(saved.cpu(), qkv[:, :, :2 * D])
+    # out-of-place mode (flags bit1): pre-norm q,k read from `saved`, result into the q,k sections of qkv -- same bits, v untouched
+    buf2 = torch.zeros_like(buf)
+    buf2[:, :, 2 * D:] = buf[:, :, 2 * D:]
+    ops.qk_norm_rope(buf2, saved, rope.to(DEV), wd[0], wd[1], wd[2], wd[3], Bn, S, T, H, dh, flags=2)
+    assert torch.equal(buf2, buf) and torch.equal(saved.cpu(), qkv[:, :, :2 * D])
     # backward vs fp32 autograd
     dq = randn(Bn, S, 3 * D, seed=5).to(BF)
     xx = qkv.float().requires_grad_(True)
