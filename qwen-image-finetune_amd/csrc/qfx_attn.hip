@@ -504,16 +504,21 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
   auto stage = [&](int it, int buf) {
     const int i0 = it * 64;
     char* dQ_ = sStage + buf * 2 * TB;
+    // the lane-constant parts of the DMA source offsets are RE-DERIVED from the lane id at every call (the empty asm hides the
+    // value's origin from loop-invariant code motion): hoisted, they get spilled -- the kernel sits at the 256-VGPR limit -- and a
+    // scratch reload costs an s_waitcnt vmcnt(0) at the top of every iteration (155-158 us against 165-168 at S = 2432)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int i = 0; i < NIS; ++i) {
-      const int row = w * RPW + i * RPI + lane / CPR;
-      const int sc8 = ((lane % CPR) ^ swz_row<DH>(row)) * 8;
+      const int row = w * RPW + i * RPI + ln / CPR;
+      const int sc8 = ((ln % CPR) ^ swz_row<DH>(row)) * 8;
       int sr = i0 + row; sr = sr < S ? sr : S - 1;
       glds16(Qb + (unsigned)(sr * a.ldq + sc8), dQ_ + (w * RPW + i * RPI) * (DH * 2));
       glds16(dOb + (unsigned)(sr * a.lddo + sc8), dQ_ + TB + (w * RPW + i * RPI) * (DH * 2));
     }
-    if (w == 0) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(lseb + i0 + lane), (QFX_AS3 void*)(sStat + buf * 512), 4, 0, 0);
-    if (w == 1) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(dsb + i0 + lane), (QFX_AS3 void*)(sStat + buf * 512 + 256), 4, 0, 0);
+    if (w == 0) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(lseb + i0 + ln), (QFX_AS3 void*)(sStat + buf * 512), 4, 0, 0);
+    if (w == 1) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(dsb + i0 + ln), (QFX_AS3 void*)(sStat + buf * 512 + 256), 4, 0, 0);
   };
 #pragma unroll
   for (int i = 0; i < 4; ++i) stage_rows_n<DH, NW>(sV + i * TB, Vb, a.ldv, kb + 64 * i, S, w, lane);
