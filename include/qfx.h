@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QFX_ABI_VERSION 1
+#define QFX_ABI_VERSION 2
 
 #define QFX_OK 0
 #define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
@@ -98,6 +98,12 @@ typedef struct qfx_gemm_fp8_args {
   qfx_gemm_args g;
   const uint8_t* sa; int64_t ldsa;
   const uint8_t* sb; int64_t ldsb;
+  /* ABI 2: quantising epilogue (persistent kernel only: problems of >= 160 256x128 tiles, N % 128 == 0, not GATE_RES).  When
+   * cq != NULL the output the NEXT GEMM contracts over -- C2 = gelu(h) for EPI_GELU, C otherwise -- also leaves the epilogue as
+   * MX-FP8: bytes at cq + row*ldcq + n (rows indexed like C), E8M0 scales tile-major in cs ([N/128][cq_rows][4], cq_rows >= the
+   * row extent of C); bit-identical to qfx_quant_mxfp8 of the bf16 tensor.  cq_only != 0: the bf16 copy of that output is not
+   * written at all (the consumer is an MX-FP8 GEMM and nothing else reads it). */
+  uint8_t* cq; uint8_t* cs; int64_t ldcq; int32_t cq_rows; int32_t cq_only;
 } qfx_gemm_fp8_args;
 int qfx_gemm_mxfp8(const qfx_gemm_fp8_args* a, void* stream);
 /* n <= QFX_MAX_GROUPS problems with the same epilogue in ONE persistent grid (image + text stream, q/k/v), as qfx_gemm_grouped;

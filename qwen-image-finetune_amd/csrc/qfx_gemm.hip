@@ -244,6 +244,13 @@ struct GroupedArgs {
   // 2-byte units: a 128-byte fp8 K tile is indistinguishable from a 64-element bf16 K tile until it reaches the matrix pipe)
   const uint8_t* sa[QFX_MAX_GROUPS];
   const uint8_t* sb[QFX_MAX_GROUPS];
+  // optional MX-FP8 image of the output the NEXT GEMM consumes (qfx_gemm_fp8_args.cq): fp8 bytes, tile-major scales, row stride
+  // (bytes), scale rows, "skip the bf16 copy"
+  uint8_t* cq[QFX_MAX_GROUPS];
+  uint8_t* cs[QFX_MAX_GROUPS];
+  int64_t ldcq[QFX_MAX_GROUPS];
+  int cq_rows[QFX_MAX_GROUPS];
+  int cq_only[QFX_MAX_GROUPS];
 };
 
 // The argument block is read straight from the kernarg segment (constant address space, scalar loads): indexing the
@@ -598,6 +605,37 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     const bool n_ok = n + 7 < p.N;
     float gt[8];
     int last_b = -1;
+    // MX-FP8 instantiation: the output the next GEMM contracts over (gelu(h) / dh / y) can leave the epilogue quantised -- the 8
+    // lanes of a row hold 64 consecutive columns = 2 MX blocks of 4 lanes; same arithmetic as quant_mxfp8_kernel on the
+    // bf16-rounded values, so the result is bit-identical to quantising the bf16 tensor in a separate pass.
+    uint8_t* cq = nullptr; uint8_t* cs = nullptr; int64_t ldcq = 0; int cq_rows = 0; bool cq_only = false;
+    if constexpr (FP8) { cq = ga.cq[gi]; cs = ga.cs[gi]; ldcq = ga.ldcq[gi]; cq_rows = ga.cq_rows[gi]; cq_only = ga.cq_only[gi] != 0; }
+    auto quant_store = [&](const u32x4& packed, int64_t crow) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(packed[q] << 16); v[2 * q + 1] = __uint_as_float(packed[q] & 0xffff0000u); }
+      float amax = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(v[q]));
+      amax = fmaxf(amax, __shfl_xor(amax, 1));
+      amax = fmaxf(amax, __shfl_xor(amax, 2));
+      int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+      if (amax == 0.f) e = -127;
+      e = e < -127 ? -127 : e;
+      const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+      uint32_t w0 = 0, w1 = 0;
+      float qv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) qv[q] = fminf(fmaxf(v[q] * inv, -448.f), 448.f);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[0], qv[1], w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[2], qv[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[4], qv[5], w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(qv[6], qv[7], w1, true);
+      const u32x2 o = {w0, w1};
+      *(u32x2*)(cq + crow * ldcq + n) = o;
+      const int kb = n >> 5;
+      if ((ch & 3) == 0) cs[((int64_t)(kb >> 2) * cq_rows + crow) * 4 + (kb & 3)] = (uint8_t)(e + 127);
+    };
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -617,6 +655,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
           const u32x4 z = {0u, 0u, 0u, 0u};
           *(u32x4*)(p.C + crow * p.ldc + n) = z;
+          if constexpr (FP8 && EPI != QFX_EPI_GATE_RES) { if (cq) quant_store(z, crow); }
           if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
           if constexpr (EPI == QFX_EPI_GATE_RES) { if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = z; }
           continue;
@@ -625,13 +664,15 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 #pragma unroll
         for (int q = 0; q < 4; ++q) { y[2 * q] = __uint_as_float(yv[q] << 16); y[2 * q + 1] = __uint_as_float(yv[q] & 0xffff0000u); }
         if constexpr (EPI == QFX_EPI_NONE) {
-          *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+          if (!cq_only) *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+          if constexpr (FP8) { if (cq) quant_store(yv, crow); }
         } else if constexpr (EPI == QFX_EPI_GELU) {
           u32x4 o2;
 #pragma unroll
           for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
           *(u32x4*)(p.C + crow * p.ldc + n) = yv;
-          *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+          if (!cq_only) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+          if constexpr (FP8) { if (cq) quant_store(o2, crow); }
         } else if constexpr (EPI == QFX_EPI_GATE_RES) {
           const int bidx = m / p.rows_per_batch;
           if (bidx != last_b) {
@@ -657,7 +698,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
             const float h0 = __uint_as_float(hv[q] << 16), h1 = __uint_as_float(hv[q] & 0xffff0000u);
             o[q] = pack2bf(y[2 * q] * gelu_tanh_grad_f(h0), y[2 * q + 1] * gelu_tanh_grad_f(h1));
           }
-          *(u32x4*)(p.C + crow * p.ldc + n) = o;
+          if (!cq_only) *(u32x4*)(p.C + crow * p.ldc + n) = o;
+          if constexpr (FP8) { if (cq) quant_store(o, crow); }
         }
       }
     }
@@ -751,13 +793,21 @@ extern "C" int qfx_gemm_mxfp8_grouped(const qfx_gemm_fp8_args* list, int32_t n, 
     const int rc = validate(&g);
     if (rc) return rc;
     if (g.epi != list[0].g.epi || !ok256(&g)) return QFX_EINVAL;
+    if (list[i].cq) {   // quantised output image: whole 128-column tiles (4 MX blocks), 8-byte stores, scale rows cover every C row
+      if (!list[i].cs || g.epi == QFX_EPI_GATE_RES || (g.N % 128) || (list[i].ldcq % 8) || list[i].ldcq < g.N ||
+          list[i].cq_rows < (g.c_batch_rows ? (g.M / g.rows_per_batch) * g.c_batch_rows : g.M))
+        return QFX_EINVAL;
+    } else if (list[i].cq_only) {
+      return QFX_EINVAL;
+    }
     ga.g[i] = g;
     ga.sa[i] = list[i].sa; ga.sb[i] = list[i].sb;
+    ga.cq[i] = list[i].cq; ga.cs[i] = list[i].cs; ga.ldcq[i] = list[i].ldcq; ga.cq_rows[i] = list[i].cq_rows; ga.cq_only[i] = list[i].cq_only;
     ga.tile_start[i] = tiles;
     tiles += ((g.M + BM2 - 1) / BM2) * ((g.N + 127) / 128);
   }
   for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
-  for (int i = n; i < QFX_MAX_GROUPS; ++i) { ga.sa[i] = nullptr; ga.sb[i] = nullptr; }
+  for (int i = n; i < QFX_MAX_GROUPS; ++i) { ga.sa[i] = nullptr; ga.sb[i] = nullptr; ga.cq[i] = nullptr; ga.cs[i] = nullptr; ga.ldcq[i] = 0; ga.cq_rows[i] = 0; ga.cq_only[i] = 0; }
   ga.n = n;
   hipStream_t s = (hipStream_t)stream;
   const int rounds = (tiles + QFX_NUM_CU - 1) / QFX_NUM_CU;

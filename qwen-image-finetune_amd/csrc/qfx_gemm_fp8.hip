@@ -303,6 +303,7 @@ extern "C" int qfx_gemm_mxfp8(const qfx_gemm_fp8_args* a, void* stream) {
       !(g.epi == QFX_EPI_GELU && (g.ldc2 % 8)) && !((g.epi == QFX_EPI_GATE_RES || g.epi == QFX_EPI_DGELU) && (g.ldaux % 8)) &&
       !(g.epi == QFX_EPI_GATE_RES && ((g.gate_bstride % 8) || (g.C2 && (g.ldc2 % 8)))))
     return qfx_gemm_mxfp8_grouped(a, 1, stream);
+  if (a->cq || a->cq_only) return QFX_EUNSUPPORTED;   // the quantising epilogue lives in the persistent kernel only
   hipStream_t s = (hipStream_t)stream;
   switch (g.epi) {
     case QFX_EPI_NONE: hipLaunchKernelGGL(gemm_fp8_kernel<QFX_EPI_NONE>, dim3(tiles), dim3(256), 0, s, *a); break;

@@ -36,7 +36,8 @@ class QuantArgs(C.Structure):
 
 
 class GemmFp8Args(C.Structure):
-    _fields_ = [("g", GemmArgs), ("sa", C.c_void_p), ("ldsa", C.c_int64), ("sb", C.c_void_p), ("ldsb", C.c_int64)]
+    _fields_ = [("g", GemmArgs), ("sa", C.c_void_p), ("ldsa", C.c_int64), ("sb", C.c_void_p), ("ldsb", C.c_int64),
+                ("cq", C.c_void_p), ("cs", C.c_void_p), ("ldcq", C.c_int64), ("cq_rows", C.c_int32), ("cq_only", C.c_int32)]
 
 
 class LoraDownArgs(C.Structure):
@@ -121,6 +122,7 @@ class AttnArgs(C.Structure):
     ]
 
 
+ABI_VERSION = 2        # QFX_ABI_VERSION
 MAX_BATCH = 8          # QFX_MAX_BATCH
 MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
@@ -182,7 +184,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.qfx_abi_version() != 1:
+    if lib.qfx_abi_version() != ABI_VERSION:
         raise ImportError("libqfx.so ABI version mismatch")
     return lib
 

@@ -15,6 +15,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -837,6 +838,10 @@ class _QwenPlan:
         q = getattr(self.model, "_quant", None)
         if q and (prog is self.fwd or (q == "mxfp8-fb" and prog is self.bwd)) and all(self._fp8_ok(g) for g in groups):
             return self._gemm_group_mxfp8(prog, groups)
+        for g in groups:      # an operand that left its producer as MX-FP8 only (no bf16 copy) must not reach a bf16 GEMM
+            A1, lda1, a_map, rpb, B1 = g._src
+            if isinstance(A1, torch.Tensor) and (A1.data_ptr(), lda1, a_map, g.M) in self.__dict__.get("_preq", {}):
+                raise RuntimeError("internal: a pre-quantised GEMM operand is consumed by a bf16 GEMM")
         if len(groups) == 1:
             prog.keep.append(groups[0])
             prog.c(lib.qfx_gemm_bf16, C.byref(groups[0]))
@@ -861,15 +866,20 @@ class _QwenPlan:
         from .. import ops
         cache = self.model.__dict__.setdefault("_wq_cache", {})
         scratch = self.__dict__.setdefault("_q8", {})
+        preq = self.__dict__.setdefault("_preq", {})      # operands that left their producer's epilogue already quantised
         quantised = {}
         fp8 = []
-        for g in groups:
+        tiles = sum(((g.M + 255) // 256) * ((g.N + 127) // 128) for g in groups)
+        persistent = tiles >= 160 and len(groups) <= 6
+        for gi_, g in enumerate(groups):
             A1, lda1, a_map, rpb, B1 = g._src
             key = (B1.data_ptr(), tuple(B1.shape))
             if key not in cache:
                 cache[key] = ops.quant_mxfp8(B1)
             wq, ws = cache[key]
             akey = (A1.data_ptr(), lda1, a_map, g.M)
+            if akey in preq:
+                quantised[akey] = preq.pop(akey)
             if akey not in quantised:
                 slot = (g.M, g.K1, len(quantised))
                 if slot not in scratch:
@@ -888,11 +898,23 @@ class _QwenPlan:
             f.g.A1, f.g.lda1, f.g.a_batch_rows, f.g.a_row_off = _ptr(xq), g.K1, 0, 0
             f.g.B1, f.g.ldb1 = _ptr(wq), g.K1
             f.sa, f.ldsa, f.sb, f.ldsb = _ptr(xs), 0, _ptr(ws), 0
+            # quantising epilogue: gelu(h) (forward fc1 -> fc2) / dh (backward fc2-dX -> fc1-dX) leave the producer as MX-FP8 when the
+            # consumer is an MX-FP8 GEMM too; the stand-alone quantisation pass of that operand (60 MB read per block) disappears,
+            # and so does the bf16 copy when nothing else reads it (`nxt` = (tensor, row stride, bf16 copy still needed))
+            nxt = getattr(g, "_next", None)
+            if (nxt is not None and persistent and g.N % 128 == 0 and g.N >= 1024 and g.c_batch_rows == 0
+                    and os.environ.get("QFX_FP8_FUSED_QUANT", "1") != "0"):
+                out, ld_out, keep_bf16 = nxt
+                slot = ("pre", g.M, g.N, gi_)
+                if slot not in scratch:
+                    scratch[slot] = (self.buf(g.M, g.N, dtype=torch.uint8), self.buf(g.N // 128, g.M, 4, dtype=torch.uint8))
+                oq, osc = scratch[slot]
+                f.cq, f.cs, f.ldcq, f.cq_rows, f.cq_only = _ptr(oq), _ptr(osc), g.N, g.M, 0 if keep_bf16 else 1
+                preq[(out.data_ptr(), ld_out, (0, 0), g.M)] = (oq, osc)
             fp8.append(f)
             prog.keep.append((wq, ws))
         # one persistent grid for the whole group (image + text stream, q/k/v) when it is large enough, else one launch each
-        tiles = sum(((f.g.M + 255) // 256) * ((f.g.N + 127) // 128) for f in fp8)
-        if tiles >= 160 and len(fp8) <= 6:
+        if persistent:
             arr = (L.GemmFp8Args * len(fp8))(*fp8)
             prog.keep.append(arr)
             prog.c(lib.qfx_gemm_mxfp8_grouped, arr, len(fp8))
@@ -1204,6 +1226,7 @@ class _QwenPlan:
                 kw = lora_ext(s, f1, xm2[s], D, "Uf1.")
                 groups.append(self._gargs(A1=xm2[s], lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D,
                                           bias=f1.b, epi=L.EPI_GELU, C2=gact[s], ldc2=4 * D, **kw))
+                groups[-1]._next = (gact[s], 4 * D, w[s + ".fc2"].lora is not None)    # gelu(h) feeds fc2 (and its adapter's dA, if any)
             self._gemm_group(p, groups)
             groups = []
             for s, sidx in live:
@@ -1305,6 +1328,7 @@ class _QwenPlan:
                 kw = lora_bwd(s, f2, A["dyg2"][s], D, bb.get("g." + s), 4 * D, "Uf2.", "VtF2", early=True)
                 groups.append(self._gargs(A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s],
                                           ldc=4 * D, epi=L.EPI_DGELU, aux=bb["h"][s], ldaux=4 * D, **kw))
+                groups[-1]._next = (A["dh"][s], 4 * D, w[s + ".fc1"].lora is not None)   # dh feeds fc1's dX GEMM (and its adapter's v / dB)
             self._gemm_group(p, groups)
             groups = []
             for s, _ in live:

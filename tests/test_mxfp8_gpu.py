@@ -345,3 +345,72 @@ def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
     # fp8 rounding boundaries (bf16 inputs that differ in the last bit) are the residual.
     assert e_bf < 2e-2 and abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2
     assert e < 0.6 * gap and e < rel(pred_h, pred_b) and gw < 6e-2
+
+
+@pytest.mark.parametrize("epi", ["none", "gelu", "dgelu"])
+def test_gemm_mxfp8_quantising_epilogue_is_bit_identical_to_a_separate_pass(epi):
+    """qfx_gemm_fp8_args.cq: the output the next GEMM contracts over leaves the persistent kernel's epilogue as MX-FP8 bytes + tile-
+    major scales that equal qfx_quant_mxfp8 of the bf16 output bit for bit; cq_only suppresses the bf16 copy (the buffer keeps its
+    previous contents) without changing the quantised image; the small-problem kernel refuses the request."""
+    from qflux_amd import _lib as L
+    ops = _ops()
+    E = {"none": L.EPI_NONE, "gelu": L.EPI_GELU, "dgelu": L.EPI_DGELU}[epi]
+    Mi, Mt, N, K = 2048, 384, 3072, 1024
+    gg = torch.Generator().manual_seed(5)
+
+    def build(cq_only):
+        fs, keep = [], []
+        for M in (Mi, Mt):
+            g2 = torch.Generator().manual_seed(M)
+            a = torch.randn(M, K, generator=g2).to(BF).to(DEV)
+            b = (torch.randn(N, K, generator=g2) * 0.03).to(BF).to(DEV)
+            bias = torch.randn(N, generator=g2).to(BF).to(DEV)
+            aux = torch.randn(M, N, generator=g2).to(BF).to(DEV)
+            aq, asc = ops.quant_mxfp8(a)
+            bq, bsc = ops.quant_mxfp8(b)
+            y = torch.full((M, N), 7.0, dtype=BF, device=DEV)
+            y2 = torch.full((M, N), 7.0, dtype=BF, device=DEV)
+            oq = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+            osc = torch.zeros(N // 128, M, 4, dtype=torch.uint8, device=DEV)
+            f = L.GemmFp8Args()
+            q = f.g
+            q.A1, q.B1, q.lda1, q.ldb1, q.K1 = aq.data_ptr(), bq.data_ptr(), K, K, K
+            q.M, q.N, q.bias, q.C, q.ldc = M, N, bias.data_ptr(), y.data_ptr(), N
+            q.rows_per_batch, q.epi = M, E
+            if E == L.EPI_GELU:
+                q.C2, q.ldc2 = y2.data_ptr(), N
+            if E == L.EPI_DGELU:
+                q.aux, q.ldaux = aux.data_ptr(), N
+            f.sa, f.sb = asc.data_ptr(), bsc.data_ptr()
+            f.cq, f.cs, f.ldcq, f.cq_rows, f.cq_only = oq.data_ptr(), osc.data_ptr(), N, M, int(cq_only)
+            fs.append(f); keep.append((a, b, bias, aux, aq, asc, bq, bsc, y, y2, oq, osc))
+        arr = (L.GemmFp8Args * 2)(*fs)
+        L.check(L.lib.qfx_gemm_mxfp8_grouped(arr, 2, ops.stream_ptr()), "grouped")
+        torch.cuda.synchronize()
+        return keep
+
+    full = build(False)
+    only = build(True)
+    for kf, ko in zip(full, only):
+        y, y2, oq, osc = kf[8], kf[9], kf[10], kf[11]
+        consumed = y2 if E == L.EPI_GELU else y          # the tensor the next GEMM contracts over
+        rq, rs = ops.quant_mxfp8(consumed)
+        assert torch.equal(oq, rq) and torch.equal(osc.reshape(-1), rs.reshape(-1))
+        assert torch.equal(ko[10], oq) and torch.equal(ko[11], osc)                       # same image with cq_only
+        untouched = ko[9] if E == L.EPI_GELU else ko[8]
+        assert bool((untouched == 7.0).all())                                            # ... and no bf16 copy of it
+        if E == L.EPI_GELU:
+            assert torch.equal(ko[8], y)                                                  # h is still written
+    # a problem below the persistent threshold cannot honour the request
+    f = L.GemmFp8Args()
+    a = torch.randn(128, K, generator=gg).to(BF).to(DEV)
+    b = torch.randn(128, K, generator=gg).to(BF).to(DEV)
+    aq, asc = ops.quant_mxfp8(a)
+    bq, bsc = ops.quant_mxfp8(b)
+    y = torch.zeros(128, 128, dtype=BF, device=DEV)
+    oq = torch.zeros(128, 128, dtype=torch.uint8, device=DEV)
+    osc = torch.zeros(1, 128, 4, dtype=torch.uint8, device=DEV)
+    f.g.A1, f.g.B1, f.g.lda1, f.g.ldb1, f.g.K1, f.g.M, f.g.N, f.g.C, f.g.ldc, f.g.rows_per_batch = aq.data_ptr(), bq.data_ptr(), K, K, K, 128, 128, y.data_ptr(), 128, 128
+    f.sa, f.sb, f.cq, f.cs, f.ldcq, f.cq_rows = asc.data_ptr(), bsc.data_ptr(), oq.data_ptr(), osc.data_ptr(), 128, 128
+    import ctypes as C
+    assert L.lib.qfx_gemm_mxfp8(C.byref(f), ops.stream_ptr()) == -2        # QFX_EUNSUPPORTED

@@ -20,9 +20,17 @@ def t(n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, l.item()
 out = {}
 modes = sys.argv[1:] or ["none", "mxfp8"]
-for mode in modes:
+# mode[:unfused] -- "mxfp8-fb:unfused" switches the quantising GEMM epilogues off (stand-alone quantisation passes for every operand)
+p0 = dit.lora_store.pflat.detach().clone()
+for mode_ in modes:
+    mode, _, opt = mode_.partition(":")
+    os.environ["QFX_FP8_FUSED_QUANT"] = "0" if opt == "unfused" else "1"
     dit.quantize_trunk(None if mode == "none" else mode)
+    # every mode starts from the same adapter weights / optimizer state and sees the same noise: losses are comparable
+    dit.lora_store.pflat.copy_(p0); step._m = None; step.global_step = 0
+    torch.manual_seed(7)
     ms, l = t()
+    mode = mode_
     out[mode] = {"ms_per_step": round(ms, 2), "images_per_s": round(1e3 / ms, 2), "loss": round(l, 4)}
     print(mode, out[mode], flush=True)
 json.dump(out, open("gpurun_out/fp8_step.json", "w"), indent=1)
