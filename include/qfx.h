@@ -187,14 +187,19 @@ int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* s
 /* Batched forms: n <= QFX_MAX_LN_BATCH problems in ONE launch (the image and the text stream of a block: the 384-row text
  * problem otherwise pays a dispatch gap and a memory round trip of its own).  Every problem but the last needs rows % 4 == 0. */
 #define QFX_MAX_LN_BATCH 4
+/* ABI 2, MX-FP8 trunk: yq / dygq != NULL -- the output (y resp. dyg) ALSO leaves the kernel as MX-FP8 (bytes at yq + row*ldyq,
+ * E8M0 scales tile-major [D/128][ys_rows][4] as qfx_quant_mxfp8 writes them, bit-identical to quantising the bf16 output in a
+ * separate pass; D % 128 == 0): the GEMM that consumes it skips its quantisation pass. */
 typedef struct qfx_ln_fwd_args {
   const uint16_t* x; const uint16_t* shift; const uint16_t* scale; int64_t mod_bstride; uint16_t* y;
   int32_t rows; int32_t D; int32_t rows_per_batch; float eps;
+  uint8_t* yq; uint8_t* ys; int64_t ldyq; int32_t ys_rows; int32_t pad_;
 } qfx_ln_fwd_args;
 typedef struct qfx_ln_bwd_args {
   const uint16_t* dy; const uint16_t* x; const uint16_t* scale; int64_t mod_bstride;
   const uint16_t* dres; const uint16_t* gate; int64_t gate_bstride; uint16_t* dx; uint16_t* dyg;
   const float* row_mask; int32_t rows; int32_t D; int32_t rows_per_batch; float eps;
+  uint8_t* dygq; uint8_t* dygs; int64_t lddygq; int32_t dygs_rows; int32_t pad_;
 } qfx_ln_bwd_args;
 int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n, void* stream);
 int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n, void* stream);

@@ -64,3 +64,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// MX-FP8 quantisation of 8 consecutive elements of a 32-element block held by 4 lanes (the caller passes the block maximum over
+// those lanes): OCP MX, shared exponent floor(log2(amax)) - 8, e4m3 elements RNE, saturated at +-448 -- the arithmetic of
+// quant_mxfp8_kernel, so that producers that quantise on the fly emit the same bytes as a separate pass over their bf16 output.
+__device__ __forceinline__ u32x2 mx_quant8(const float (&v)[8], float amax, int& e_biased) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+  if (amax == 0.f) e = -127;
+  e = e < -127 ? -127 : e;
+  const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+  float q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf(v[i] * inv, -448.f), 448.f);
+  uint32_t w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+  e_biased = e + 127;
+  return (u32x2){w0, w1};
+}

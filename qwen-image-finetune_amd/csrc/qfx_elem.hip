@@ -25,6 +25,23 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
   *(u32x4*)p = u;
 }
 
+// MX-FP8 image of 8 consecutive output columns of a row-per-wave kernel (lane l holds columns 8l' .. 8l'+7: an MX block is 4
+// adjacent lanes).  `o` are the fp32 values that st8 rounds to bf16: the image is taken from the ROUNDED values, like a separate
+// qfx_quant_mxfp8 pass over the bf16 tensor.  Every lane of the 4-lane group must call it (shuffles).
+__device__ __forceinline__ void mx_store8(const float (&o)[8], uint8_t* dst, uint8_t* sc, int sc_rows, int row, int col, int lane) {
+  float v[8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = rbf(o[i]); amax = fmaxf(amax, fabsf(v[i])); }
+  amax = fmaxf(amax, __shfl_xor(amax, 1));
+  amax = fmaxf(amax, __shfl_xor(amax, 2));
+  int eb;
+  const u32x2 q = mx_quant8(v, amax, eb);
+  *(u32x2*)dst = q;
+  const int kb = col >> 5;
+  if ((lane & 3) == 0) sc[((int64_t)(kb >> 2) * sc_rows + row) * 4 + (kb & 3)] = (uint8_t)eb;
+}
+
 // ---------------------------------------------------------------- LayerNorm + modulate, forward
 // Batched: up to QFX_MAX_LN_BATCH problems (e.g. the image and the text stream of a block) share one launch; a wave owns
 // one row of one problem.  The tiny text-stream problems otherwise pay a full dispatch gap + memory round trip each.
@@ -40,9 +57,11 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt) {
     if (pi == i && i + 1 < bt.n && row >= bt.a[i].rows) { row -= bt.a[i].rows; pi = i + 1; }
   const bf16_t* __restrict__ x; const bf16_t* __restrict__ shift; const bf16_t* __restrict__ scale; bf16_t* __restrict__ y;
   int64_t mod_bstride; int rows, D, rpb; float eps;
+  uint8_t* yq; uint8_t* ys; int64_t ldyq; int ys_rows;
   {
     const qfx_ln_fwd_args& q = pi == 0 ? bt.a[0] : (pi == 1 ? bt.a[1] : (pi == 2 ? bt.a[2] : bt.a[3]));
     x = q.x; shift = q.shift; scale = q.scale; y = q.y; mod_bstride = q.mod_bstride; rows = q.rows; D = q.D; rpb = q.rows_per_batch; eps = q.eps;
+    yq = q.yq; ys = q.ys; ldyq = q.ldyq; ys_rows = q.ys_rows;
   }
   if (row >= rows) return;
   const int b = row / rpb;
@@ -83,6 +102,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt) {
         o[i] = rbf(ln * t1) + sh[i];
       }
       st8(y + (int64_t)row * D + col, o);
+      if (yq) mx_store8(o, yq + (int64_t)row * ldyq + col, ys, ys_rows, row, col, lane);
     }
   }
 }
@@ -99,10 +119,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   const bf16_t* __restrict__ dy; const bf16_t* __restrict__ x; const bf16_t* __restrict__ scale; const bf16_t* __restrict__ dres;
   const bf16_t* __restrict__ gate; bf16_t* __restrict__ dx; bf16_t* __restrict__ dyg; const float* __restrict__ row_mask;
   int64_t mod_bstride, gate_bstride; int rows, D, rpb; float eps;
+  uint8_t* dygq; uint8_t* dygs; int64_t lddygq; int dygs_rows;
   {
     const qfx_ln_bwd_args& q = pi == 0 ? bt.a[0] : (pi == 1 ? bt.a[1] : (pi == 2 ? bt.a[2] : bt.a[3]));
     dy = q.dy; x = q.x; scale = q.scale; dres = q.dres; gate = q.gate; dx = q.dx; dyg = q.dyg; row_mask = q.row_mask;
     mod_bstride = q.mod_bstride; gate_bstride = q.gate_bstride; rows = q.rows; D = q.D; rpb = q.rows_per_batch; eps = q.eps;
+    dygq = q.dygq; dygs = q.dygs; lddygq = q.lddygq; dygs_rows = q.dygs_rows;
   }
   if (row >= rows) return;
   const int b = row / rpb;
@@ -112,7 +134,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int col = (p * 64 + lane) * 8;
-      if (col < D) { *(u32x4*)(dx + ro + col) = z; if (dyg) *(u32x4*)(dyg + ro + col) = z; }
+      if (col < D) {
+        *(u32x4*)(dx + ro + col) = z;
+        if (dyg) *(u32x4*)(dyg + ro + col) = z;
+        if (dyg && dygq) { const float zf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; mx_store8(zf, dygq + (int64_t)row * lddygq + col, dygs, dygs_rows, row, col, lane); }
+      }
     }
     return;
   }
@@ -187,6 +213,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) og[i] = gt[i] * o[i];
         st8(dyg + ro + col, og);
+        if (dygq) mx_store8(og, dygq + (int64_t)row * lddygq + col, dygs, dygs_rows, row, col, lane);
       }
     }
   }
@@ -769,6 +796,7 @@ extern "C" int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n,
     if (!a.x || !a.shift || !a.scale || !a.y || a.rows <= 0 || a.D <= 0 || (a.D % 8) || a.D > MAXP * 512 || a.rows_per_batch <= 0 ||
         (a.mod_bstride % 8))
       return QFX_EINVAL;
+    if (a.yq && (!a.ys || (a.D % 128) || (a.ldyq % 8) || a.ldyq < a.D || a.ys_rows < a.rows)) return QFX_EINVAL;
     bt.a[i] = a;
     rows += (a.rows + 3) / 4 * 4;     // problems start on a block boundary (4 rows per block)
     if (i + 1 < n && (a.rows % 4)) return QFX_EINVAL;   /* only the last problem may have a ragged row count */
@@ -782,7 +810,7 @@ extern "C" int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n,
 
 extern "C" int qfx_ln_modulate_fwd(const uint16_t* x, const uint16_t* shift, const uint16_t* scale, int64_t mod_bstride,
                                    uint16_t* y, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, void* stream) {
-  qfx_ln_fwd_args a;
+  qfx_ln_fwd_args a = {};
   a.x = x; a.shift = shift; a.scale = scale; a.mod_bstride = mod_bstride; a.y = y; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch;
   a.eps = eps;
   return qfx_ln_modulate_fwd_batch(&a, 1, stream);
@@ -798,6 +826,7 @@ extern "C" int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n,
         (a.mod_bstride % 8))
       return QFX_EINVAL;
     if (a.dyg && (!a.gate || (a.gate_bstride % 8))) return QFX_EINVAL;
+    if (a.dygq && (!a.dyg || !a.dygs || (a.D % 128) || (a.lddygq % 8) || a.lddygq < a.D || a.dygs_rows < a.rows)) return QFX_EINVAL;
     bt.a[i] = a;
     rows += (a.rows + 3) / 4 * 4;
     if (i + 1 < n && (a.rows % 4)) return QFX_EINVAL;
@@ -816,7 +845,7 @@ extern "C" int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const 
                                    const uint16_t* dres, const uint16_t* gate, int64_t gate_bstride, uint16_t* dx,
                                    uint16_t* dyg, int32_t rows, int32_t D, int32_t rows_per_batch, float eps, const float* row_mask,
                                    void* stream) {
-  qfx_ln_bwd_args a;
+  qfx_ln_bwd_args a = {};
   a.dy = dy; a.x = x; a.scale = scale; a.mod_bstride = mod_bstride; a.dres = dres; a.gate = gate; a.gate_bstride = gate_bstride;
   a.dx = dx; a.dyg = dyg; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch; a.eps = eps; a.row_mask = row_mask;
   return qfx_ln_modulate_bwd_batch(&a, 1, stream);

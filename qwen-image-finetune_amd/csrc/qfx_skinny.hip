@@ -210,6 +210,20 @@ __global__ __launch_bounds__(512) void ln_down_kernel(const LnDownBatch batch_by
       }
       xs[i] = o;
       if (row_ok) *(bf16x8*)(p.ln.y + (int64_t)mr * D + 8 * g + ks * 32) = o;
+      if (p.ln.yq) {   // MX-FP8 image of y (block-uniform): the 32 columns of this k-step are one MX block held by the 4 lane groups
+        float v[8];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = bf2f((bf16_t)o[j]); amax = fmaxf(amax, fabsf(v[j])); }
+        amax = fmaxf(amax, __shfl_xor(amax, 16));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        int eb;
+        const u32x2 qv = mx_quant8(v, amax, eb);
+        if (row_ok) {
+          *(u32x2*)(p.ln.yq + (int64_t)mr * p.ln.ldyq + 8 * g + ks * 32) = qv;
+          if (g == 0) p.ln.ys[((int64_t)(ks >> 2) * p.ln.ys_rows + mr) * 4 + (ks & 3)] = (uint8_t)eb;
+        }
+      }
     }
   }
   if (p.W_hi == nullptr) return;             // plain LayerNorm rows (block-uniform)
@@ -531,6 +545,7 @@ extern "C" int qfx_ln_down_fwd(const qfx_ln_down_args* list, int32_t n, void* st
     const qfx_ln_down_args& a = list[i];
     if (!a.ln.x || !a.ln.shift || !a.ln.scale || !a.ln.y || a.ln.rows <= 0 || a.ln.rows_per_batch <= 0) return QFX_EINVAL;
     if (a.ln.D <= 0 || (a.ln.D % 256) || a.ln.D > 3072 || (a.ln.mod_bstride % 8)) return QFX_EUNSUPPORTED;
+    if (a.ln.yq && (!a.ln.ys || (a.ln.ldyq % 8) || a.ln.ldyq < a.ln.D || a.ln.ys_rows < a.ln.rows)) return QFX_EINVAL;
     if (a.W_hi) {
       if (!a.W_lo || (a.ldw % 8) || a.R <= 0 || (a.R % 16) || a.R > 48) return QFX_EUNSUPPORTED;
       if (R && a.R != R) return QFX_EINVAL;

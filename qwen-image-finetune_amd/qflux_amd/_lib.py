@@ -64,7 +64,8 @@ class LoraGradArgs(C.Structure):
 
 class LnFwdArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("shift", C.c_void_p), ("scale", C.c_void_p), ("mod_bstride", C.c_int64), ("y", C.c_void_p),
-                ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
+                ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float),
+                ("yq", C.c_void_p), ("ys", C.c_void_p), ("ldyq", C.c_int64), ("ys_rows", C.c_int32), ("pad_", C.c_int32)]
 
 
 class LnDownArgs(C.Structure):
@@ -76,14 +77,16 @@ class LnDownArgs(C.Structure):
 class LnBwdArgs(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("x", C.c_void_p), ("scale", C.c_void_p), ("mod_bstride", C.c_int64),
                 ("dres", C.c_void_p), ("gate", C.c_void_p), ("gate_bstride", C.c_int64), ("dx", C.c_void_p), ("dyg", C.c_void_p),
-                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
+                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float),
+                ("dygq", C.c_void_p), ("dygs", C.c_void_p), ("lddygq", C.c_int64), ("dygs_rows", C.c_int32), ("pad_", C.c_int32)]
 
 
 class ModGradArgs(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("ld_dy", C.c_int64), ("x", C.c_void_p), ("ld_x", C.c_int64),
                 ("dxo", C.c_void_p), ("ld_dxo", C.c_int64), ("y", C.c_void_p), ("ld_y", C.c_int64),
                 ("dshift", C.c_void_p), ("dscale", C.c_void_p), ("dgate", C.c_void_p), ("out_bstride", C.c_int64),
-                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
+                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float),
+                ("dygq", C.c_void_p), ("dygs", C.c_void_p), ("lddygq", C.c_int64), ("dygs_rows", C.c_int32), ("pad_", C.c_int32)]
 
 
 class LoraPackArgs(C.Structure):

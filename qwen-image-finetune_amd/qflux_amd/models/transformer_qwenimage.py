@@ -833,15 +833,40 @@ class _QwenPlan:
     def _gemm(self, prog, **kw):
         self._gemm_group(prog, [self._gargs(**kw)])
 
+    def _preq_out(self, prog, out, ld, M, N, tag, keep_bf16=True):
+        """Scratch (fp8 bytes [M, N], tile-major scales [N/128, M, 4]) for the MX-FP8 image of `out` that its PRODUCER writes on
+        the fly; registered so that the MX-FP8 GEMM group that comes next skips its quantisation pass for this operand (the
+        registration lives until that next group).  None when the trunk is not quantised in this direction / shape."""
+        q = getattr(self.model, "_quant", None)
+        if (not q or (prog is self.bwd and q != "mxfp8-fb") or N % 128 or N < 1024 or out is None
+                or os.environ.get("QFX_FP8_FUSED_QUANT", "1") == "0"):
+            return None
+        scratch = self.__dict__.setdefault("_q8", {})
+        slot = ("pre", M, N, tag)
+        if slot not in scratch:
+            scratch[slot] = (self.buf(M, N, dtype=torch.uint8), self.buf(N // 128, M, 4, dtype=torch.uint8))
+        oq, osc = scratch[slot]
+        self.__dict__.setdefault("_preq", {})[(out.data_ptr(), ld, (0, 0), M)] = (oq, osc, not keep_bf16)
+        return oq, osc
+
     def _gemm_group(self, prog, groups):
         """One grid for several independent GEMMs with the same epilogue (image+text streams, q/k/v)."""
+        try:
+            return self._gemm_group_impl(prog, groups)
+        finally:
+            pq = self.__dict__.setdefault("_preq", {})
+            pq.clear()      # on-the-fly quantised operands are for the GEMM group that follows their producer
+            pq.update(self.__dict__.pop("_preq_next", None) or [])
+
+    def _gemm_group_impl(self, prog, groups):
         q = getattr(self.model, "_quant", None)
         if q and (prog is self.fwd or (q == "mxfp8-fb" and prog is self.bwd)) and all(self._fp8_ok(g) for g in groups):
             return self._gemm_group_mxfp8(prog, groups)
         for g in groups:      # an operand that left its producer as MX-FP8 only (no bf16 copy) must not reach a bf16 GEMM
             A1, lda1, a_map, rpb, B1 = g._src
-            if isinstance(A1, torch.Tensor) and (A1.data_ptr(), lda1, a_map, g.M) in self.__dict__.get("_preq", {}):
-                raise RuntimeError("internal: a pre-quantised GEMM operand is consumed by a bf16 GEMM")
+            ent = self.__dict__.get("_preq", {}).get((A1.data_ptr(), lda1, a_map, g.M)) if isinstance(A1, torch.Tensor) else None
+            if ent is not None and ent[2]:
+                raise RuntimeError("internal: an operand that exists only as MX-FP8 is consumed by a bf16 GEMM")
         if len(groups) == 1:
             prog.keep.append(groups[0])
             prog.c(lib.qfx_gemm_bf16, C.byref(groups[0]))
@@ -869,6 +894,7 @@ class _QwenPlan:
         preq = self.__dict__.setdefault("_preq", {})      # operands that left their producer's epilogue already quantised
         quantised = {}
         fp8 = []
+        produced = []       # operands this group's epilogues quantise for the NEXT group (registered after this one is emitted)
         tiles = sum(((g.M + 255) // 256) * ((g.N + 127) // 128) for g in groups)
         persistent = tiles >= 160 and len(groups) <= 6
         for gi_, g in enumerate(groups):
@@ -879,7 +905,7 @@ class _QwenPlan:
             wq, ws = cache[key]
             akey = (A1.data_ptr(), lda1, a_map, g.M)
             if akey in preq:
-                quantised[akey] = preq.pop(akey)
+                quantised[akey] = preq[akey][:2]
             if akey not in quantised:
                 slot = (g.M, g.K1, len(quantised))
                 if slot not in scratch:
@@ -910,7 +936,7 @@ class _QwenPlan:
                     scratch[slot] = (self.buf(g.M, g.N, dtype=torch.uint8), self.buf(g.N // 128, g.M, 4, dtype=torch.uint8))
                 oq, osc = scratch[slot]
                 f.cq, f.cs, f.ldcq, f.cq_rows, f.cq_only = _ptr(oq), _ptr(osc), g.N, g.M, 0 if keep_bf16 else 1
-                preq[(out.data_ptr(), ld_out, (0, 0), g.M)] = (oq, osc)
+                produced.append(((out.data_ptr(), ld_out, (0, 0), g.M), (oq, osc, not keep_bf16)))
             fp8.append(f)
             prog.keep.append((wq, ws))
         # one persistent grid for the whole group (image + text stream, q/k/v) when it is large enough, else one launch each
@@ -922,6 +948,7 @@ class _QwenPlan:
             for f in fp8:
                 prog.keep.append(f)
                 prog.c(lib.qfx_gemm_mxfp8, C.byref(f))
+        self._preq_next = produced
 
     def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
               group_stride=0, rpb=None, x_map=(0, 0), defer=None):
@@ -1139,6 +1166,9 @@ class _QwenPlan:
                 grp = w[s + ".qkv_lora"]
                 xm1 = bb["xm1." + s] if grp is not None else A["xm"][s]
                 ln = self._ln_fwd_args(x_in[s], mod[:, 0:D], mod[:, D:2 * D], 6 * D, xm1, rows[s], D, rpb[s], eps)
+                pq_ = self._preq_out(p, xm1, D, rows[s], D, s)       # MX-FP8 trunk: the q/k/v GEMMs take xm1 quantised by its producer
+                if pq_ is not None:
+                    ln.yq, ln.ys, ln.ldyq, ln.ys_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
                 lnl.append(ln)
                 ents.append((ln, None if grp is None else dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
                                                                Ut=bb["Uqkv." + s], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
@@ -1210,6 +1240,10 @@ class _QwenPlan:
             gact = {s: (bb["g." + s] if w[s + ".fc2"].lora is not None else A["g"][s]) for s, _ in live}
             lnl = [self._ln_fwd_args(bb["x1"][s], mods[s][:, 3 * D:4 * D], mods[s][:, 4 * D:5 * D], 6 * D, xm2[s], rows[s], D, rpb[s], eps)
                    for s, sidx in live]
+            for ln, (s, sidx) in zip(lnl, live):
+                pq_ = self._preq_out(p, xm2[s], D, rows[s], D, s)    # ... and fc1 takes xm2
+                if pq_ is not None:
+                    ln.yq, ln.ys, ln.ldyq, ln.ys_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
             self._flush_ln(p, lnl, L.LnFwdArgs, lib.qfx_ln_modulate_fwd_batch)
 
             def lora_ext(s, lw, X, ldx, ukey):
@@ -1348,6 +1382,10 @@ class _QwenPlan:
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
                                      A["dx1"][s], dyg1[s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
+            for ln, (s, sidx) in zip(lnl, live):
+                pq_ = self._preq_out(p, dyg1[s], D, rows[s], D, s)   # "mxfp8-fb": the out-projection dX GEMM takes gate1*dx quantised
+                if pq_ is not None:
+                    ln.dygq, ln.dygs, ln.lddygq, ln.dygs_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
             self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
             for s, sidx in live:
                 mod = mods[s]
@@ -1428,6 +1466,9 @@ class _QwenPlan:
                     lnl.append(self._ln_bwd_args(A["dxm"][s], x_in[s], mods[s][:, D:2 * D], 6 * D, dres, gp,
                                                  (gp.stride(0) if gp is not None else 0), out_dx[s],
                                                  A["dyg2"][s] if gp is not None else None, rows[s], D, rpb[s], eps, self.rmask[s]))
+                    pq_ = self._preq_out(p, A["dyg2"][s] if gp is not None else None, D, rows[s], D, s)   # the previous block's fc2-dX operand
+                    if pq_ is not None:
+                        lnl[-1].dygq, lnl[-1].dygs, lnl[-1].lddygq, lnl[-1].dygs_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
                 self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
         if self.side_grads and gl:
             p.py(self._side_fork)

@@ -414,3 +414,50 @@ def test_gemm_mxfp8_quantising_epilogue_is_bit_identical_to_a_separate_pass(epi)
     f.sa, f.sb, f.cq, f.cs, f.ldcq, f.cq_rows = asc.data_ptr(), bsc.data_ptr(), oq.data_ptr(), osc.data_ptr(), 128, 128
     import ctypes as C
     assert L.lib.qfx_gemm_mxfp8(C.byref(f), ops.stream_ptr()) == -2        # QFX_EUNSUPPORTED
+
+
+def test_layernorm_kernels_emit_bit_identical_mxfp8_images():
+    """qfx_ln_modulate_fwd_batch (yq), qfx_ln_down_fwd (ln.yq) and qfx_ln_modulate_bwd_batch (dygq): the MX-FP8 image written on the
+    fly equals qfx_quant_mxfp8 of the bf16 output of the same launch, bytes and tile-major scales."""
+    import ctypes as C
+    from qflux_amd import _lib as L
+    ops = _ops()
+    D = 1024
+    g = torch.Generator().manual_seed(11)
+    for rows in (2048, 384):
+        x = (torch.randn(rows, D, generator=g) * 2).to(BF).to(DEV)
+        mod = (torch.randn(1, 3 * D, generator=g) * 0.3).to(BF).to(DEV)
+        # forward, row-per-wave kernel
+        y = torch.empty(rows, D, dtype=BF, device=DEV)
+        yq = torch.zeros(rows, D, dtype=torch.uint8, device=DEV)
+        ys = torch.zeros(D // 128, rows, 4, dtype=torch.uint8, device=DEV)
+        a = (L.LnFwdArgs * 1)()
+        a[0].x, a[0].shift, a[0].scale, a[0].mod_bstride, a[0].y = x.data_ptr(), mod[:, :D].data_ptr(), mod[:, D:2 * D].data_ptr(), 3 * D, y.data_ptr()
+        a[0].rows, a[0].D, a[0].rows_per_batch, a[0].eps = rows, D, rows, 1e-6
+        a[0].yq, a[0].ys, a[0].ldyq, a[0].ys_rows = yq.data_ptr(), ys.data_ptr(), D, rows
+        L.check(L.lib.qfx_ln_modulate_fwd_batch(a, 1, ops.stream_ptr()), "ln fwd")
+        rq, rs = ops.quant_mxfp8(y)
+        assert torch.equal(yq, rq) and torch.equal(ys.reshape(-1), rs.reshape(-1))
+        # forward, fused LN + down kernel (plain LayerNorm rows: W_hi = NULL)
+        y2 = torch.empty(rows, D, dtype=BF, device=DEV)
+        yq.zero_(); ys.zero_()
+        d = (L.LnDownArgs * 1)()
+        C.memmove(C.byref(d[0].ln), C.byref(a[0]), C.sizeof(L.LnFwdArgs))
+        d[0].ln.y = y2.data_ptr()
+        L.check(L.lib.qfx_ln_down_fwd(d, 1, ops.stream_ptr()), "ln_down")
+        rq, rs = ops.quant_mxfp8(y2)
+        assert torch.equal(yq, rq) and torch.equal(ys.reshape(-1), rs.reshape(-1))
+        # backward: dyg = gate * dx
+        dy = torch.randn(rows, D, generator=g).to(BF).to(DEV)
+        dres = torch.randn(rows, D, generator=g).to(BF).to(DEV)
+        dx = torch.empty(rows, D, dtype=BF, device=DEV)
+        dyg = torch.empty(rows, D, dtype=BF, device=DEV)
+        yq.zero_(); ys.zero_()
+        b = (L.LnBwdArgs * 1)()
+        b[0].dy, b[0].x, b[0].scale, b[0].mod_bstride = dy.data_ptr(), x.data_ptr(), mod[:, D:2 * D].data_ptr(), 3 * D
+        b[0].dres, b[0].gate, b[0].gate_bstride, b[0].dx, b[0].dyg = dres.data_ptr(), mod[:, 2 * D:].data_ptr(), 3 * D, dx.data_ptr(), dyg.data_ptr()
+        b[0].rows, b[0].D, b[0].rows_per_batch, b[0].eps = rows, D, rows, 1e-6
+        b[0].dygq, b[0].dygs, b[0].lddygq, b[0].dygs_rows = yq.data_ptr(), ys.data_ptr(), D, rows
+        L.check(L.lib.qfx_ln_modulate_bwd_batch(b, 1, ops.stream_ptr()), "ln bwd")
+        rq, rs = ops.quant_mxfp8(dyg)
+        assert torch.equal(yq, rq) and torch.equal(ys.reshape(-1), rs.reshape(-1))
