@@ -126,6 +126,11 @@ typedef struct qfx_lora_down_args {
   int32_t group_R; int32_t group_stride; /* ext column of U column j: (j/group_R)*group_stride + j%group_R + {0,group_R,2*group_R}
                                             (several LoRA targets sharing X are fused in one call; group_R = R for one) */
   int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off; /* X row remap as in gemm */
+  /* ABI 2, MX-FP8 trunk: xq != NULL -- the kernel reads every element of X anyway; it also writes X's MX-FP8 image for the GEMM that
+   * contracts over it: bytes at xq + m*ldxq + k (m = compact row), E8M0 scales tile-major as qfx_quant_mxfp8 writes them, the
+   * 32-column block ks of this call being block xq_kb0 + ks of an operand with xs_rows rows (several calls fill the column
+   * sections of one operand: q / k / v sections of dqkv).  K % 128 == 0, xq_kb0 % 4 == 0. */
+  uint8_t* xq; uint8_t* xs; int64_t ldxq; int32_t xs_rows; int32_t xq_kb0;
 } qfx_lora_down_args;
 
 int qfx_lora_down(const qfx_lora_down_args* args, void* stream);

@@ -65,6 +65,31 @@ __global__ __launch_bounds__(512) void lora_down_kernel(const DownBatch batch_by
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) xs[i][rb] = ks < nks ? *(const bf16x8*)(xrow[rb] + ks * 32) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
+    if (p.xq != nullptr) {   // MX-FP8 image of X (block-uniform): the 32 columns of a k-step are one MX block held by the 4 lane groups
+#pragma unroll
+      for (int i = 0; i < CHK; ++i) {
+        const int ks = base + i * NW;
+        if (ks < nks) {      // wave-uniform
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            float v[8];
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = bf2f((bf16_t)xs[i][rb][j]); amax = fmaxf(amax, fabsf(v[j])); }
+            amax = fmaxf(amax, __shfl_xor(amax, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            int eb;
+            const u32x2 qv = mx_quant8(v, amax, eb);
+            const int m = m0 + rb * 16 + li;
+            if (m < p.M) {
+              *(u32x2*)(p.xq + (int64_t)m * p.ldxq + ks * 32 + 8 * g) = qv;
+              const int kb = p.xq_kb0 + ks;
+              if (g == 0) p.xs[((int64_t)(kb >> 2) * p.xs_rows + m) * 4 + (kb & 3)] = (uint8_t)eb;
+            }
+          }
+        }
+      }
+    }
     // weight fragments: L2 hits streamed through a register ring DEPTH k-steps deep (all of the chunk for one fragment column:
     // with a single step of look-ahead the CHK dependent L2 round trips were most of the launch)
     constexpr int DEPTH = (NF == 1 ? CHK : (NF == 2 ? 6 : 3)) < CHK ? (NF == 1 ? CHK : (NF == 2 ? 6 : 3)) : CHK;
@@ -487,6 +512,7 @@ int check_down(const qfx_lora_down_args* a) {
   if (a->ext && (a->group_R <= 0 || (a->R % a->group_R))) return QFX_EINVAL;
   if (a->Ut_hi && (!a->Ut_lo || a->ld_ut < a->M)) return QFX_EINVAL;
   if (a->rows_per_batch <= 0) return QFX_EINVAL;
+  if (a->xq && (!a->xs || (a->K % 128) || (a->ldxq % 8) || a->ldxq < a->K || a->xs_rows < a->M || (a->xq_kb0 % 4) || a->xq_kb0 < 0)) return QFX_EINVAL;
   return QFX_OK;
 }
 int check_grad(const qfx_lora_grad_args* a) {

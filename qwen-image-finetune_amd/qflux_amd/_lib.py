@@ -49,6 +49,7 @@ class LoraDownArgs(C.Structure):
         ("Ut_hi", C.c_void_p), ("Ut_lo", C.c_void_p), ("ld_ut", C.c_int64),
         ("group_R", C.c_int32), ("group_stride", C.c_int32),
         ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
+        ("xq", C.c_void_p), ("xs", C.c_void_p), ("ldxq", C.c_int64), ("xs_rows", C.c_int32), ("xq_kb0", C.c_int32),
     ]
 
 

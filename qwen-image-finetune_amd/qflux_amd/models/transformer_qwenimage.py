@@ -833,7 +833,7 @@ class _QwenPlan:
     def _gemm(self, prog, **kw):
         self._gemm_group(prog, [self._gargs(**kw)])
 
-    def _preq_out(self, prog, out, ld, M, N, tag, keep_bf16=True):
+    def _preq_out(self, prog, out, ld, M, N, tag, keep_bf16=True, a_map=(0, 0)):
         """Scratch (fp8 bytes [M, N], tile-major scales [N/128, M, 4]) for the MX-FP8 image of `out` that its PRODUCER writes on
         the fly; registered so that the MX-FP8 GEMM group that comes next skips its quantisation pass for this operand (the
         registration lives until that next group).  None when the trunk is not quantised in this direction / shape."""
@@ -846,7 +846,7 @@ class _QwenPlan:
         if slot not in scratch:
             scratch[slot] = (self.buf(M, N, dtype=torch.uint8), self.buf(N // 128, M, 4, dtype=torch.uint8))
         oq, osc = scratch[slot]
-        self.__dict__.setdefault("_preq", {})[(out.data_ptr(), ld, (0, 0), M)] = (oq, osc, not keep_bf16)
+        self.__dict__.setdefault("_preq", {})[(out.data_ptr(), ld, tuple(a_map), M)] = (oq, osc, not keep_bf16)
         return oq, osc
 
     def _gemm_group(self, prog, groups):
@@ -951,8 +951,10 @@ class _QwenPlan:
         self._preq_next = produced
 
     def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
-              group_stride=0, rpb=None, x_map=(0, 0), defer=None):
+              group_stride=0, rpb=None, x_map=(0, 0), defer=None, xq=None):
         a = L.LoraDownArgs()
+        if xq is not None:      # (bytes, scales, row stride, scale rows, first 32-column block): X's MX-FP8 image rides along
+            a.xq, a.xs, a.ldxq, a.xs_rows, a.xq_kb0 = xq
         a.X, a.ldx, a.M, a.K = _ptr(X), ldx, M, K
         a.W_hi, a.W_lo, a.ldw, a.R = _ptr(W_hi), _ptr(W_lo), ldw, R
         a.U, a.ldu = _ptr(U), ldu
@@ -1224,9 +1226,13 @@ class _QwenPlan:
                 lw = w[s + ".o"]
                 kw = {}
                 if lw.lora is not None:
+                    # MX-FP8 trunk: the down projection reads every attention-output row of this stream anyway and leaves its
+                    # MX-FP8 image for the out-projection GEMM
+                    pq_ = self._preq_out(p, ao2, D, rows[s], D, "ao." + s, a_map=(S, off[s]))
                     self._down(p, X=ao2, ldx=D, M=rows[s], K=D, W_hi=lw.lora.A_hi, W_lo=lw.lora.A_lo, ldw=D, R=lw.lora.Rp,
                                Ut=bb["Uo." + s], ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0),
-                               rpb=rpb[s], x_map=(S, off[s]))
+                               rpb=rpb[s], x_map=(S, off[s]),
+                               xq=None if pq_ is None else (_ptr(pq_[0]), _ptr(pq_[1]), D, rows[s], 0))
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
                 if "y1" in bb:
                     kw.update(C2=bb["y1"][s], ldc2=D)
@@ -1423,6 +1429,11 @@ class _QwenPlan:
                     Vth, Vtl = VtQ[s]
                     Uth, Utl = bb["Uqkv." + s]
                     e3 = A["ext3"][s]
+                    # "mxfp8-fb": the three down projections together read every element of this stream's dqkv rows and leave
+                    # its MX-FP8 image (q, k, v column sections of one operand) for the qkv dX GEMM
+                    pq_ = None
+                    if i > 0 and all(w[s + ".qkv"][sec].lora is not None for sec in range(3)):
+                        pq_ = self._preq_out(p, dq2, 3 * D, rows[s], 3 * D, "dqkv." + s, a_map=(S, off[s]))
                     for sec in range(3):
                         lw = w[s + ".qkv"][sec]
                         if lw.lora is None:
@@ -1431,7 +1442,8 @@ class _QwenPlan:
                         sl = slice(sec * Rp, (sec + 1) * Rp)
                         self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=rows[s], K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo,
                                    ldw=lo.Bt_hi.stride(0), R=Rp, Ut=(Vth[sl], Vtl[sl]), ext=e3[:, sec * Kext:],
-                                   ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]), defer=dl)
+                                   ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]), defer=dl,
+                                   xq=None if pq_ is None else (_ptr(pq_[0]) + sec * D, _ptr(pq_[1]), 3 * D, rows[s], sec * D // 32))
                         self._grad(p, Vt=(Uth[sl], Utl[sl]), R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D,
                                    M=rows[s], K=D, G=lo.gB, g_sr=1, g_sc=lo.r, rpb=rpb[s], x_map=(S, off[s]), out_scale=lo.scale,
                                    defer=gl)

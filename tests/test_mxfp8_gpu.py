@@ -1,5 +1,6 @@
 """Low-precision trunk: MX-FP8 quantiser and block-scaled FP8 GEMM vs an fp8-emulating reference in plain PyTorch
 (torch.float8_e4m3fn + power-of-two block scales restated from the OCP MX specification)."""
+import ctypes as C_
 import math
 
 import pytest
@@ -461,3 +462,39 @@ def test_layernorm_kernels_emit_bit_identical_mxfp8_images():
         L.check(L.lib.qfx_ln_modulate_bwd_batch(b, 1, ops.stream_ptr()), "ln bwd")
         rq, rs = ops.quant_mxfp8(dyg)
         assert torch.equal(yq, rq) and torch.equal(ys.reshape(-1), rs.reshape(-1))
+
+
+def test_lora_down_emits_bit_identical_mxfp8_image_of_its_input():
+    """qfx_lora_down_args.xq: the rank-r down projection also writes the MX-FP8 image of the X it reads -- whole operand (attention
+    output) and column sections of a wider operand with a joint-buffer row remap (q / k / v sections of dqkv) -- equal to
+    qfx_quant_mxfp8 of the same rows; U / ext are unchanged by the option."""
+    from qflux_amd import _lib as L
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    D, R, T, S_i = 1024, 16, 24, 232
+    S = T + S_i
+    joint = torch.randn(2 * S, 3 * D, generator=g).to(BF).to(DEV)          # [B*S, 3D], image rows follow the text rows per sample
+    A = torch.randn(R, D, generator=g) * 0.05
+    a_hi = A.to(BF); a_lo = (A - a_hi.float()).to(BF)
+    a_hi, a_lo = a_hi.to(DEV), a_lo.to(DEV)
+    M = 2 * S_i
+    img = torch.cat([joint[b * S + T:(b + 1) * S] for b in range(2)])        # compact image rows
+    xq = torch.zeros(M, 3 * D, dtype=torch.uint8, device=DEV)
+    xs = torch.zeros(3 * D // 128, M, 4, dtype=torch.uint8, device=DEV)
+    outs = []
+    for with_q in (False, True):
+        ext = torch.zeros(M, 64, dtype=BF, device=DEV)
+        for sec in range(3):
+            a = L.LoraDownArgs()
+            a.X, a.ldx, a.M, a.K = joint[:, sec * D:].data_ptr(), 3 * D, M, D
+            a.W_hi, a.W_lo, a.ldw, a.R = a_hi.data_ptr(), a_lo.data_ptr(), D, R
+            a.ext, a.ld_ext, a.group_R, a.group_stride = ext.data_ptr(), 64, R, 0
+            a.rows_per_batch, a.x_batch_rows, a.x_row_off = S_i, S, T
+            if with_q:
+                a.xq, a.xs, a.ldxq, a.xs_rows, a.xq_kb0 = xq.data_ptr() + sec * D, xs.data_ptr(), 3 * D, M, sec * D // 32
+            L.check(L.lib.qfx_lora_down(C_.byref(a), ops.stream_ptr()), "down")
+        torch.cuda.synchronize()
+        outs.append(ext.clone())
+    assert torch.equal(outs[0], outs[1])
+    rq, rs = ops.quant_mxfp8(img.contiguous())
+    assert torch.equal(xq, rq) and torch.equal(xs.reshape(-1), rs.reshape(-1))
