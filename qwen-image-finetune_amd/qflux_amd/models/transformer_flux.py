@@ -353,9 +353,11 @@ class _FluxPlan(_QwenPlan):
         kext_m = 0
         for w in P["singles"]:
             b = dict(qkv=buf(B, S, 3 * D), sqk=buf(B, S, 2 * D), lse=buf(B, H, S_pad, dtype=F32, zero=True), h=buf(B * S, 4 * D))
-            if w["out"].lora is not None:
+            if w["out"].lora is not None or getattr(self.model, "_quant", None):
                 # adapter on proj_out: its input [attn | gelu(mlp)] is kept as ONE row-major buffer (attention and the GELU epilogue
-                # write straight into its two column ranges), so that u = cat A^T and dA = v^T cat are single rank-r launches
+                # write straight into its two column ranges), so that u = cat A^T and dA = v^T cat are single rank-r launches.
+                # MX-FP8 trunk: the same layout makes proj_out ONE contraction over K = 5D, which the block-scaled kernel takes
+                # (its two-segment form -- different operands per segment -- exists in bf16 only)
                 b["cat"] = buf(B * S, 5 * D)
                 b["ao"] = b["cat"][:, :D]
             else:

@@ -267,8 +267,8 @@ def test_gemm_mxfp8_grouped_persistent_all_epilogues():
 
 
 def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
-    """FLUX double + single block of width 1024 with the MX-FP8 trunk (forward + dX GEMMs): the single block's two-segment
-    proj_out contraction stays bf16 in the HIP path, so the oracle keeps that linear un-quantised too."""
+    """FLUX double + single block of width 1024 with the MX-FP8 trunk (forward + dX GEMMs): the single block's proj_out runs as one
+    MX-FP8 contraction over the kept [attn | gelu(mlp)] buffer; the single block's backward stays bf16 (oracle: per-module flag)."""
     import os
     from oracle import flux_dit as FO
     from oracle import mxfp8 as QX
@@ -318,9 +318,8 @@ def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
     plan = list(hip._plans.values())[0]
     e_bf = rel(plan.A["out"].view(B, -1, 64)[:, :S_t].float().cpu(), pred_b)                     # bf16 HIP path vs bf16 oracle
     step.zero_grad()
-    nq = QX.quantize_oracle(oracle, predicate=lambda name, m: QX.eligible(name, m) and not (name.startswith("single_") and "proj_out" in name),
-                            backward=True)
-    assert nq == 12 + 1 + 4      # double block linears, context_embedder, single-block q/k/v + proj_mlp
+    nq = QX.quantize_oracle(oracle, backward=True)
+    assert nq == 12 + 1 + 5      # double block linears, context_embedder, single-block q/k/v + proj_mlp + proj_out (K = 5D, one contraction)
     loss_o, pred_o = FO.flux_compute_loss(oracle, emb_o, noise, t, BF, return_pred=True)
     loss_o.float().backward()
     gap = rel(pred_o, pred_b)
@@ -339,7 +338,7 @@ def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
             n_fp8 += 1
         elif c[0] is not None and c[0].__name__ == "qfx_gemm_mxfp8_grouped":
             n_fp8 += c[1][1]
-    assert n_fp8 == nq       # the same 17 linears run on the scaled MFMA in the HIP forward
+    assert n_fp8 == nq       # the same 18 linears run on the scaled MFMA in the HIP forward
     print(f"flux mxfp8-fb: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, worst LoRA grad rel {gw:.4f}")
     # width-1024 weights of std 0.03 make this a noisy net: the fp8 trunk moves the prediction by `gap` (8 % of its maximum, the
     # bf16 paths agree to 1 %).  The HIP path must sit well inside that distance from the fp8-emulating oracle -- element flips at
