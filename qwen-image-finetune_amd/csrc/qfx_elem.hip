@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
 // grid = (row chunks of 32 per sample, B); block = 4 waves; a wave owns 8 consecutive rows (one row at a time in registers, as in
 // the LayerNorm kernels), accumulates its column sums in registers, the four waves combine in LDS and the block issues ONE fp32
 // atomic per column and output.  HBM-bound (reads dy, x [, dxo, y] once).
+constexpr int MG_RPW = 2;
 template <int NP>
 __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a) {
   __shared__ float sacc[3][NP * 512];
@@ -237,13 +238,25 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
   for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { as[p][i] = 0.f; ac[p][i] = 0.f; ag[p][i] = 0.f; }
-  const int r_lo = blockIdx.x * 32 + w * 8;
-  for (int rr = 0; rr < 8; ++rr) {
+  // MG_RPW rows per wave, 4 * MG_RPW per block: with 8 rows per wave a 2048-row stream was 64 blocks (a quarter of the CUs), each
+  // wave a chain of 8 x 3 dependent memory round trips -- 120 us per launch, 29 ms of an all-linear step.  Two rows per wave fill
+  // the chip four times over (one LDS-combined atomic per column and block: 4x the atomics, still < 10 us of them), and all four
+  // streams of a row (x, dy, dxo, y) are requested together, packed.
+  const int r_lo = blockIdx.x * (4 * MG_RPW) + w * MG_RPW;
+  for (int rr = 0; rr < MG_RPW; ++rr) {
     const int rl = r_lo + rr;
     if (rl >= a.rows_per_batch) break;            // wave-uniform
     const int64_t row = (int64_t)b * a.rows_per_batch + rl;
     if (row >= a.rows) break;
     if (a.row_mask != nullptr && a.row_mask[row] == 0.f) continue;
+    u32x4 gxp[NP], gyp[NP];
+    if (has_gate) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int col = (p * 64 + lane) * 8;
+        if (col < D) { gxp[p] = *(const u32x4*)(a.dxo + row * a.ld_dxo + col); gyp[p] = *(const u32x4*)(a.y + row * a.ld_y + col); }
+      }
+    }
     float xv[NP][8], dv[NP][8];
     float s = 0.f;
 #pragma unroll
@@ -277,11 +290,11 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
           ac[p][i] += dv[p][i] * rbf((xv[p][i] - mean) * rstd);
         }
         if (has_gate) {
-          float gx[8], gy[8];
-          ld8(a.dxo + row * a.ld_dxo + col, gx);
-          ld8(a.y + row * a.ld_y + col, gy);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ag[p][i] += gx[i] * gy[i];
+          for (int i = 0; i < 4; ++i) {
+            ag[p][2 * i] += __uint_as_float(gxp[p][i] << 16) * __uint_as_float(gyp[p][i] << 16);
+            ag[p][2 * i + 1] += __uint_as_float(gxp[p][i] & 0xffff0000u) * __uint_as_float(gyp[p][i] & 0xffff0000u);
+          }
         }
       }
     }
@@ -858,7 +871,7 @@ extern "C" int qfx_mod_grad(const qfx_mod_grad_args* a, void* stream) {
   if ((a->dgate != nullptr) != (a->dxo != nullptr) || (a->dgate != nullptr) != (a->y != nullptr)) return QFX_EINVAL;
   if (a->dgate && ((a->ld_dxo % 8) || (a->ld_y % 8))) return QFX_EINVAL;
   const int B = (a->rows + a->rows_per_batch - 1) / a->rows_per_batch;
-  dim3 grid((a->rows_per_batch + 31) / 32, B);
+  dim3 grid((a->rows_per_batch + 4 * MG_RPW - 1) / (4 * MG_RPW), B);
   hipStream_t s = (hipStream_t)stream;
   switch ((a->D + 511) / 512) {
     case 1: hipLaunchKernelGGL(mod_grad_kernel<1>, grid, dim3(256), 0, s, *a); break;
