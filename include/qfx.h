@@ -252,6 +252,12 @@ int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const uint16_t* con
                  int32_t nmat, int32_t N, int32_t apply_silu, uint16_t* out, void* stream);
 /* W, bias: DEVICE arrays of nmat device pointers. apply_silu=0 gives a plain small-batch Linear
  * (timestep_embedder.linear_1). B <= 8. */
+/* Backward of the same frozen linears w.r.t. their (shared) input, needed when the conditioning head carries adapters
+ * (target_modules "all-linear", configs/example_with_sampling.yaml:9): out[b, k] (fp32 [B, K], zeroed by the caller) +=
+ * sum_mat sum_n dy[mat, b, n] * W_mat[n, k], dy bf16 [nmat, B, N] -- what autograd computes as dy @ W per module and sums.
+ * One streaming pass over the weights (two passes per pair of samples beyond B = 2).  K <= 3072, K % 8 == 0. */
+int qfx_mod_gemv_t(const uint16_t* dy, int32_t B, int32_t N, int32_t K, const uint16_t* const* W, int32_t nmat, float* out,
+                   void* stream);
 
 /* ---- sinusoidal timestep projection (diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0, scale);
  * transformer_qwenimage.py:147,151-152,623-624): t is first rounded to bf16 (timestep.to(bf16)),

@@ -233,11 +233,6 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
   const bool has_gate = a.dgate != nullptr;
   for (int i = threadIdx.x; i < 3 * NP * 512; i += 256) (&sacc[0][0])[i] = 0.f;
   __syncthreads();
-  float as[NP][8], ac[NP][8], ag[NP][8];
-#pragma unroll
-  for (int p = 0; p < NP; ++p)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { as[p][i] = 0.f; ac[p][i] = 0.f; ag[p][i] = 0.f; }
   // MG_RPW rows per wave, 4 * MG_RPW per block: with 8 rows per wave a 2048-row stream was 64 blocks (a quarter of the CUs), each
   // wave a chain of 8 x 3 dependent memory round trips -- 120 us per launch, 29 ms of an all-linear step.  Two rows per wave fill
   // the chip four times over (one LDS-combined atomic per column and block: 4x the atomics, still < 10 us of them), and all four
@@ -284,30 +279,20 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
     for (int p = 0; p < NP; ++p) {
       const int col = (p * 64 + lane) * 8;
       if (col < D) {
+        // (two rows per wave: the row's terms go straight into the block's LDS sums -- register accumulators cost 144 VGPRs and
+        // with them the kernel ran one wave per SIMD)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          as[p][i] += dv[p][i];
-          ac[p][i] += dv[p][i] * rbf((xv[p][i] - mean) * rstd);
+          atomicAdd(&sacc[0][col + i], dv[p][i]);
+          atomicAdd(&sacc[1][col + i], dv[p][i] * rbf((xv[p][i] - mean) * rstd));
         }
         if (has_gate) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            ag[p][2 * i] += __uint_as_float(gxp[p][i] << 16) * __uint_as_float(gyp[p][i] << 16);
-            ag[p][2 * i + 1] += __uint_as_float(gxp[p][i] & 0xffff0000u) * __uint_as_float(gyp[p][i] & 0xffff0000u);
+            atomicAdd(&sacc[2][col + 2 * i], __uint_as_float(gxp[p][i] << 16) * __uint_as_float(gyp[p][i] << 16));
+            atomicAdd(&sacc[2][col + 2 * i + 1], __uint_as_float(gxp[p][i] & 0xffff0000u) * __uint_as_float(gyp[p][i] & 0xffff0000u));
           }
         }
-      }
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int col = (p * 64 + lane) * 8;
-    if (col < D) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        atomicAdd(&sacc[0][col + i], as[p][i]);
-        atomicAdd(&sacc[1][col + i], ac[p][i]);
-        if (has_gate) atomicAdd(&sacc[2][col + i], ag[p][i]);
       }
     }
   }
@@ -425,6 +410,81 @@ __global__ __launch_bounds__(256) void mod_gemv_kernel(const bf16_t* __restrict_
       }
     }
   }
+}
+
+// ---------------------------------------------------------------- transposed modulation GEMV (backward of the frozen AdaLN linears)
+// out[b, k] += sum_mat sum_n dy[mat, b, n] * W_mat[n, k]: d(silu(temb)) through the frozen base weights of every modulation linear,
+// needed when the conditioning head carries adapters.  One pass over the same 13.6 GB as qfx_mod_gemv: persistent blocks stride
+// over (matrix, 4-row group) items, a wave owns one whole weight row at a time (6 KB contiguous) and keeps the [NB, K] partial sums
+// in registers (lane l: columns 8l + 512p); four row loads in flight per wave; one LDS combine and one fp32 atomic per (b, k) and
+// block at the end.
+template <int NB, int NP>
+__global__ __launch_bounds__(256) void mod_gemv_t_kernel(const bf16_t* __restrict__ dy, int B, int b0, int N, int K,
+                                                         const bf16_t* const* __restrict__ Ws, int nmat, float* __restrict__ out) {
+  __shared__ float sacc[NB][NP * 512];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < NB * NP * 512; i += 256) (&sacc[0][0])[i] = 0.f;
+  __syncthreads();
+  float acc[NB][NP][8];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[b][p][i] = 0.f;
+  const int groups_per_mat = (N + 3) / 4;
+  const int64_t nitems = (int64_t)nmat * groups_per_mat;
+  // wave-granular grid stride: item = (matrix, group of 4 consecutive rows); the 4 rows are 4 independent loads in flight
+  for (int64_t it = (int64_t)blockIdx.x * 4 + w; it < nitems; it += (int64_t)gridDim.x * 4) {
+    const int mat = (int)(it / groups_per_mat);
+    const int n0 = (int)(it % groups_per_mat) * 4;
+    const bf16_t* W = Ws[mat];
+    u32x4 wv[4][NP];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + r < N ? n0 + r : N - 1;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int col = (p * 64 + lane) * 8;
+        if (col < K) wv[r][p] = *(const u32x4*)(W + (int64_t)n * K + col);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n0 + r < N) {      // wave-uniform
+        float g[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) g[b] = (b0 + b < B) ? bf2f(dy[((int64_t)mat * B + b0 + b) * N + n0 + r]) : 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const int col = (p * 64 + lane) * 8;
+          if (col < K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float w0 = __uint_as_float(wv[r][p][i] << 16), w1 = __uint_as_float(wv[r][p][i] & 0xffff0000u);
+#pragma unroll
+              for (int b = 0; b < NB; ++b) { acc[b][p][2 * i] = fmaf(g[b], w0, acc[b][p][2 * i]); acc[b][p][2 * i + 1] = fmaf(g[b], w1, acc[b][p][2 * i + 1]); }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&sacc[b][col + i], acc[b][p][i]);
+      }
+    }
+  __syncthreads();
+  for (int c = tid; c < K; c += 256)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (b0 + b < B) unsafeAtomicAdd(out + (int64_t)(b0 + b) * K + c, sacc[b][c]);
 }
 
 // ---------------------------------------------------------------- QK RMSNorm + RoPE (in place on qkv)
@@ -912,6 +972,26 @@ extern "C" int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const ui
   if (lds > 64 * 1024) return QFX_EUNSUPPORTED;
   hipLaunchKernelGGL(mod_gemv_kernel, dim3((N + 15) / 16, nmat), dim3(256), lds, (hipStream_t)stream, temb, B, K, W, bias, N,
                      apply_silu, out);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_mod_gemv_t(const uint16_t* dy, int32_t B, int32_t N, int32_t K, const uint16_t* const* W, int32_t nmat,
+                              float* out, void* stream) {
+  if (!dy || !W || !out || B <= 0 || B > 8 || N <= 0 || K <= 0 || (K % 8) || K > 3072 || nmat <= 0) return QFX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t items = (int64_t)nmat * ((N + 3) / 4);
+  int grid = (int)((items + 3) / 4);
+  if (grid > 4 * 256) grid = 4 * 256;   // 4 blocks per CU (256 CUs)
+  const int np = (K + 511) / 512;
+  for (int b0 = 0; b0 < B; b0 += 2) {   // two samples' partial sums per pass over the weights (registers); B <= 2 is one pass
+    const bool two = b0 + 1 < B;
+#define QFX_GT(NB_, NP_) hipLaunchKernelGGL((mod_gemv_t_kernel<NB_, NP_>), dim3(grid), dim3(256), 0, s, dy, B, b0, N, K, W, nmat, out)
+    if (np <= 2) { if (two) QFX_GT(2, 2); else QFX_GT(1, 2); }
+    else if (np <= 4) { if (two) QFX_GT(2, 4); else QFX_GT(1, 4); }
+    else { if (two) QFX_GT(2, 6); else QFX_GT(1, 6); }
+#undef QFX_GT
+  }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -153,6 +153,7 @@ SYMBOLS = {
     "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "qfx_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "qfx_mod_gemv_t": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "qfx_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f, _f, _vp, _vp]),
     "qfx_add3_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "qfx_qk_norm_rope_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _i64, _vp]),

@@ -167,6 +167,28 @@ def mod_gemv(temb, weights, biases, apply_silu=True):
     return out
 
 
+def mod_gemv_tables(temb, wt, bt, nmat, N, apply_silu=True):
+    """qfx_mod_gemv with prepared device pointer tables (wt / bt: int64 tensors of nmat device pointers)."""
+    B, K = temb.shape
+    out = torch.empty(nmat, B, N, dtype=BF, device=temb.device)
+    L.check(lib.qfx_mod_gemv(_p(temb), B, K, _p(wt), _p(bt), nmat, N, int(apply_silu), _p(out), stream_ptr()), "qfx_mod_gemv")
+    return out
+
+
+def mod_gemv_t(dy, weights=None, out=None, table=None):
+    """out[b, k] += sum_mat dy[mat, b, :] @ W_mat  (fp32 [B, K]); dy bf16 [nmat, B, N] contiguous; weights: list of [N, K] bf16
+    tensors, or table = (prepared device pointer table, K)."""
+    nmat, B, N = dy.shape
+    if table is None:
+        K = weights[0].shape[1]
+        wt = ptr_table(weights, dy.device)
+    else:
+        wt, K = table
+    out = torch.zeros(B, K, dtype=torch.float32, device=dy.device) if out is None else out
+    L.check(lib.qfx_mod_gemv_t(_p(dy), B, N, K, _p(wt), nmat, _p(out), stream_ptr()), "qfx_mod_gemv_t")
+    return out
+
+
 def timestep_embed(t, dim=256, scale=1000.0, pre_scale=1.0):
     out = torch.empty(t.shape[0], dim, dtype=BF, device=t.device)
     L.check(lib.qfx_timestep_embed(_p(t.float().contiguous()), t.shape[0], dim, scale, pre_scale, _p(out), stream_ptr()),

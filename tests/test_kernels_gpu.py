@@ -434,6 +434,19 @@ def test_mod_gemv_and_timestep():
     check("timestep_embed", ops.timestep_embed(t.to(DEV)), ref, 2e-2)
 
 
+@pytest.mark.parametrize("Bn,K,N,nmat", [(1, 3072, 1000, 5), (2, 1024, 768, 3), (3, 512, 130, 2)])
+def test_mod_gemv_transposed(Bn, K, N, nmat):
+    """qfx_mod_gemv_t: sum over matrices of dy[mat] @ W_mat (fp32 accumulation) -- the backward of qfx_mod_gemv w.r.t. its input."""
+    ops = _ops()
+    Ws = [randn(N, K, seed=30 + i, scale=0.05).to(BF) for i in range(nmat)]
+    dy = randn(nmat, Bn, N, seed=7).to(BF)
+    ref = sum(dy[i].float() @ Ws[i].float() for i in range(nmat))
+    out = ops.mod_gemv_t(dy.to(DEV), [w.to(DEV) for w in Ws])
+    check(f"mod_gemv_t_{Bn}_{K}", out, ref, 2e-4)
+    out2 = ops.mod_gemv_t(dy.to(DEV), [w.to(DEV) for w in Ws], out=out.clone())      # accumulates into `out`
+    check(f"mod_gemv_t_acc_{Bn}_{K}", out2, 2 * ref, 2e-4)
+
+
 @pytest.mark.parametrize("dh", [64, 128])
 def test_qk_norm_rope_fwd_bwd(dh):
     from oracle.qwen_dit import OracleRMSNorm, apply_rope_complex, qwen_rope_tables
