@@ -231,12 +231,15 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
   const int b = blockIdx.y;
   const int D = a.D;
   const bool has_gate = a.dgate != nullptr;
-  for (int i = threadIdx.x; i < 3 * NP * 512; i += 256) (&sacc[0][0])[i] = 0.f;
-  __syncthreads();
+  float as[NP][8], ac[NP][8], ag[NP][8];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { as[p][i] = 0.f; ac[p][i] = 0.f; ag[p][i] = 0.f; }
   // MG_RPW rows per wave, 4 * MG_RPW per block: with 8 rows per wave a 2048-row stream was 64 blocks (a quarter of the CUs), each
-  // wave a chain of 8 x 3 dependent memory round trips -- 120 us per launch, 29 ms of an all-linear step.  Two rows per wave fill
-  // the chip four times over (one LDS-combined atomic per column and block: 4x the atomics, still < 10 us of them), and all four
-  // streams of a row (x, dy, dxo, y) are requested together, packed.
+  // wave a chain of 8 x 3 dependent memory round trips.  Two rows per wave fill the chip four times over (one global atomic per
+  // column and block: 4x the atomics, still < 10 us of them), and all four streams of a row (x, dy, dxo, y) are requested
+  // together, packed.  (114 -> 45 us per launch with the plain LDS combine below; 29 -> 10 ms of an all-linear step.)
   const int r_lo = blockIdx.x * (4 * MG_RPW) + w * MG_RPW;
   for (int rr = 0; rr < MG_RPW; ++rr) {
     const int rl = r_lo + rr;
@@ -283,24 +286,46 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
         // with them the kernel ran one wave per SIMD)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          atomicAdd(&sacc[0][col + i], dv[p][i]);
-          atomicAdd(&sacc[1][col + i], dv[p][i] * rbf((xv[p][i] - mean) * rstd));
+          as[p][i] += dv[p][i];
+          ac[p][i] += dv[p][i] * rbf((xv[p][i] - mean) * rstd);
         }
         if (has_gate) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            atomicAdd(&sacc[2][col + 2 * i], __uint_as_float(gxp[p][i] << 16) * __uint_as_float(gyp[p][i] << 16));
-            atomicAdd(&sacc[2][col + 2 * i + 1], __uint_as_float(gxp[p][i] & 0xffff0000u) * __uint_as_float(gyp[p][i] & 0xffff0000u));
+            ag[p][2 * i] += __uint_as_float(gxp[p][i] << 16) * __uint_as_float(gyp[p][i] << 16);
+            ag[p][2 * i + 1] += __uint_as_float(gxp[p][i] & 0xffff0000u) * __uint_as_float(gyp[p][i] & 0xffff0000u);
           }
         }
       }
     }
   }
-  __syncthreads();
+  // the four waves fold their register sums into the block's LDS sums one after the other with PLAIN reads / writes (an LDS float
+  // atomic costs ~600 cycles per wave instruction here, conflict-free or not: 288 of them were 80 of the kernel's 110 us).
+  // Element-major slots -- column (p*64 + lane)*8 + i at i*(NP*64) + p*64 + lane -- keep the 64 lanes on 64 banks.
+#pragma unroll 1
+  for (int turn = 0; turn < 4; ++turn) {
+    if (w == turn) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int sl = p * 64 + lane;
+        if (sl * 8 < D) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int o = i * (NP * 64) + sl;
+            sacc[0][o] = (turn ? sacc[0][o] : 0.f) + as[p][i];
+            sacc[1][o] = (turn ? sacc[1][o] : 0.f) + ac[p][i];
+            if (has_gate) sacc[2][o] = (turn ? sacc[2][o] : 0.f) + ag[p][i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
   for (int c = threadIdx.x; c < D; c += 256) {
-    unsafeAtomicAdd(a.dshift + (int64_t)b * a.out_bstride + c, sacc[0][c]);
-    unsafeAtomicAdd(a.dscale + (int64_t)b * a.out_bstride + c, sacc[1][c]);
-    if (has_gate) unsafeAtomicAdd(a.dgate + (int64_t)b * a.out_bstride + c, sacc[2][c]);
+    const int slot = (c & 7) * (NP * 64) + (c >> 3);
+    unsafeAtomicAdd(a.dshift + (int64_t)b * a.out_bstride + c, sacc[0][slot]);
+    unsafeAtomicAdd(a.dscale + (int64_t)b * a.out_bstride + c, sacc[1][slot]);
+    if (has_gate) unsafeAtomicAdd(a.dgate + (int64_t)b * a.out_bstride + c, sacc[2][slot]);
   }
 }
 

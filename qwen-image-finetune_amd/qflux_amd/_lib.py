@@ -86,8 +86,7 @@ class ModGradArgs(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("ld_dy", C.c_int64), ("x", C.c_void_p), ("ld_x", C.c_int64),
                 ("dxo", C.c_void_p), ("ld_dxo", C.c_int64), ("y", C.c_void_p), ("ld_y", C.c_int64),
                 ("dshift", C.c_void_p), ("dscale", C.c_void_p), ("dgate", C.c_void_p), ("out_bstride", C.c_int64),
-                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float),
-                ("dygq", C.c_void_p), ("dygs", C.c_void_p), ("lddygq", C.c_int64), ("dygs_rows", C.c_int32), ("pad_", C.c_int32)]
+                ("row_mask", C.c_void_p), ("rows", C.c_int32), ("D", C.c_int32), ("rows_per_batch", C.c_int32), ("eps", C.c_float)]
 
 
 class LoraPackArgs(C.Structure):
