@@ -1222,6 +1222,7 @@ class _QwenPlan:
             # the text stream of the last block never reaches the output (:661-663): dead compute, skipped
             live = [(s, sidx) for s, sidx in STREAMS if not (last and s == "txt")]
             groups = []
+            dfo = []
             for s, sidx in live:
                 lw = w[s + ".o"]
                 kw = {}
@@ -1231,7 +1232,7 @@ class _QwenPlan:
                     pq_ = self._preq_out(p, ao2, D, rows[s], D, "ao." + s, a_map=(S, off[s]))
                     self._down(p, X=ao2, ldx=D, M=rows[s], K=D, W_hi=lw.lora.A_hi, W_lo=lw.lora.A_lo, ldw=D, R=lw.lora.Rp,
                                Ut=bb["Uo." + s], ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0),
-                               rpb=rpb[s], x_map=(S, off[s]),
+                               rpb=rpb[s], x_map=(S, off[s]), defer=dfo,
                                xq=None if pq_ is None else (_ptr(pq_[0]), _ptr(pq_[1]), D, rows[s], 0))
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
                 if "y1" in bb:
@@ -1239,6 +1240,7 @@ class _QwenPlan:
                 groups.append(self._gargs(A1=ao2, lda1=D, B1=lw.W, K1=D, M=rows[s], N=D, C_=bb["x1"][s], ldc=D, bias=lw.b,
                                           epi=L.EPI_GATE_RES, aux=x_in[s], ldaux=D, gate=mods[s][:, 2 * D:3 * D], gate_bs=6 * D,
                                           rpb=rpb[s], a_map=(S, off[s]), **kw))
+            self._flush_batch(p, dfo, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             groups = []
             # feed-forward (+ LoRA on net.0.proj / net.2: the adapter's input is then kept per block instead of in scratch)
@@ -1258,15 +1260,17 @@ class _QwenPlan:
                     return {}
                 lo, e1 = lw.lora, A["ext1"][s]
                 self._down(p, X=X, ldx=ldx, M=rows[s], K=lw.K, W_hi=lo.A_hi, W_lo=lo.A_lo, ldw=lo.A_hi.stride(0), R=lo.Rp,
-                           Ut=bb[ukey + s], ext=e1, ld_ext=e1.stride(0))
+                           Ut=bb[ukey + s], ext=e1, ld_ext=e1.stride(0), defer=dfw)
                 return dict(A2=e1, lda2=e1.stride(0), B2=lo.We, ldb2=lo.We.stride(0), K2=lo.Kext)
 
+            dfw = []      # the image- and text-stream down projections of one site go out as ONE batched launch
             for s, sidx in live:
                 f1 = w[s + ".fc1"]
                 kw = lora_ext(s, f1, xm2[s], D, "Uf1.")
                 groups.append(self._gargs(A1=xm2[s], lda1=D, B1=f1.W, K1=D, M=rows[s], N=4 * D, C_=bb["h"][s], ldc=4 * D,
                                           bias=f1.b, epi=L.EPI_GELU, C2=gact[s], ldc2=4 * D, **kw))
                 groups[-1]._next = (gact[s], 4 * D, w[s + ".fc2"].lora is not None)    # gelu(h) feeds fc2 (and its adapter's dA, if any)
+            self._flush_batch(p, dfw, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             groups = []
             for s, sidx in live:
@@ -1277,6 +1281,7 @@ class _QwenPlan:
                 groups.append(self._gargs(A1=gact[s], lda1=4 * D, B1=f2.W, K1=4 * D, M=rows[s], N=D, C_=x_out[s][0], ldc=D,
                                           bias=f2.b, epi=L.EPI_GATE_RES, aux=bb["x1"][s], ldaux=D, gate=mods[s][:, 5 * D:6 * D],
                                           gate_bs=6 * D, rpb=rpb[s], c_map=x_out[s][1], aux_unmapped=1, row_mask=self.rmask[s], **kw))
+            self._flush_batch(p, dfw, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
 
     # ------------------------------------------------------------------ backward program
@@ -1356,25 +1361,28 @@ class _QwenPlan:
                 lo, e1 = lw.lora, A["ext1"][s]
                 Vt = (A[vkey][s][0][:lo.Rp], A[vkey][s][1][:lo.Rp])
                 self._down(p, X=dY, ldx=ldy, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp,
-                           Ut=Vt, ext=e1, ld_ext=e1.stride(0))
+                           Ut=Vt, ext=e1, ld_ext=e1.stride(0), defer=dbw)
                 self._grad(p, Vt=bb[ukey + s], R=lo.Rp, r_valid=lo.r, X=dY, ldx=ldy, M=rows[s], K=lw.N, G=lo.gB, g_sr=1, g_sc=lo.r,
                            out_scale=lo.scale, defer=ge if early else gl)
                 self._grad(p, Vt=Vt, R=lo.Rp, r_valid=lo.r, X=Xin, ldx=ldxin, M=rows[s], K=lw.K, G=lo.gA, g_sr=lw.K, g_sc=1, defer=gl)
                 return dict(A2=e1, lda2=e1.stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
 
             groups = []
+            dbw = []      # both streams' v = dY B of a site in ONE batched launch
             for s, _ in live:
                 f2 = w[s + ".fc2"]
                 kw = lora_bwd(s, f2, A["dyg2"][s], D, bb.get("g." + s), 4 * D, "Uf2.", "VtF2", early=True)
                 groups.append(self._gargs(A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s],
                                           ldc=4 * D, epi=L.EPI_DGELU, aux=bb["h"][s], ldaux=4 * D, **kw))
                 groups[-1]._next = (A["dh"][s], 4 * D, w[s + ".fc1"].lora is not None)   # dh feeds fc1's dX GEMM (and its adapter's v / dB)
+            self._flush_batch(p, dbw, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             groups = []
             for s, _ in live:
                 f1 = w[s + ".fc1"]
                 kw = lora_bwd(s, f1, A["dh"][s], 4 * D, bb.get("xm2." + s), D, "Uf1.", "VtF1", early=False)
                 groups.append(self._gargs(A1=A["dh"][s], lda1=4 * D, B1=f1.WT, K1=4 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D, **kw))
+            self._flush_batch(p, dbw, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             if ge:
                 self._flush_batch(p, ge, L.LoraGradArgs, lib.qfx_lora_grad_batch)
@@ -1393,6 +1401,7 @@ class _QwenPlan:
                 if pq_ is not None:
                     ln.dygq, ln.dygs, ln.lddygq, ln.dygs_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
             self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
+            dbo = []
             for s, sidx in live:
                 mod = mods[s]
                 # attention out-projection backward (+ LoRA)
@@ -1402,7 +1411,7 @@ class _QwenPlan:
                     lo = lw.lora
                     Vt = (VtO[s][0][:lo.Rp], VtO[s][1][:lo.Rp])
                     self._down(p, X=dyg1[s], ldx=D, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0),
-                               R=lo.Rp, Ut=Vt, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0))
+                               R=lo.Rp, Ut=Vt, ext=A["ext1"][s], ld_ext=A["ext1"][s].stride(0), defer=dbo)
                     self._grad(p, Vt=bb["Uo." + s], R=lo.Rp, r_valid=lo.r, X=dyg1[s], ldx=D, M=rows[s], K=lw.N,
                                G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale, defer=gl)
                     self._grad(p, Vt=Vt, R=lo.Rp, r_valid=lo.r, X=ao2, ldx=D, M=rows[s], K=lw.K, G=lo.gA,
@@ -1410,6 +1419,7 @@ class _QwenPlan:
                     kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lo.WeT, ldb2=lo.WeT.stride(0), K2=lo.Kext)
                 groups.append(self._gargs(A1=dyg1[s], lda1=D, B1=lw.WT, K1=lw.N, M=rows[s], N=lw.K, C_=dao2, ldc=D, rpb=rpb[s],
                                           c_map=(S, off[s]), **kw))
+            self._flush_batch(p, dbo, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             # ---- attention backward
             q2 = bb["qkv"].view(B * S, 3 * D)
