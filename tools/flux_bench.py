@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--double", type=int, default=19); ap.add_argument("--single", type=int, default=38)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--res", type=int, default=512); ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--targets", default="", help='"all-linear", or the regex of configs/face_seg_flux_kontext_fp16.yaml:11 with "regex"')
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
@@ -21,7 +22,14 @@ with torch.device(dev):
 with torch.no_grad():
     for n, p in dit.named_parameters():
         p.normal_(0.0, 0.02) if p.ndim == 2 else (p.fill_(1.0) if "norm" in n and p.ndim == 1 and "linear" not in n else p.normal_(0.0, 0.02))
-dit.add_adapter(LoraConfig(r=16, lora_alpha=16), "default", generator=torch.Generator().manual_seed(0))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REGEX = None
+if a.targets == "regex":      # the reference's shipped broad regex is test data: tests/test_flux_gpu.py::_REFERENCE_REGEX
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tfg", os.path.join(ROOT, "tests", "test_flux_gpu.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); REGEX = m._REFERENCE_REGEX
+kw = {} if not a.targets else dict(target_modules=("all-linear" if a.targets == "all-linear" else REGEX))
+dit.add_adapter(LoraConfig(r=16, lora_alpha=16, **kw), "default", generator=torch.Generator().manual_seed(0))
 step = FluxKontextTrainStep(dit)
 side = a.res // 16; S_t = side * side; T = 512; B = a.batch
 ctl = prepare_latent_image_ids(side, side); ctl[:, 0] = 1
