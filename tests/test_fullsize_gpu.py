@@ -146,3 +146,58 @@ def test_backward_is_linear_in_the_loss_scale_and_samples_are_independent():
     assert abs(l1 - l2) < 1e-5 * abs(l1) and lin < 1e-5    # the loss reduction uses fp32 atomics: order varies
     assert torch.equal(outA.flip(0), outB)
     assert abs(l3 - l1) < 1e-6 * abs(l1) + 1e-7 and ((g3 - g1).abs().max() / g1.abs().max()).item() < 1e-4
+
+
+def test_one_full_width_block_all_linear_vs_oracle():
+    """target_modules="all-linear" at the model's full WIDTH (one block, short sequences so that the CPU oracle finishes in
+    seconds): every Linear adapted -- the D = 3072 instantiations of the modulation-gradient kernel, the conditioning-head banks
+    (N = 18432 / 6144 modulation linears on qfx_mod_gemv / qfx_mod_gemv_t), feed-forward and embedder adapters -- against the bf16
+    oracle, tensor by tensor."""
+    from oracle import qwen_dit as O
+    from parity_util import _grad_tol_factor, relmax
+    from qflux_amd.models import QwenImageTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import QwenLoraTrainStep
+    with torch.device(DEV):
+        hip = QwenImageTransformer2DModel(num_layers=1, **FULL)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if p.ndim == 1 and "norm" in n:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=DEV) * 0.02).to(p.dtype))
+    hip.add_adapter(LoraConfig(r=16, lora_alpha=16, target_modules="all-linear"), "default", generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(7)).to(p.device) * 1e-2)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    emb, noise, u = _emb(B=2, side=16, T=64)
+    oracle = O.OracleQwenDiT(num_layers=1, **FULL)
+    O.add_lora(oracle, r=16, lora_alpha=16, adapter_name="default", target_modules="all-linear")
+    oracle.load_state_dict({k: v.float().cpu() for k, v in hip.state_dict().items()}, strict=True)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    loss_o, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+    loss_o.float().backward()
+    step = QwenLoraTrainStep(hip)
+    loss_h = step.forward_backward(emb, noise=noise, u=u).item()
+    plan = list(hip._plans.values())[0]
+    pred_h = plan.A["out"].view(2, -1, 64)[:, : pred_o.shape[1]]
+    e = relmax(pred_h, pred_o)
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    worst, wname, n_cmp = 0.0, None, 0
+    for n, p in hip.named_parameters():
+        if "lora" not in n:
+            continue
+        if og[n] is None:
+            assert p.grad.abs().max().item() == 0.0, n
+            continue
+        r = relmax(p.grad, og[n]) / _grad_tol_factor(n)
+        n_cmp += 1
+        if r > worst:
+            worst, wname = r, n
+    print(f"full-width all-linear block: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, worst grad rel {worst:.4f} ({wname}), {n_cmp} tensors")
+    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 4e-2 and worst < 4e-2 and n_cmp >= 30      # (the single block is also the LAST one: its text tail is dead compute)
