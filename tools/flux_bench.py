@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--double", type=int, default=19); ap.add_argument("--single", type=int, default=38)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--res", type=int, default=512); ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--quant", default="", help='MX-FP8 trunk mode: "mxfp8" | "mxfp8-fb"')
 ap.add_argument("--targets", default="", help='"all-linear", or the regex of configs/face_seg_flux_kontext_fp16.yaml:11 with "regex"')
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -30,6 +31,8 @@ if a.targets == "regex":      # the reference's shipped broad regex is test data
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); REGEX = m._REFERENCE_REGEX
 kw = {} if not a.targets else dict(target_modules=("all-linear" if a.targets == "all-linear" else REGEX))
 dit.add_adapter(LoraConfig(r=16, lora_alpha=16, **kw), "default", generator=torch.Generator().manual_seed(0))
+if a.quant:
+    dit.quantize_trunk(a.quant)
 step = FluxKontextTrainStep(dit)
 side = a.res // 16; S_t = side * side; T = 512; B = a.batch
 ctl = prepare_latent_image_ids(side, side); ctl[:, 0] = 1
@@ -44,6 +47,6 @@ S = T + 2 * S_t; D = 3072
 f_lin = 2 * (a.double * S * 12 * D * D + a.single * S * (3 * D * D + 4 * D * D + 5 * D * D))
 f_attn = 2 * (a.double + a.single) * 2 * S * S * D
 tf = (2 * f_lin + 3.5 * f_attn) * B / 1e12
-print(json.dumps({"model": f"FLUX-Kontext-sized DiT {a.double}+{a.single} blocks", "images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 2),
+print(json.dumps({"model": f"FLUX-Kontext-sized DiT {a.double}+{a.single} blocks", "targets": a.targets or "default", "trunk": a.quant or "bf16", "images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 2),
                   "step_tflop_algorithmic": round(tf, 1), "tflops": round(tf / dt, 1), "loss": float(loss.item()),
                   "mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
