@@ -682,11 +682,14 @@ class _QwenPlan:
     def _init_side_grads(self, blocks, allowed):
         """LoRA weight gradients are leaves of the backward: the batched lora_grad launch of block i goes to a low-priority side
         stream and overlaps the first two GEMMs of block i-1 (persistent 240-block grids leave 16 CUs idle); the main stream joins
-        it right before block i-1 first overwrites one of its operands (dyg1).  Not with feed-forward adapters (their operands dh /
-        dyg2 are overwritten at once).  QFX_SIDE_GRADS=0 keeps everything on the main stream."""
+        it right before block i-1 first overwrites one of its operands (dyg1).  With feed-forward adapters dh and their v^T scratch
+        alternate by block parity too, the join sits at the top of the block (dh is the first thing a block's backward overwrites),
+        and the launches that read dyg2 stay on the main stream.  QFX_SIDE_GRADS=0 keeps everything on the main stream."""
         import os
         ff = any(w[s + k].lora is not None for w in blocks for s in ("img", "txt") for k in (".fc1", ".fc2"))
-        self.side_grads = bool(allowed and self.has_lora and not ff and os.environ.get("QFX_SIDE_GRADS", "1") != "0")
+        self._ff_side = bool(ff)      # feed-forward adapters: dh / v^T(fc1, fc2) join the parity-alternated scratch, the join moves to the block top
+        self.side_grads = bool(allowed and self.has_lora and os.environ.get("QFX_SIDE_GRADS", "1") != "0"
+                               and (not ff or os.environ.get("QFX_SIDE_GRADS_FF", "1") != "0"))
         self._side_q = []              # (event, prefix) of the blocks whose gradient launches are in flight on the side stream
         if self.side_grads:
             dev = self.model.device
@@ -698,7 +701,7 @@ class _QwenPlan:
             # the scratch operands of those launches (dyg1, dqkv, v^T) alternate between two copies by block parity, so a launch
             # has a whole block of main-stream work to hide under (on the 16 idle CUs it runs ~5x longer than alone)
             A = self.A
-            for name in ("dyg1", "dqkv", "Vt", "VtO"):
+            for name in ("dyg1", "dqkv", "Vt", "VtO") + (("dh", "VtF1", "VtF2") if ff else ()):
                 src = A[name]
                 if isinstance(src, dict):
                     A[name + "#1"] = {s: (tuple(torch.zeros_like(t) for t in v) if isinstance(v, tuple) else torch.zeros_like(v))
@@ -1338,6 +1341,11 @@ class _QwenPlan:
         eps = 1e-6
         dao2 = A["dao"].view(B * S, D)
         dqkv, dyg1, VtO, VtQ = self._sb("dqkv", par), self._sb("dyg1", par), self._sb("VtO", par), self._sb("Vt", par)
+        ff_side = self.side_grads and self._ff_side
+        dh_ = self._sb("dh", par) if ff_side else A["dh"]
+        vtf = {"VtF1": self._sb("VtF1", par) if ff_side else A.get("VtF1"), "VtF2": self._sb("VtF2", par) if ff_side else A.get("VtF2")}
+        if ff_side:
+            self._side_join(p, keep=1)      # the launch of block i+2 read this parity's dh: overwritten by this block's first GEMM
         dq2 = dqkv.view(B * S, 3 * D)
         STREAMS = (("img", 0), ("txt", 1))
         i = 0 if first else 1
@@ -1359,7 +1367,7 @@ class _QwenPlan:
                 if lw.lora is None:
                     return {}
                 lo, e1 = lw.lora, A["ext1"][s]
-                Vt = (A[vkey][s][0][:lo.Rp], A[vkey][s][1][:lo.Rp])
+                Vt = (vtf[vkey][s][0][:lo.Rp], vtf[vkey][s][1][:lo.Rp])
                 self._down(p, X=dY, ldx=ldy, M=rows[s], K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp,
                            Ut=Vt, ext=e1, ld_ext=e1.stride(0), defer=dbw)
                 self._grad(p, Vt=bb[ukey + s], R=lo.Rp, r_valid=lo.r, X=dY, ldx=ldy, M=rows[s], K=lw.N, G=lo.gB, g_sr=1, g_sc=lo.r,
@@ -1372,16 +1380,16 @@ class _QwenPlan:
             for s, _ in live:
                 f2 = w[s + ".fc2"]
                 kw = lora_bwd(s, f2, A["dyg2"][s], D, bb.get("g." + s), 4 * D, "Uf2.", "VtF2", early=True)
-                groups.append(self._gargs(A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=A["dh"][s],
+                groups.append(self._gargs(A1=A["dyg2"][s], lda1=D, B1=f2.WT, K1=D, M=rows[s], N=4 * D, C_=dh_[s],
                                           ldc=4 * D, epi=L.EPI_DGELU, aux=bb["h"][s], ldaux=4 * D, **kw))
-                groups[-1]._next = (A["dh"][s], 4 * D, w[s + ".fc1"].lora is not None)   # dh feeds fc1's dX GEMM (and its adapter's v / dB)
+                groups[-1]._next = (dh_[s], 4 * D, w[s + ".fc1"].lora is not None)   # dh feeds fc1's dX GEMM (and its adapter's v / dB)
             self._flush_batch(p, dbw, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             groups = []
             for s, _ in live:
                 f1 = w[s + ".fc1"]
-                kw = lora_bwd(s, f1, A["dh"][s], 4 * D, bb.get("xm2." + s), D, "Uf1.", "VtF1", early=False)
-                groups.append(self._gargs(A1=A["dh"][s], lda1=4 * D, B1=f1.WT, K1=4 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D, **kw))
+                kw = lora_bwd(s, f1, dh_[s], 4 * D, bb.get("xm2." + s), D, "Uf1.", "VtF1", early=False)
+                groups.append(self._gargs(A1=dh_[s], lda1=4 * D, B1=f1.WT, K1=4 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D, **kw))
             self._flush_batch(p, dbw, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._gemm_group(p, groups)
             if ge:

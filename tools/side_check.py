@@ -11,12 +11,14 @@ from qflux_amd.trainer import QwenLoraTrainStep
 dev = torch.device("cuda", 0)
 torch.manual_seed(1234)
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+targets = sys.argv[2] if len(sys.argv) > 2 else None      # e.g. "all-linear": feed-forward adapters put dh / v^T(fc) on the parity scratch too
 with torch.device(dev):
     dit = QwenImageTransformer2DModel(num_layers=layers)
 with torch.no_grad():
     for n, p in dit.named_parameters():
         p.normal_(0.0, 0.02) if p.ndim == 2 else (p.fill_(1.0) if "norm" in n else p.normal_(0.0, 0.02))
-dit.add_adapter(LoraConfig(r=16, lora_alpha=16), "default", generator=torch.Generator().manual_seed(0))
+dit.add_adapter(LoraConfig(r=16, lora_alpha=16, **({"target_modules": targets} if targets else {})), "default",
+                generator=torch.Generator().manual_seed(0))
 with torch.no_grad():
     for n, p in dit.named_parameters():
         if "lora_B" in n:
