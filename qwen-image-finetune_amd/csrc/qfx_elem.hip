@@ -226,7 +226,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
 constexpr int MG_RPW = 2;
 template <int NP>
 __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a) {
-  __shared__ float sacc[3][NP * 512];
+  constexpr int NS = NP <= 6 ? 4 : 2;         // LDS slabs: one per wave (144 KiB at NP = 6; the kernel runs one block per CU anyway), two beyond
+  __shared__ float sacc[NS][3][NP * 512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int D = a.D;
@@ -299,12 +300,14 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
       }
     }
   }
-  // the four waves fold their register sums into the block's LDS sums one after the other with PLAIN reads / writes (an LDS float
-  // atomic costs ~600 cycles per wave instruction here, conflict-free or not: 288 of them were 80 of the kernel's 110 us).
-  // Element-major slots -- column (p*64 + lane)*8 + i at i*(NP*64) + p*64 + lane -- keep the 64 lanes on 64 banks.
-#pragma unroll 1
-  for (int turn = 0; turn < 4; ++turn) {
-    if (w == turn) {
+  // each wave parks its register sums in its OWN LDS slab (plain, independent stores), one barrier, then every thread adds the four
+  // slabs for its columns.  No LDS float atomics: one costs ~600 cycles per wave instruction here, conflict-free or not (288 of them
+  // were 80 of the kernel's 110 us); no read-modify-write chains either.  Element-major slots -- column (p*64 + lane)*8 + i at
+  // i*(NP*64) + p*64 + lane -- keep the 64 lanes of a store on 64 banks.
+#pragma unroll
+  for (int rnd = 0; rnd < 4 / NS; ++rnd) {
+    if (w / NS == rnd) {
+      const int sb = w % NS;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int sl = p * 64 + lane;
@@ -312,9 +315,9 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int o = i * (NP * 64) + sl;
-            sacc[0][o] = (turn ? sacc[0][o] : 0.f) + as[p][i];
-            sacc[1][o] = (turn ? sacc[1][o] : 0.f) + ac[p][i];
-            if (has_gate) sacc[2][o] = (turn ? sacc[2][o] : 0.f) + ag[p][i];
+            sacc[sb][0][o] = (rnd ? sacc[sb][0][o] : 0.f) + as[p][i];
+            sacc[sb][1][o] = (rnd ? sacc[sb][1][o] : 0.f) + ac[p][i];
+            if (has_gate) sacc[sb][2][o] = (rnd ? sacc[sb][2][o] : 0.f) + ag[p][i];
           }
         }
       }
@@ -323,9 +326,12 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
   }
   for (int c = threadIdx.x; c < D; c += 256) {
     const int slot = (c & 7) * (NP * 64) + (c >> 3);
-    unsafeAtomicAdd(a.dshift + (int64_t)b * a.out_bstride + c, sacc[0][slot]);
-    unsafeAtomicAdd(a.dscale + (int64_t)b * a.out_bstride + c, sacc[1][slot]);
-    if (has_gate) unsafeAtomicAdd(a.dgate + (int64_t)b * a.out_bstride + c, sacc[2][slot]);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int sb = 0; sb < NS; ++sb) { t0 += sacc[sb][0][slot]; t1 += sacc[sb][1][slot]; if (has_gate) t2 += sacc[sb][2][slot]; }
+    unsafeAtomicAdd(a.dshift + (int64_t)b * a.out_bstride + c, t0);
+    unsafeAtomicAdd(a.dscale + (int64_t)b * a.out_bstride + c, t1);
+    if (has_gate) unsafeAtomicAdd(a.dgate + (int64_t)b * a.out_bstride + c, t2);
   }
 }
 
