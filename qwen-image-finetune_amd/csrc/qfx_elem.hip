@@ -1108,7 +1108,9 @@ extern "C" int qfx_mse_loss_fwd_bwd(const uint16_t* pred, const uint16_t* target
                                     int32_t S_all, int32_t S_t, int32_t C, float gscale, void* stream) {
   if (!pred || !target || !loss || B <= 0 || S_all <= 0 || S_t <= 0 || S_t > S_all || C <= 0) return QFX_EINVAL;
   const int64_t total = (int64_t)B * S_all * C;
-  if (C % 8 == 0) {
+  // the 8-wide form issues 16-byte accesses on all three tensors: offset views (a row- or column-sliced target) keep the scalar form
+  const bool al16 = (((uintptr_t)pred | (uintptr_t)target | (uintptr_t)dpred) & 15) == 0;
+  if (C % 8 == 0 && al16) {
     int blocks = (int)((total / 8 + 255) / 256);
     if (blocks > 128) blocks = 128;
     hipLaunchKernelGGL(mse_kernel8, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, loss, dpred, B, S_all, S_t, C, gscale);

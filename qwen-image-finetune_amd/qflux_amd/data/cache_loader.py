@@ -104,6 +104,33 @@ def collate_cached(batch: list) -> dict:
     return out
 
 
+def _to_device(obj, device):
+    """Tensors of a (possibly nested) batch value to the device, asynchronously; everything else unchanged."""
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device, non_blocking=True)
+    if isinstance(obj, list):
+        return [_to_device(v, device) for v in obj]
+    if isinstance(obj, tuple):
+        return tuple(_to_device(v, device) for v in obj)
+    if isinstance(obj, dict):
+        return {k: _to_device(v, device) for k, v in obj.items()}
+    return obj
+
+
+def _record_stream(obj, stream):
+    """record_stream on every CUDA tensor of a (possibly nested) batch container."""
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for k, v in obj.items():
+            if k != "_host":
+                _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
 class PrefetchLoader:
     """Iterates device-resident batches.  `workers` threads read + collate into pinned memory; the upload of batch n+1 runs on a
     side stream while the training step consumes batch n."""
@@ -131,8 +158,10 @@ class PrefetchLoader:
             idx = idx[:len(idx) // chunk * chunk]
         elif len(idx) % chunk:
             idx = idx + (idx * chunk)[:chunk - len(idx) % chunk]   # wrap-around padding to a whole number of global batches
-        idx = idx[self.rank::self.world]            # rank-strided shard
-        return [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
+        # whole batches dealt round-robin: global batch j goes to rank j % world -- the composition accelerate's BatchSamplerShard
+        # (split_batches=False, the reference's setting) gives each process for the same permutation
+        batches = [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
+        return batches[self.rank::self.world]
 
     def __len__(self):
         return len(self.indices())
@@ -200,8 +229,8 @@ class PrefetchLoader:
                 return hb, None
             ev = torch.cuda.Event()
             with torch.cuda.stream(side):
-                db = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and
-                          (self.keys_to_device is None or k in self.keys_to_device) else v) for k, v in hb.items()}
+                db = {k: (_to_device(v, self.device) if (self.keys_to_device is None or k in self.keys_to_device) else v)
+                      for k, v in hb.items()}
                 ev.record(side)
             db["_host"] = hb     # keep the pinned buffers alive until the copy has been consumed
             return db, ev
@@ -216,9 +245,7 @@ class PrefetchLoader:
                     consumer.wait_event(ev)
                     # the tensors were allocated on the side stream's pool: tell the caching allocator that the consumer stream
                     # uses them too, or their blocks could be handed to upload(i+2) while this step's kernels are still queued
-                    for v in cur.values():
-                        if isinstance(v, torch.Tensor) and v.is_cuda:
-                            v.record_stream(consumer)
+                    _record_stream(cur, consumer)
                 cur.pop("_host", None)
                 yield cur
         finally:

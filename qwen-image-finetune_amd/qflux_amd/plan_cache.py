@@ -83,17 +83,37 @@ class PlanCache(OrderedDict):
         if key in self:
             self.move_to_end(key)
             return self[key]
-        plan = builder()
+        # make room BEFORE building: the newcomer is estimated at the size of the largest resident plan of the same key class
+        # (first element of the key: shared vs "multires"), so the peak is the budget, not the budget plus one plan
+        cls = key[0] if isinstance(key, tuple) and key else key
+        est = max([sz for k, sz in self.sizes.items() if (k[0] if isinstance(k, tuple) and k else k) == cls] or [0])
+        self._evict(keep=None, incoming=est)
+        try:
+            plan = builder()
+        except torch.OutOfMemoryError:
+            # one retry with everything else gone (the estimate was too small, or weights / optimizer state ate the headroom)
+            while len(self):
+                del self[next(iter(self))]
+                self.evictions += 1
+            import gc
+            gc.collect()
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+            plan = builder()
         self.builds += 1
         self[key] = plan
         self.sizes[key] = int((sizer or (lambda p: arena_bytes(getattr(p, "A", None))))(plan))
         self._evict(keep=key)
         return plan
 
-    def _evict(self, keep):
+    def _evict(self, keep, incoming: int = 0):
+        """Drop least-recently-used plans until the survivors (plus `incoming` bytes and one entry, when a build is about to
+        happen) fit the budget and the entry cap; `keep` is never dropped."""
         budget, cap = self.budget_bytes(), self.max_entries()
         n0 = self.evictions
-        while len(self) > 1 and (len(self) > cap or self.total_bytes() > budget):
+        extra = 1 if (incoming or keep is None) else 0
+        floor = 1 if keep is not None else 0
+        while len(self) > floor and (len(self) + extra > cap or self.total_bytes() + incoming > budget):
             old = next(k for k in self if k != keep)
             del self[old]
             self.evictions += 1

@@ -55,6 +55,7 @@ class FluxKontextTrainStep(QwenLoraTrainStep):
         dit = self.dit
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], img_ids, txt_ids)
         dit.lora_store
+        self._ensure_synced()
         pred = plan.run_forward((packed, pooled, guidance), pe, t)
         if self.criterion == "mask_edit":
             B = packed.shape[0]
@@ -143,6 +144,7 @@ def _forward_backward_multires(self, samples, txt, grad_scale=1.0, sync=True):
     valid = b["mask"][:, T:].sum(dim=1).tolist()
     plan = dit.get_plan_multires(B, S_i, T, b["ids"], valid)
     dit.lora_store
+    self._ensure_synced()
     pred = plan.run_forward((b["inp"], b["pooled"], b["guidance"]), b["pe"], b["timestep"])
     loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, b["target"], b["tok_w"].contiguous(), b["n_t_max"], 1.0 / (b["n_valid"] + 1e-12),
                                                  gscale=grad_scale)

@@ -83,6 +83,14 @@ class QwenLoraTrainStep:
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self._pending = []
         self._reduced = False
+        self._synced = False      # rank 0's adapter / optimizer state is broadcast before the first step (broadcast_state)
+
+    def _ensure_synced(self):
+        if not self._synced:
+            self._synced = True
+            if self.world > 1:
+                self.dit.lora_store
+                self.broadcast_state()
 
     # ------------------------------------------------------------------ sampling (CPU RNG like the reference)
     def sample_timesteps(self, batch_size, u=None):
@@ -135,6 +143,7 @@ class QwenLoraTrainStep:
         dit = self.dit
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
         dit.lora_store  # make sure the flat buffers / grads are attached
+        self._ensure_synced()
         pred = plan.run_forward(packed, pe, t_in)
         if self.criterion == "mask_edit":
             B = packed.shape[0]
@@ -158,6 +167,9 @@ class QwenLoraTrainStep:
         if self.criterion == "mask_edit":
             raise NotImplementedError("capture_graph: the mask_edit criterion takes per-step token weights; use train_step")
         dit = self.dit
+        if getattr(dit, "cond_lora", False):
+            raise NotImplementedError("capture_graph: adapters on the conditioning head run host-side steps inside the launch programs "
+                                      "(not capturable); use train_step")
         packed, target, pe, t_in, S_t = self._prepare(embeddings)
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
         dit.lora_store
@@ -197,7 +209,7 @@ class QwenLoraTrainStep:
             self._finish_buckets = None
             self.optimizer_step(grad_scale=self.allreduce_grads())
             self.zero_grad()
-            return loss_static
+            return loss_static.clone()      # the graph overwrites loss_static on every replay
 
         step.graph = graph
         return step
@@ -218,8 +230,15 @@ class QwenLoraTrainStep:
                 self._pending.append(dist.all_reduce(st.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             acc.clear()
 
+        # adapters of the conditioning head (AdaLN modulation linears img_mod.1 / txt_mod.1, FLUX norm*.linear, the embedders) live
+        # under the block prefixes too, but their gradients are written by the LAST call of the backward program (the head's own
+        # backward, fed by the d(modulation) column sums of every block): they are never final at a block mark and go out with
+        # finish(), after the whole program
+        cond_sfx = tuple(getattr(self.dit, "_COND_SUFFIXES", ()))
+        late = {i for i in todo if cond_sfx and ents[i][0].split(".lora_")[0].endswith(cond_sfx)}
+
         def hook(prefix):
-            done = [i for i in todo if ents[i][0].startswith(prefix)]
+            done = [i for i in todo if i not in late and ents[i][0].startswith(prefix)]
             todo.difference_update(done)
             acc.extend(done)
             flush()
@@ -369,8 +388,66 @@ class QwenLoraTrainStep:
         if adapter_name is not None:
             self.dit.load_lora_adapter(save_dir, adapter_name=adapter_name)
         self.load_state_dict(torch.load(os.path.join(save_dir, "optimizer.bin"), map_location="cpu", weights_only=False))
+        self.broadcast_state()       # every replica continues from rank 0's copy of the checkpoint
         with open(os.path.join(save_dir, "state.json")) as f:
             return json.load(f)
+
+    # ------------------------------------------------------------------ replica consistency (main.py:58, base_trainer.py:384-393)
+    def _state_buffers(self):
+        """Every flat buffer that must be identical on all ranks: adapter weights, then the optimizer's moment / Prodigy buffers."""
+        st = self.dit.lora_store
+        bufs = [("lora", st.pflat)]
+        for name in ("_m", "_v", "_ps", "_p0", "_pstate"):
+            t = getattr(self, name, None)
+            if t is not None:
+                bufs.append((name, t))
+        return bufs
+
+    def broadcast_state(self, src: int = 0):
+        """Rank `src`'s adapter weights (+ optimizer state, + step count) to every rank: what DDP's constructor does for the
+        reference's LoRA container (base_trainer.py:384-393; the reference otherwise relies on equal seeds, main.py:58).  Called
+        once before the first step and after load_checkpoint / load_lora_adapter: a resumed or re-injected adapter set must not
+        depend on every rank having read identical files.  Which optimizer buffers exist is agreed on first (rank `src` decides)."""
+        if self.world <= 1:
+            return
+        dev = self.dit.lora_store.pflat.device
+        have = torch.tensor([float(self._m is not None), float(self._pstate is not None), float(self.global_step)], device=dev)
+        dist.broadcast(have, src=src, group=self.group)
+        st = self.dit.lora_store
+        if have[0].item() and self._m is None:
+            self._m, self._v = torch.zeros_like(st.pflat), torch.zeros_like(st.pflat)
+            self._gnorm = torch.zeros((), dtype=torch.float32, device=dev)
+        if have[1].item() and self._pstate is None:
+            self._ps, self._p0 = torch.zeros_like(st.pflat), torch.zeros_like(st.pflat)
+            self._pstate = torch.zeros(L_PRODIGY_STATE, dtype=torch.float64, device=dev)
+        self.global_step = int(have[2].item())
+        for _, t in self._state_buffers():
+            dist.broadcast(t, src=src, group=self.group)
+
+    def check_replicas(self, what: str = "adapter weights"):
+        """Raises if the adapter weights (and optimizer buffers) differ between ranks: two order-sensitive fp64 checksums per
+        buffer, gathered and compared on every rank.  Cheap (one small all-gather); call it after loading state and periodically."""
+        if self.world <= 1:
+            return True
+        st = self.dit.lora_store
+        dev = st.pflat.device
+        sums = []
+        for name in ("lora", "_m", "_v", "_ps", "_p0", "_pstate"):      # fixed layout: a buffer a rank lacks is part of the verdict
+            t = st.pflat if name == "lora" else getattr(self, name, None)
+            if t is None:
+                sums += [torch.zeros((), dtype=torch.float64, device=dev)] * 3
+                continue
+            d = t.detach().double().flatten()
+            w = torch.arange(1, d.numel() + 1, device=d.device, dtype=torch.float64) % 8191
+            sums += [torch.ones((), dtype=torch.float64, device=dev), d.sum(), (d * w).sum()]
+        mine = torch.stack(sums)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.group)
+        for r, o in enumerate(out):
+            if not torch.equal(o, out[0]):
+                raise RuntimeError(f"data-parallel replicas diverged ({what}): rank {r} differs from rank 0 "
+                                   f"(checksums {o.tolist()} vs {out[0].tolist()}); call broadcast_state() after loading state")
+        return True
 
     def train_step(self, embeddings, noise=None, u=None, micro_batches=None):
         """One full optimisation step; returns the (device) loss.  micro_batches: optional list of further embedding dicts

@@ -369,6 +369,200 @@ def make_f1_f3_fixtures():
           [(e["model"], e["style"], e["label"]) for e in out["repo_written_files"]])
 
 
+
+def _ref_functions(path, names, glb):
+    """Compile the named function definitions of a reference file WHERE IT LIES (ast of /root/reference/...; nothing is copied
+    into this repository) into namespaces that supply the module-level names they use.  Decorators (@staticmethod / @classmethod)
+    are dropped: the callers below pass `self` / `cls` explicitly."""
+    import ast
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    out = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names and node.name not in out:
+            node.decorator_list = []
+            ns = dict(glb)
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+            out[node.name] = ns[node.name]
+    missing = set(names) - set(out)
+    assert not missing, (path, missing)
+    return out
+
+
+class _Sched:
+    """FlowMatchEulerDiscreteScheduler as constructed from the model repo's scheduler_config.json (third party, restated:
+    timesteps = linspace(1, N, N)[::-1], sigmas = timesteps / N with a trailing 0; dynamic shifting => unshifted at init)."""
+
+    def __init__(self, n=1000):
+        self.config = type("Cfg", (), {"num_train_timesteps": n})()
+        self.timesteps = torch.linspace(1, n, n).flip(0)
+        self.sigmas = torch.cat([self.timesteps / n, torch.zeros(1)])
+
+
+class _Rec(torch.nn.Module):
+    """Records what the step caller hands to the DiT and what comes back."""
+
+    def __init__(self, dit):
+        super().__init__()
+        self.dit, self.config, self.calls = dit, dit.config, []
+
+    def forward(self, **kw):
+        out = self.dit(**kw)
+        self.calls.append((kw, out[0].detach().clone()))
+        return out
+
+
+def make_step_caller_fixtures():
+    """SURVEY 8 rows a1 / a13 pinned by EXECUTION: the bodies of the reference's own step callers
+         QwenImageEditTrainer._compute_loss (+ _get_sigmas)                qwen_image_edit_trainer.py:777-861
+         FluxKontextLoraTrainer._compute_loss_shared_mode                  flux_kontext_trainer.py:494-577
+         FluxKontextLoraTrainer._compute_loss_multi_resolution_mode        flux_kontext_trainer.py:579-796
+         BaseTrainer.forward_loss / convert_img_shapes_to_latent           base_trainer.py:478-506,184-240
+       run here on a stub `self` (cpu accelerator, fp32, the reference's own tiny DiT / loss classes / pad_latents_for_multi_res),
+       unbound, compiled from the files where they lie.  The trainer MODULES cannot be imported (diffusers pipelines, transformers,
+       peft at module level), their function bodies can.  Third-party names the bodies use are restated: the two diffusers
+       training_utils helpers for weighting_scheme="none" (u ~ U(0,1) on the CPU; weighting = ones) and the scheduler tables.
+       Written: tests/golden/ref_step_callers.safetensors (inputs, draws, what reached the DiT, prediction, loss)."""
+    import copy
+    import types as _t
+    from oracle import flux_dit as FO
+    from oracle import qwen_dit as O
+    ref = import_reference_qwen()
+    reff = import_reference_flux()
+    refc = importlib.import_module("qflux.models.transformer_flux_custom")
+    (tools,) = import_reference_by_path("qflux.utils.tools")
+    for m_ in ("qflux.losses",):
+        if m_ not in sys.modules:
+            pk = types.ModuleType(m_); pk.__path__ = [os.path.join(REF, "src", "qflux", "losses")]; sys.modules[m_] = pk
+    mse_mod = importlib.import_module("qflux.losses.mse_loss")
+    am_mod = importlib.import_module("qflux.losses.attention_mask_loss")
+
+    def density(weighting_scheme, batch_size, logit_mean=None, logit_std=None, mode_scale=None, device="cpu", generator=None):
+        assert weighting_scheme == "none"
+        return torch.rand(size=(batch_size,), device=device, generator=generator)     # diffusers.training_utils (third party)
+
+    def weighting_sd3(weighting_scheme, sigmas=None):
+        assert weighting_scheme == "none"
+        return torch.ones_like(sigmas)                                                  # diffusers.training_utils (third party)
+
+    glb = dict(torch=torch, copy=copy, compute_density_for_timestep_sampling=density, compute_loss_weighting_for_sd3=weighting_sd3,
+               pad_latents_for_multi_res=tools.pad_latents_for_multi_res)
+    tdir = os.path.join(REF, "src", "qflux", "trainer")
+    qf = _ref_functions(os.path.join(tdir, "qwen_image_edit_trainer.py"), ["_compute_loss", "_get_sigmas"], glb)
+    bf = _ref_functions(os.path.join(tdir, "base_trainer.py"), ["forward_loss", "convert_img_shapes_to_latent"], glb)
+    ids_fn = _ref_functions(os.path.join(tdir, "flux_kontext_trainer.py"), ["_prepare_latent_image_ids"], glb)["_prepare_latent_image_ids"]
+    FK = type("FluxKontextLoraTrainer", (), {"_prepare_latent_image_ids": staticmethod(ids_fn)})
+    ff = _ref_functions(os.path.join(tdir, "flux_kontext_trainer.py"), ["_compute_loss_shared_mode", "_compute_loss_multi_resolution_mode"],
+                        dict(glb, FluxKontextLoraTrainer=FK))
+
+    def stub(dit, criterion):
+        s = _t.SimpleNamespace()
+        s.accelerator = _t.SimpleNamespace(device=torch.device("cpu"))
+        s.weight_dtype = torch.float32
+        s.scheduler = _Sched()
+        s.dit = _Rec(dit)
+        s.criterion = criterion
+        s.vae_scale_factor = 8
+        s.forward_loss = lambda *a, **k: bf["forward_loss"](s, *a, **k)
+        s._get_sigmas = lambda *a, **k: qf["_get_sigmas"](s, *a, **k)
+        s._prepare_latent_image_ids = ids_fn
+        s.convert_img_shapes_to_latent = lambda *a, **k: bf["convert_img_shapes_to_latent"](s, *a, **k)
+        return s
+
+    out = {}
+    # ---------------- Qwen: _compute_loss ----------------
+    model = ref.QwenImageTransformer2DModel(**TINY, guidance_embeds=False).eval()
+    fill_weights(model, seed=1)
+    g = torch.Generator().manual_seed(101)
+    B, T = 2, 5
+    shapes = [(1, 4, 6), (1, 4, 6)]
+    emb = dict(image_latents=torch.randn(B, 24, 64, generator=g).half(), control_latents=torch.randn(B, 24, 64, generator=g).half(),
+               prompt_embeds=(torch.randn(B, T, 512, generator=g) * 4).half(), prompt_embeds_mask=torch.ones(B, T, dtype=torch.int64),
+               img_shapes=[shapes] * B)
+    s = stub(model, mse_mod.MseLoss())
+    torch.manual_seed(4242)
+    loss = qf["_compute_loss"](s, emb)
+    torch.manual_seed(4242)                 # replay the two draws of the body in its order: randn_like(image_latents), rand(B)
+    noise = torch.randn_like(emb["image_latents"].float())
+    u = torch.rand(size=(B,), device="cpu")
+    kw, pred = s.dit.calls[0]
+    oracle = O.OracleQwenDiT(**TINY)
+    oracle.load_state_dict(model.state_dict(), strict=True)
+    lo, po = O.qwen_compute_loss(oracle, emb, noise, u, torch.float32, return_pred=True)
+    print("qwen _compute_loss (reference body) vs oracle step caller: loss %.3e pred %.3e" % (
+        abs(lo.item() - loss.item()), (po - pred[:, :24]).abs().max().item()))
+    assert abs(lo.item() - loss.item()) < 1e-6 and (po - pred[:, :24]).abs().max() < 1e-5
+    out.update({"qwen.image_latents": emb["image_latents"], "qwen.control_latents": emb["control_latents"],
+                "qwen.prompt_embeds": emb["prompt_embeds"], "qwen.noise": noise, "qwen.u": u,
+                "qwen.dit_hidden_states": kw["hidden_states"].detach(), "qwen.dit_timestep": kw["timestep"].detach(),
+                "qwen.pred": pred, "qwen.loss": loss.detach().reshape(1), "qwen.w_checksum": weight_checksum(model)})
+    # ---------------- FLUX: _compute_loss_shared_mode ----------------
+    cfg = dict(FLUX_TINY, guidance_embeds=True)
+    fm = reff.FluxTransformer2DModel(**cfg).eval()
+    fill_weights(fm, seed=3)
+    g = torch.Generator().manual_seed(103)
+    B, hh, ww, T = 2, 4, 6, 7
+    S_t = hh * ww
+    ctl = ids_fn(B, hh, ww, "cpu", torch.float32); ctl[:, 0] = 1
+    femb = dict(image_latents=torch.randn(B, S_t, 64, generator=g), control_latents=torch.randn(B, S_t, 64, generator=g),
+                control_ids=ctl, text_ids=torch.zeros(T, 3), pooled_prompt_embeds=torch.randn(B, cfg["pooled_projection_dim"], generator=g),
+                prompt_embeds=torch.randn(B, T, cfg["joint_attention_dim"], generator=g), image=torch.zeros(B, 3, hh * 16, ww * 16),
+                noise=torch.randn(B, S_t, 64, generator=g), timestep=torch.tensor([0.7109, 0.1611]))
+    s = stub(fm, mse_mod.MseLoss())
+    loss = ff["_compute_loss_shared_mode"](s, femb)
+    kw, pred = s.dit.calls[0]
+    fo = FO.OracleFluxDiT(**cfg)
+    fo.load_state_dict(fm.state_dict(), strict=True)
+    lo, po = FO.flux_compute_loss(fo, dict(femb, latent_hw=(hh, ww)), femb["noise"], femb["timestep"], torch.float32, return_pred=True)
+    print("flux _compute_loss_shared_mode (reference body) vs oracle: loss %.3e pred %.3e" % (
+        abs(lo.item() - loss.item()), (po - pred[:, :S_t]).abs().max().item()))
+    assert abs(lo.item() - loss.item()) < 1e-6 and (po - pred[:, :S_t]).abs().max() < 1e-5
+    out.update({"flux." + k: v for k, v in femb.items() if k != "image"})
+    out.update({"flux.dit_hidden_states": kw["hidden_states"].detach(), "flux.dit_img_ids": kw["img_ids"].detach(),
+                "flux.dit_guidance": kw["guidance"].detach(), "flux.pred": pred, "flux.loss": loss.detach().reshape(1),
+                "flux.w_checksum": weight_checksum(fm)})
+    # ---------------- FLUX: _compute_loss_multi_resolution_mode (ragged: one square, one non-square sample) ----------------
+    cm = refc.FluxTransformer2DModel(**cfg).eval()
+    fill_weights(cm, seed=3)
+    g = torch.Generator().manual_seed(107)
+    px = [[(3, 64, 96), (3, 64, 96)], [(3, 80, 48), (3, 48, 80)]]      # per sample: target + control in PIXELS -> 4x6, 4x6 | 5x3, 3x5 tokens
+    lat = [[(h // 16, w // 16) for _, h, w in sh] for sh in px]
+    n_t = [lat[i][0][0] * lat[i][0][1] for i in range(2)]
+    n_c = [sum(a * b for a, b in lat[i][1:]) for i in range(2)]
+    il = torch.zeros(2, max(n_t), 64); cl = torch.zeros(2, max(n_c), 64)
+    noises = []
+    for i in range(2):
+        il[i, : n_t[i]] = torch.randn(n_t[i], 64, generator=g)
+        cl[i, : n_c[i]] = torch.randn(n_c[i], 64, generator=g)
+        noises.append(torch.randn(n_t[i], 64, generator=g))
+    T = 7
+    memb = dict(image_latents=il, control_latents=cl, text_ids=torch.zeros(T, 3), img_shapes=px,
+                pooled_prompt_embeds=torch.randn(2, cfg["pooled_projection_dim"], generator=g),
+                prompt_embeds=torch.randn(2, T, cfg["joint_attention_dim"], generator=g), noise=noises,
+                timestep=[torch.tensor([0.7109]), torch.tensor([0.1611])])
+    s = stub(cm, am_mod.AttentionMaskMseLoss())
+    loss, aux = ff["_compute_loss_multi_resolution_mode"](s, memb, return_pred=True)
+    fo = FO.OracleFluxDiT(**cfg)
+    fo.load_state_dict(cm.state_dict(), strict=True)
+    samples = [dict(image_latents=il[i, : n_t[i]], control_latents=cl[i, : n_c[i]], hw=lat[i][0], control_hw=lat[i][1:], noise=noises[i],
+                    t=memb["timestep"][i].reshape(())) for i in range(2)]
+    lo, po = FO.flux_compute_loss_multires(fo, samples, dict(text_ids=memb["text_ids"], pooled_prompt_embeds=memb["pooled_prompt_embeds"],
+                                                             prompt_embeds=memb["prompt_embeds"]), torch.float32, return_pred=True)
+    print("flux _compute_loss_multi_resolution_mode (reference body) vs oracle: loss %.3e pred %.3e" % (
+        abs(lo.item() - loss.item()), (po - aux["model_pred"]).abs().max().item()))
+    assert abs(lo.item() - loss.item()) < 1e-6 and (po - aux["model_pred"]).abs().max() < 1e-5
+    out.update({"mr.image_latents": il, "mr.control_latents": cl, "mr.pooled_prompt_embeds": memb["pooled_prompt_embeds"],
+                "mr.prompt_embeds": memb["prompt_embeds"], "mr.noise0": noises[0], "mr.noise1": noises[1],
+                "mr.timestep": torch.cat(memb["timestep"]), "mr.px_shapes": torch.tensor(px),
+                "mr.dit_hidden_states": aux["latent_model_input"].detach(), "mr.dit_img_ids": aux["latent_ids"].detach(),
+                "mr.dit_attention_mask": aux["full_attention_mask"].to(torch.uint8), "mr.pred": aux["model_pred"].detach(),
+                "mr.loss": loss.detach().reshape(1), "mr.w_checksum": weight_checksum(cm)})
+    save_file({k: v.contiguous().clone() for k, v in out.items()}, os.path.join(HERE, "ref_step_callers.safetensors"),
+              metadata={"producer": "bodies of the reference's step callers executed on a stub self (make_golden.py --step)",
+                        "qwen_cfg": repr(TINY), "flux_cfg": repr(cfg), "qwen_weights": "fill_weights seed 1", "flux_weights": "fill_weights seed 3"})
+    print("step callers: wrote ref_step_callers.safetensors")
+
+
 def main():
     from oracle import qwen_dit as O
 
@@ -604,6 +798,7 @@ def main():
     save_file({k: v.contiguous().clone() for k, v in out.items()}, os.path.join(HERE, "losses.safetensors"))
     print("criteria: oracle == reference MseLoss / MaskEditLoss / AttentionMaskMseLoss / map_mask_to_latent")
     make_f1_f3_fixtures()
+    make_step_caller_fixtures()
     print("wrote golden vectors to", HERE)
 
 
@@ -611,5 +806,8 @@ if __name__ == "__main__":
     if "--f1f3" in sys.argv:      # only the cache / LoRA-file pins (does not need the diffusers shim)
         from common import FLUX_TINY, TINY  # noqa: F401
         make_f1_f3_fixtures()
+    elif "--step" in sys.argv:    # only the executed step-caller pins (needs the diffusers shim for the reference's DiT files)
+        import_reference_qwen()
+        make_step_caller_fixtures()
     else:
         main()

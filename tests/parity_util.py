@@ -104,7 +104,7 @@ def run_tiny_step_parity(device="cuda:0", verbose=False, cfg=None, shapes=((1, 4
             if e > worst:
                 worst, worst_name = e, n
     res["grad_rel_worst"], res["grad_worst_name"], res["grads_nonzero"] = worst, worst_name, nz
-    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 4e-2 and worst < 4e-2 and nz == len(og) - dead)
+    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 2e-2 and worst < 4e-2 and nz == len(og) - dead)
     if verbose:
         print(res)
     return res
@@ -176,7 +176,7 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
             if e > worst:
                 worst, worst_name = e, n
     res["grad_rel_worst"], res["grad_worst_name"], res["n_lora"] = worst, worst_name, len(og)
-    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 4e-2 and worst < 4e-2 and bad == 0)
+    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 2e-2 and worst < 4e-2 and bad == 0)
     if verbose:
         print(res)
     return res

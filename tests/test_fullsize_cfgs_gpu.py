@@ -163,6 +163,110 @@ def test_cfg3_full_width_block_three_images_r32_vs_oracle():
     assert e_hf < 1.25 * e_bf + 1e-3 and c_hf > c_bf - 0.02 and e_hb < 1.5 * e_bf + 1e-3
 
 
+# ---------------------------------------------------------------------------------------------- cfg #4 (whole step at 1024^2)
+def _qwen_full(layers, r, seed=13, b_seed=7):
+    from qflux_amd.models import QwenImageTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    with torch.device(DEV):
+        hip = QwenImageTransformer2DModel(num_layers=layers, **QWEN_FULL)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if p.ndim == 1 and "norm" in n:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=DEV) * 0.02).to(p.dtype))
+    if r is None:
+        return hip
+    hip.add_adapter(LoraConfig(r=r, lora_alpha=r), "default", generator=torch.Generator().manual_seed(0))
+    if b_seed is not None:
+        with torch.no_grad():
+            for n, p in hip.named_parameters():
+                if "lora_B" in n:
+                    p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(b_seed)).to(p.device) * 1e-2)
+    return hip
+
+
+def _emb_1024(B=1, T=384, seed=23):
+    g = torch.Generator().manual_seed(seed)
+    side = 64                                   # 1024^2 px -> 64 x 64 packed-latent tokens per image
+    S_t = side * side
+    emb = dict(image_latents=torch.randn(B, S_t, 64, generator=g).half().float(), control_latents=torch.randn(B, S_t, 64, generator=g).half().float(),
+               prompt_embeds=(torch.randn(B, T, 3584, generator=g) * 4).half().float(), prompt_embeds_mask=torch.ones(B, T, dtype=torch.int64),
+               img_shapes=[[(1, side, side), (1, side, side)]] * B)
+    return emb, torch.randn(B, S_t, 64, generator=g), torch.tensor([0.4, 0.8][:B])
+
+
+def test_cfg4_full_width_block_1024sq_step_vs_oracle():
+    """cfg #4 as a STEP (not only its attention kernels): one full-width Qwen block at S_i = 8192 (1024^2 target + control), T = 384,
+    r = 16 through QwenLoraTrainStep.forward_backward -- the GEMM / LayerNorm / rank-r kernels at M = 8192 / 8576 rows and the plan
+    arena at that size -- vs the bf16 oracle of the same step (reference: qwen_image_edit_trainer.py:777-849 on
+    transformer_qwenimage.py:570-672)."""
+    from oracle import qwen_dit as O
+    from qflux_amd.trainer import QwenLoraTrainStep
+    r = 16
+    hip = _qwen_full(1, r)
+    emb, noise, u = _emb_1024()
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    oracle = O.OracleQwenDiT(num_layers=1, **QWEN_FULL)
+    O.add_lora(oracle, r=r, lora_alpha=r, adapter_name="default")
+    oracle.load_state_dict({k: v.float().cpu() for k, v in hip.state_dict().items()}, strict=True)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    t0 = time.time()
+    loss_o, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+    loss_o.float().backward()
+    t_or = time.time() - t0
+    step = QwenLoraTrainStep(hip)
+    loss_h = step.forward_backward(emb, noise=noise, u=u).item()
+    plan = list(hip._plans.values())[0]
+    assert plan.S_i == 8192 and plan.S == 8576
+    S_t = 4096
+    e = _rel(plan.A["out"].view(1, -1, 64)[:, :S_t].cpu(), pred_o)
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    cs, rels = [], []
+    for n, p in hip.named_parameters():
+        if "lora" in n and og[n] is not None and og[n].abs().max() > 0:
+            cs.append(_cos(p.grad.cpu(), og[n]))
+            rels.append(_rel(p.grad.cpu(), og[n]))
+    print(f"cfg#4 block (S_i=8192, T=384, r=16): loss hip {loss_h:.5f} oracle-bf16 {loss_o.item():.5f}; pred rel {e:.4f}; LoRA grads n={len(cs)} "
+          f"min cos {min(cs):.4f} worst rel {max(rels):.4f}; oracle {t_or:.1f} s")
+    assert len(cs) == 8
+    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and min(cs) > 0.995 and max(rels) < 8e-2
+
+
+def test_cfg4_properties_at_1024sq_two_blocks():
+    """Size-independent properties at the cfg #4 shape, two blocks (so that a complete block backward incl. the q/k/v dX GEMMs and
+    the LayerNorm backward runs at M = 8192): zero-B exactness (adapted model == frozen model, bit for bit) and linearity of the
+    whole backward in a power-of-two loss scale."""
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import QwenLoraTrainStep
+    hip = _qwen_full(2, None)                     # frozen model, no adapters yet
+    emb, noise, u = _emb_1024()
+    x = torch.cat([emb["image_latents"], emb["control_latents"]], 1).to(BF).to(DEV)
+    kw = dict(hidden_states=x, timestep=torch.tensor([0.5], device=DEV), encoder_hidden_states=emb["prompt_embeds"].to(BF).to(DEV),
+              encoder_hidden_states_mask=None, img_shapes=emb["img_shapes"], txt_seq_lens=[384], return_dict=False)
+    with torch.no_grad():
+        out_base = hip(**kw)[0].clone()
+        hip.add_adapter(LoraConfig(r=16, lora_alpha=16), "default", generator=torch.Generator().manual_seed(0))   # peft init: lora_B = 0
+        out_lora = hip(**kw)[0].clone()
+    assert torch.equal(out_lora, out_base)
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(9)).to(p.device) * 1e-2)
+    step = QwenLoraTrainStep(hip)
+    st = hip.lora_store
+    l1 = step.forward_backward(emb, noise=noise, u=u, grad_scale=1.0).item()
+    g1 = st.gflat.clone(); step.zero_grad()
+    l2 = step.forward_backward(emb, noise=noise, u=u, grad_scale=0.5).item()
+    g2 = st.gflat.clone(); step.zero_grad()
+    lin = ((g2 * 2 - g1).abs().max() / g1.abs().max()).item()
+    print(f"cfg#4 two blocks: loss {l1:.5f} / {l2:.5f}, backward linearity {lin:.2e}, |g| max {g1.abs().max().item():.3e}")
+    assert abs(l1 - l2) < 1e-5 * abs(l1) and lin < 1e-5 and g1.abs().max().item() > 0 and torch.isfinite(g1).all()
+
+
 # ---------------------------------------------------------------------------------------------- cfg #1 / #5
 FLUX_FULL = dict(patch_size=1, in_channels=64, out_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128,
                  num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
@@ -235,12 +339,16 @@ def test_flux_full_width_double_and_single_block_shared_step_vs_oracle():
     assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and c > 0.995 and rg < 8e-2 and n >= 6
 
 
-def test_flux_full_width_ragged_two_bucket_batch_vs_oracle():
+@pytest.mark.parametrize("specs", [
+    [((20, 20), [(20, 20)]), ((32, 32), [(32, 32)])],                     # 320^2 and 512^2 buckets: 800 / 2048 image tokens
+    [((20, 20), [(20, 20)]), ((40, 40), [(40, 40)])],                     # 320^2 and 640^2 buckets: 800 / 3200 image tokens
+    [((40, 26), [(40, 26)]), ((40, 40), [(40, 40)])],                     # non-square 640 x 416 px (40 x 26 tokens = 1040,
+], ids=["320+512", "320+640", "640x416+640"])                             # flux_kontext_trainer.py:654-661) next to 640^2
+def test_flux_full_width_ragged_two_bucket_batch_vs_oracle(specs):
     from qflux_amd.trainer import FluxKontextTrainStep
     oracle, hip, FO = _flux_pair()
     g = torch.Generator().manual_seed(53)
     T = 512
-    specs = [((20, 20), [(20, 20)]), ((32, 32), [(32, 32)])]     # 320^2 and 512^2 buckets: 800 / 2048 image tokens
     samples = []
     for (h, w), ctl in specs:
         n_t, n_c = h * w, sum(a * b for a, b in ctl)
@@ -256,7 +364,8 @@ def test_flux_full_width_ragged_two_bucket_batch_vs_oracle():
     plan = [p for k, p in hip._plans.items() if "multires" in k][0]
     out = plan.A["out"].view(2, -1, 64)
     e = _rel(out[:, : pred_o.shape[1]].cpu(), pred_o)
-    assert out[0, 800:].abs().max().item() == 0.0            # padded rows of the small sample are exactly zero
+    n0 = sum(a * b for a, b in [specs[0][0]] + specs[0][1])
+    assert out[0, n0:].abs().max().item() == 0.0             # padded rows of the small sample are exactly zero
     c, rg, n = _grad_report(oracle, hip)
     print(f"flux full width ragged: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, LoRA grads n={n} min cos {c:.4f} worst rel {rg:.4f}")
     assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and c > 0.995 and rg < 8e-2 and n >= 6

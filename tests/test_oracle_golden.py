@@ -187,3 +187,60 @@ def test_qwen_multires_matches_reference_custom_vectors(golden_dir):
     assert pad.any() and out[pad].abs().max() == 0
     (gx,) = torch.autograd.grad(((out - t["in.target"]) ** 2).mean(), [x])
     assert (gx - t["grad.hidden_states"]).abs().max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Step callers: vectors produced by EXECUTING the bodies of the reference's own
+# QwenImageEditTrainer._compute_loss / FluxKontextLoraTrainer._compute_loss_shared_mode / _compute_loss_multi_resolution_mode
+# (qwen_image_edit_trainer.py:777-861, flux_kontext_trainer.py:494-796) on a stub trainer -- make_golden.py --step.
+def _step_vectors(golden_dir):
+    return load_file(os.path.join(golden_dir, "ref_step_callers.safetensors"))
+
+
+def test_qwen_step_caller_matches_the_executed_reference_body(golden_dir):
+    t = _step_vectors(golden_dir)
+    model = O.OracleQwenDiT(**TINY)
+    fill_weights(model, seed=1)
+    assert torch.equal(weight_checksum(model), t["qwen.w_checksum"])
+    B = t["qwen.image_latents"].shape[0]
+    emb = dict(image_latents=t["qwen.image_latents"], control_latents=t["qwen.control_latents"], prompt_embeds=t["qwen.prompt_embeds"],
+               prompt_embeds_mask=torch.ones(B, t["qwen.prompt_embeds"].shape[1], dtype=torch.int64), img_shapes=[[(1, 4, 6), (1, 4, 6)]] * B)
+    loss, pred = O.qwen_compute_loss(model, emb, t["qwen.noise"], t["qwen.u"], torch.float32, return_pred=True)
+    assert abs(loss.item() - t["qwen.loss"].item()) < 1e-6
+    assert (pred - t["qwen.pred"][:, : pred.shape[1]]).abs().max() < 1e-5
+    # what reached the DiT: sigma lookup (u -> index -> timestep -> sigma), x_t, concat order, timestep / 1000
+    ts, sig = O.flowmatch_sigmas()
+    idx = (t["qwen.u"] * 1000).long()
+    assert torch.equal(t["qwen.dit_timestep"], ts[idx] / 1000)
+    s = sig[idx].view(B, 1, 1)
+    x_t = (1.0 - s) * t["qwen.image_latents"].float() + s * t["qwen.noise"]
+    assert torch.equal(t["qwen.dit_hidden_states"], torch.cat([x_t, t["qwen.control_latents"].float()], dim=1))
+
+
+def test_flux_step_callers_match_the_executed_reference_bodies(golden_dir):
+    from common import FLUX_TINY
+    from oracle import flux_dit as FO
+    t = _step_vectors(golden_dir)
+    cfg = dict(FLUX_TINY, guidance_embeds=True)
+    fo = FO.OracleFluxDiT(**cfg)
+    fill_weights(fo, seed=3)
+    assert torch.equal(weight_checksum(fo), t["flux.w_checksum"]) and torch.equal(weight_checksum(fo), t["mr.w_checksum"])
+    emb = {k[5:]: v for k, v in t.items() if k.startswith("flux.") and not k.startswith("flux.dit_")}
+    S_t = emb["image_latents"].shape[1]
+    loss, pred = FO.flux_compute_loss(fo, dict(emb, latent_hw=(4, 6)), emb["noise"], emb["timestep"], torch.float32, return_pred=True)
+    assert abs(loss.item() - t["flux.loss"].item()) < 1e-6 and (pred - t["flux.pred"][:, :S_t]).abs().max() < 1e-5
+    assert torch.equal(t["flux.dit_guidance"], torch.ones(2))
+    # multi-resolution caller: ragged batch with a NON-SQUARE sample (5x3 target + 3x5 control tokens)
+    px = t["mr.px_shapes"].tolist()
+    lat = [[(h // 16, w // 16) for _, h, w in sh] for sh in px]
+    samples = []
+    for i in range(2):
+        n_t = lat[i][0][0] * lat[i][0][1]
+        n_c = sum(a * b for a, b in lat[i][1:])
+        samples.append(dict(image_latents=t["mr.image_latents"][i, :n_t], control_latents=t["mr.control_latents"][i, :n_c], hw=lat[i][0],
+                            control_hw=lat[i][1:], noise=t[f"mr.noise{i}"], t=t["mr.timestep"][i]))
+    T = t["mr.prompt_embeds"].shape[1]
+    loss, pred = FO.flux_compute_loss_multires(fo, samples, dict(text_ids=torch.zeros(T, 3), pooled_prompt_embeds=t["mr.pooled_prompt_embeds"],
+                                                                 prompt_embeds=t["mr.prompt_embeds"]), torch.float32, return_pred=True)
+    assert abs(loss.item() - t["mr.loss"].item()) < 1e-6 and (pred - t["mr.pred"]).abs().max() < 1e-5
+    assert not t["mr.dit_attention_mask"][1, T + 30:].any() and t["mr.dit_attention_mask"][1, : T + 30].all()   # 15 + 15 valid image rows
