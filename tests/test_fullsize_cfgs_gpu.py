@@ -233,7 +233,7 @@ def test_cfg4_full_width_block_1024sq_step_vs_oracle():
     print(f"cfg#4 block (S_i=8192, T=384, r=16): loss hip {loss_h:.5f} oracle-bf16 {loss_o.item():.5f}; pred rel {e:.4f}; LoRA grads n={len(cs)} "
           f"min cos {min(cs):.4f} worst rel {max(rels):.4f}; oracle {t_or:.1f} s")
     assert len(cs) == 8
-    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and min(cs) > 0.995 and max(rels) < 8e-2
+    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and min(cs) > 0.995 and max(rels) < 2e-2
 
 
 def test_cfg4_properties_at_1024sq_two_blocks():
@@ -336,7 +336,7 @@ def test_flux_full_width_double_and_single_block_shared_step_vs_oracle():
     e = _rel(plan.A["out"].view(B, -1, 64)[:, :S_t].cpu(), pred_o)
     c, rg, n = _grad_report(oracle, hip)
     print(f"flux full width shared: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, LoRA grads n={n} min cos {c:.4f} worst rel {rg:.4f}")
-    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and c > 0.995 and rg < 8e-2 and n >= 6
+    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and c > 0.995 and rg < 2e-2 and n >= 6
 
 
 @pytest.mark.parametrize("specs", [
@@ -368,4 +368,4 @@ def test_flux_full_width_ragged_two_bucket_batch_vs_oracle(specs):
     assert out[0, n0:].abs().max().item() == 0.0             # padded rows of the small sample are exactly zero
     c, rg, n = _grad_report(oracle, hip)
     print(f"flux full width ragged: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, LoRA grads n={n} min cos {c:.4f} worst rel {rg:.4f}")
-    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and c > 0.995 and rg < 8e-2 and n >= 6
+    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and c > 0.995 and rg < 2e-2 and n >= 6

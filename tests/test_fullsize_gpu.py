@@ -200,4 +200,4 @@ def test_one_full_width_block_all_linear_vs_oracle():
         if r > worst:
             worst, wname = r, n
     print(f"full-width all-linear block: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, worst grad rel {worst:.4f} ({wname}), {n_cmp} tensors")
-    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and worst < 4e-2 and n_cmp >= 30      # (the single block is also the LAST one: its text tail is dead compute)
+    assert abs(loss_h - loss_o.item()) / abs(loss_o.item()) < 1e-2 and e < 2e-2 and worst < 2e-2 and n_cmp >= 30      # (the single block is also the LAST one: its text tail is dead compute)
