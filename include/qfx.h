@@ -259,6 +259,37 @@ int qfx_mod_gemv(const uint16_t* temb, int32_t B, int32_t K, const uint16_t* con
 int qfx_mod_gemv_t(const uint16_t* dy, int32_t B, int32_t N, int32_t K, const uint16_t* const* W, int32_t nmat, float* out,
                    void* stream);
 
+/* ---- adapters on the conditioning head (target_modules "all-linear", configs/example_with_sampling.yaml:9; the
+ * (norm|norm1|norm1_context).linear alternatives of configs/face_seg_flux_kontext_fp16.yaml:11): the rank-r side terms of linears
+ * that see M = batch rows -- timestep / guidance / pooled-text embedders (transformer_qwenimage.py:143-156,
+ * transformer_flux.py:634-639), AdaLN modulation linears (:389-392,411-414 / transformer_flux.py:391,446-447), norm_out.linear
+ * (:565) -- for a BANK of `na` adapters of one rank that share the input x [B,K] (bf16).  peft lora.Linear semantics
+ * (call site base_trainer.py:929-941):
+ *   qfx_cond_lora_fwd:  u_a = A_a act(x) (fp32, kept in `u`);  y_a[b][n] = bf16(float(y_a[b][n]) + scale_a * sum_j B_a[n][j] u_a[b][j])
+ *                       in place on the base outputs qfx_mod_gemv wrote (y: device array of na row pointers, row b at + b*ldy).
+ *   qfx_cond_lora_bwd:  g_a = bf16 gradient rows of the outputs (device array of na pointers, row b at + b*ldg);
+ *                       dB_a += (scale_a g_a)^T u_a;  du_a = (scale_a g_a) B_a;  dA_a += du_a^T act(x);  dx[b][k] += sum_a du_a A_a
+ *                       (dx fp32 [B,K] = gradient w.r.t. act(x), may be NULL; du [na,B,r] fp32 scratch ZEROED by the caller;
+ *                       dA / dB: device arrays of pointers into the flat LoRA gradient buffer, accumulated).
+ * act = bf16(silu(.)) when apply_silu (the eager graph's F.silu on bf16), identity otherwise.  A_a [r,K], B_a [N,r] fp32
+ * (device arrays of pointers to the adapter weights), scale: device [na].  B <= 8, r <= 64. */
+typedef struct qfx_cond_lora_args {
+  const uint16_t* x; int32_t B; int32_t K; int32_t apply_silu; int32_t na; int32_t r; int32_t N;
+  const float* const* A; const float* const* Bm; const float* scale;
+  float* u;
+  uint16_t* const* y; int64_t ldy;
+  const uint16_t* const* g; int64_t ldg;
+  float* const* dA; float* const* dB;
+  float* du; float* dx;
+} qfx_cond_lora_args;
+int qfx_cond_lora_fwd(const qfx_cond_lora_args* a, void* stream);
+int qfx_cond_lora_bwd(const qfx_cond_lora_args* a, void* stream);
+/* out = bf16(in): the fp32 column sums of the HIP backward (qfx_mod_grad) handed to the head's backward as the bf16 gradients
+ * autograd would see */
+int qfx_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+/* dx = bf16(bf16(ds) * silu'(x)): silu_backward of the eager graph on the conditioning vectors (temb, the embedders' hidden layers) */
+int qfx_silu_bwd(const float* ds, const uint16_t* x, uint16_t* dx, int64_t n, void* stream);
+
 /* ---- sinusoidal timestep projection (diffusers Timesteps(dim, flip_sin_to_cos=True, shift 0, scale);
  * transformer_qwenimage.py:147,151-152,623-624): t is first rounded to bf16 (timestep.to(bf16)),
  * out[b] = bf16([cos(t*scale*f_i) | sin(t*scale*f_i)]), f_i = exp(-ln(1e4) * i / (dim/2)). */

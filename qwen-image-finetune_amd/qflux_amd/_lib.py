@@ -100,6 +100,13 @@ class LoraPackArgs(C.Structure):
     ]
 
 
+class CondLoraArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("B", C.c_int32), ("K", C.c_int32), ("apply_silu", C.c_int32), ("na", C.c_int32), ("r", C.c_int32),
+                ("N", C.c_int32), ("A", C.c_void_p), ("Bm", C.c_void_p), ("scale", C.c_void_p), ("u", C.c_void_p),
+                ("y", C.c_void_p), ("ldy", C.c_int64), ("g", C.c_void_p), ("ldg", C.c_int64), ("dA", C.c_void_p), ("dB", C.c_void_p),
+                ("du", C.c_void_p), ("dx", C.c_void_p)]
+
+
 class ProdigyArgs(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("s", C.c_void_p),
                 ("p0", C.c_void_p), ("n", C.c_int64), ("state", C.c_void_p),
@@ -154,6 +161,10 @@ SYMBOLS = {
     "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "qfx_mod_gemv_t": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "qfx_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f, _f, _vp, _vp]),
+    "qfx_cond_lora_fwd": (C.c_int, [C.POINTER(CondLoraArgs), _vp]),
+    "qfx_cond_lora_bwd": (C.c_int, [C.POINTER(CondLoraArgs), _vp]),
+    "qfx_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "qfx_silu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "qfx_add3_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "qfx_qk_norm_rope_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _i64, _vp]),
     "qfx_qk_norm_rope_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f, _i32, _i64, _vp]),

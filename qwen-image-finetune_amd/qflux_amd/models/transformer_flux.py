@@ -377,11 +377,23 @@ class _FluxPlan(_QwenPlan):
         A["A2"] = buf(B * S, 4 * D + 3 * kext_s + kext_m, zero=True)   # [d(mlp pre-act) | LoRA v ext (q,k,v) | LoRA v ext (proj_mlp)] : A operand, segment 2 of the dX GEMM
         self.cond = model.cond_lora
         if self.cond:
-            from ..cond_torch import CondHead
-            self.cond_head = CondHead()
+            from ..cond_hip import CondHeadHip
             A["dmods"] = buf(max(2 * Ld, 1), B, 6 * D, dtype=F32, zero=True)
             A["dsmods"] = buf(max(Ls, 1), B, 3 * D, dtype=F32, zero=True)
             A["dmod_out"] = buf(1, B, 2 * D, dtype=F32, zero=True)
+            te = model.time_text_embed
+            chains = [(te.timestep_embedder.linear_1, te.timestep_embedder.linear_2, A["tproj"], A["t1"], A["t2"])]
+            if cfg.guidance_embeds:
+                chains.append((te.guidance_embedder.linear_1, te.guidance_embedder.linear_2, A["gproj"], A["g1"], A["g2"]))
+            chains.append((te.text_embedder.linear_1, te.text_embedder.linear_2, A["pooled"], A["p1"], A["p2"]))
+            banks = []
+            if Ld:
+                banks.append(([m for blk in model.transformer_blocks for m in (blk.norm1.linear, blk.norm1_context.linear)],
+                              A["mods"], A["dmods"]))
+            if Ls:
+                banks.append(([blk.norm.linear for blk in model.single_transformer_blocks], A["smods"], A["dsmods"]))
+            banks.append(([model.norm_out.linear], A["mod_out"], A["dmod_out"]))
+            self.cond_head = CondHeadHip(model, B, D, chains=chains, temb=A["temb"], banks=banks, buf=buf)
             for bb in A["blk"]:
                 bb["y1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
                 bb["y2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
@@ -420,13 +432,10 @@ class _FluxPlan(_QwenPlan):
         eps = 1e-6
         # ---- temb = time_emb(+ guidance_emb) + pooled text emb   (CombinedTimestep(Guidance)TextProjEmbeddings)
         p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1.0, 1000.0, _ptr(A["tproj"]))
-        if self.cond:   # adapters on the conditioning head: library GEMVs under autograd (cond_torch.py)
-            from ..cond_torch import flux_head
+        if self.cond:   # adapters on the conditioning head: base GEMVs + the banks' rank-r launches (cond_hip.py)
             if cfg.guidance_embeds:
                 p.c(lib.qfx_timestep_embed, _ptr(A["gd"]), B, 256, 1.0, 1000.0, _ptr(A["gproj"]))
-            p.py(lambda: self.cond_head.run(
-                lambda: flux_head(model, A["tproj"], A["gproj"] if cfg.guidance_embeds else None, A["pooled"]),
-                [A["mods"] if Ld else None, A["smods"] if Ls else None, A["mod_out"]]))
+            self.cond_head.emit_forward(p)
         else:
             self._cond_hip(p, P)
         self._build_forward_body(P)
@@ -625,7 +634,7 @@ class _FluxPlan(_QwenPlan):
             self._site_bwd(p, P["x_in"], A["site"]["x_in"], A["dX"]["img"][dcur], D, rows["img"], A["in_img"], cfg.in_channels)
             self._site_bwd(p, P["c_in"], A["site"]["c_in"], A["dX"]["txt"][dcur], D, rows["txt"], A["in_txt"], P["c_in"].K)
         if self.cond:
-            p.py(lambda: self.cond_head.backward([A["dmods"] if Ld else None, A["dsmods"] if Ls else None, A["dmod_out"]]))
+            self.cond_head.emit_backward(p)
 
     def _emit_single_bwd(self, p, w, bb, a, mod, x, dJ_out, dJ_in, i, Ld):
         """In: dJ_out = d(block output) [B*S,D], A["dyg_j"] = gate*dJ_out.  Out: dJ_in and A["dyg_j"] = gate_prev*dJ_in

@@ -317,7 +317,7 @@ class QwenImageTransformer2DModel(nn.Module):
     # embedders / output projection: plain GEMM sites outside the blocks (K-extension + the two rank-r gradient launches)
     _HEAD_SITES = {"img_in": "img_in", "txt_in": "txt_in", "proj_out": "proj_out"}      # module name -> key in the prepared weights
 
-    # conditioning head (M = batch rows): timestep embedder, AdaLN modulation linears -- evaluated by cond_torch when adapted
+    # conditioning head (M = batch rows): timestep embedder, AdaLN modulation linears -- cond_hip.py when adapted
     _COND_SUFFIXES = ("timestep_embedder.linear_1", "timestep_embedder.linear_2", "img_mod.1", "txt_mod.1", "norm_out.linear")
 
     def _lora_supported(self, name: str) -> bool:
@@ -334,7 +334,7 @@ class QwenImageTransformer2DModel(nn.Module):
 
     @property
     def cond_lora(self) -> bool:
-        """True when a linear of the conditioning head carries an adapter (the head then runs through cond_torch)."""
+        """True when a linear of the conditioning head carries an adapter (the head is then emitted by cond_hip.CondHeadHip)."""
         return any(isinstance(m, QfxLoraLinear) for m in self._cond_modules())
 
     def set_adapter(self, adapter_name):
@@ -660,10 +660,14 @@ class _QwenPlan:
         self._alloc_double_scratch(P["blocks"])
         self.cond = model.cond_lora
         if self.cond:
-            from ..cond_torch import CondHead
-            self.cond_head = CondHead()
+            from ..cond_hip import CondHeadHip
             A["dmods"] = buf(2 * Lyr, B, 6 * D, dtype=F32, zero=True)
             A["dmod_out"] = buf(1, B, 2 * D, dtype=F32, zero=True)
+            te = model.time_text_embed.timestep_embedder
+            self.cond_head = CondHeadHip(
+                model, B, D, chains=[(te.linear_1, te.linear_2, A["tproj"], A["t1"], A["temb"])], temb=A["temb"],
+                banks=[([m for blk in model.transformer_blocks for m in (blk.img_mod[1], blk.txt_mod[1])], A["mods"], A["dmods"]),
+                       ([model.norm_out.linear], A["mod_out"], A["dmod_out"])], buf=buf)
             for bb in A["blk"]:    # pre-gate outputs of the two gated linears of a block (d gate = sum_rows dx_out * y)
                 bb["y1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
                 bb["y2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
@@ -1120,9 +1124,8 @@ class _QwenPlan:
         eps = 1e-6
         # head: timestep embedding -> temb ; img_in ; txt_norm + txt_in ; all modulation vectors in one GEMV launch
         p.c(lib.qfx_timestep_embed, _ptr(A["t"]), B, 256, 1000.0, 1.0, _ptr(A["tproj"]))
-        if self.cond:   # adapters on the conditioning head: library GEMVs under autograd (cond_torch.py)
-            from ..cond_torch import qwen_head
-            p.py(lambda: self.cond_head.run(lambda: qwen_head(model, A["tproj"]), [A["mods"], A["mod_out"]]))
+        if self.cond:   # adapters on the conditioning head: base GEMVs + the banks' rank-r launches (cond_hip.py)
+            self.cond_head.emit_forward(p)
         else:
             p.c(lib.qfx_mod_gemv, _ptr(A["tproj"]), B, 256, _ptr(P["t1_Wp"]), _ptr(P["t1_bp"]), 1, D, 0, _ptr(A["t1"]))
             p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
@@ -1330,7 +1333,7 @@ class _QwenPlan:
             self._site_bwd(p, P["img_in"], A["site"]["img_in"], A["dX"]["img"][cur], D, rows["img"], A["in_img"], cfg.in_channels)
             self._site_bwd(p, P["txt_in"], A["site"]["txt_in"], A["dX"]["txt"][cur], D, rows["txt"], A["txt_n"], cfg.joint_attention_dim)
         if self.cond:
-            p.py(lambda: self.cond_head.backward([A["dmods"], A["dmod_out"]]))
+            self.cond_head.emit_backward(p)
 
     def _emit_double_bwd(self, p, w, bb, a, mods, x_in, dx2, out_dx, gate_prev, last, first, norm_flags, prefix=None, par=0, dmods=None):
         """Backward of one double-stream block.  In: dx2[s] = d(block output), A["dyg2"][s] = gate2*dx2 (emitted by whoever

@@ -85,7 +85,7 @@ def test_ctypes_structs_match_the_c_header_layout(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = {"qfx_gemm_args": L.GemmArgs, "qfx_lora_down_args": L.LoraDownArgs, "qfx_lora_grad_args": L.LoraGradArgs,
              "qfx_lora_pack_args": L.LoraPackArgs, "qfx_attn_args": L.AttnArgs, "qfx_ln_fwd_args": L.LnFwdArgs, "qfx_ln_bwd_args": L.LnBwdArgs,
-             "qfx_prodigy_args": L.ProdigyArgs}
+             "qfx_prodigy_args": L.ProdigyArgs, "qfx_cond_lora_args": L.CondLoraArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "qfx.h"', "int main(void) {"]
     for cname, ct in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')

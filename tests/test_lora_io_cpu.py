@@ -29,7 +29,7 @@ def test_adapter_names_and_trainable_filter():
     names = f.add_adapter(LoraConfig(r=8, lora_alpha=8, target_modules=".*attn[.]to_[qkv]"), "a")
     assert len(names) == 3 * (FLUX_TINY["num_layers"] + FLUX_TINY["num_single_layers"])
     # every Linear of the DiT can carry an adapter (target_modules "all-linear", configs/example_with_sampling.yaml:9): the
-    # conditioning-head linears switch the head to the autograd evaluation (cond_torch.py)
+    # conditioning-head linears switch the head to the adapted launch sequence (cond_hip.py)
     q2, f2 = _models()
     assert not q2.cond_lora
     names = q2.add_adapter(LoraConfig(r=4, target_modules="all-linear"), "b")

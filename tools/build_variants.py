@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "qwen-image-finetune_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_ab")
-SOURCES = ["qfx_gemm.hip", "qfx_gemm_fp8.hip", "qfx_skinny.hip", "qfx_elem.hip", "qfx_attn.hip"]
+SOURCES = ["qfx_gemm.hip", "qfx_gemm_fp8.hip", "qfx_skinny.hip", "qfx_elem.hip", "qfx_attn.hip", "qfx_cond.hip"]
 
 
 def main():
