@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch2", action="store_true", help="skip the secondary per-GPU-batch-2 measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the secondary MX-FP8 trunk measurement")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the secondary drop-in (autograd + torch optimizer) measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args.gpus))
@@ -303,6 +304,7 @@ def main():
     # ---- data-parallel exchange: what the bucketed all-reduce costs on top of the step, and how much of it the backward hides
     dp = None
     if world > 1:
+        replicas_ok = bool(step.check_replicas())   # adapter weights + optimizer state identical on every rank after the timed steps
         gflat = dit.lora_store.gflat
         k2 = max(2, min(args.steps, 10))
         step.world = 1                      # same step without the gradient exchange (measurement only: replicas would diverge)
@@ -325,6 +327,7 @@ def main():
         noex, alone = vals.tolist()
         exposed = max(0.0, ms_per_step - noex)
         dp = {"collective": "all_reduce(SUM) of the flat fp32 LoRA gradient, bucketed behind the backward", "backend": dist.get_backend(),
+              "ranks": dist.get_world_size(), "replicas_checked": replicas_ok,
               "bytes_per_step": gflat.numel() * 4, "bucket_mb": step.bucket_bytes / (1 << 20),
               "ms_per_step_without_exchange": round(noex, 3), "allreduce_alone_ms": round(alone, 3),
               "exposed_ms_per_step": round(exposed, 3), "hidden_ms_per_step": round(max(0.0, alone - exposed), 3)}
@@ -357,6 +360,35 @@ def main():
     }
     if dp is not None:
         out["dp_exchange"] = dp
+    if world == 1 and B == 1 and not args.no_dropin:
+        # secondary line: the DROP-IN path a reference user gets after the two-line swap of INTEGRATION.md -- the reference's own
+        # loop body (base_trainer.py:508-561): loss = criterion(dit(...)[0]); loss.backward(); clip_grad_norm_(trainable, 1.0);
+        # torch.optim.AdamW.step(); zero_grad() -- autograd node around the same launch programs, torch's optimizer over the per-tensor
+        # LoRA parameters (views of the flat buffer)
+        params = dit.lora_parameters()
+        opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+        def dropin_step():
+            l = step.compute_loss(emb)
+            l.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            opt.zero_grad()
+            return l
+        for _ in range(3):
+            dropin_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nd = max(4, min(args.steps, 10))
+        for _ in range(nd):
+            dropin_step()
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t1
+        out["dropin_autograd"] = {"value": round(nd / dtd, 4), "unit": "images/s", "ms_per_step": round(dtd / nd * 1e3, 3), "steps": nd,
+                                  "vs_fused_step": round((dtd / nd * 1e3) / ms_per_step, 4),
+                                  "note": "dit(...)[0] -> MSE -> loss.backward() -> clip_grad_norm_ -> torch.optim.AdamW.step() -> zero_grad(), "
+                                          "the reference's loop body (base_trainer.py:508-561) on the drop-in module; `value` above is the fused step"}
+        del opt
+        step.zero_grad()
     if world == 1 and B == 1 and not args.no_batch2:
         # secondary line: the reference's own default micro-batch for this config is 2 (configs/face_seg_config.yaml:31, and its
         # README numbers are quoted at bs 2).  At B=2 every GEMM runs >= 2 rounds per CU, so the per-launch fixed cost (pipeline

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QFX_ABI_VERSION 2
+#define QFX_ABI_VERSION 3
 
 #define QFX_OK 0
 #define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
@@ -376,6 +376,10 @@ int qfx_flowmatch_prepare(const uint16_t* x0, const uint16_t* noise, const uint1
 /* ---- fused global-norm clip + AdamW over the flat LoRA parameter buffer ----------------------
  * (base_trainer.py:449-455 clip_grad_norm_ ; optimizer.step :531 with torch.optim.AdamW semantics) */
 int qfx_sumsq(const float* g, int64_t n, float* out /* zeroed by caller */, void* stream);
+/* Deterministic form (ABI 3): block partial sums into `partials` (fp32[nslots], caller workspace, e.g. 1024), folded by one block in
+ * a fixed order into out[0] (overwritten).  Same inputs -> same bits: data-parallel replicas (identical gradients after the
+ * all-reduce) compute the SAME clip coefficient; qfx_sumsq's fp32 atomics let them drift apart by ~1e-10 per step. */
+int qfx_sumsq_det(const float* g, int64_t n, float* out, float* partials, int32_t nslots, void* stream);
 int qfx_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float bias_corr1, float bias_corr2,
                    const float* gnorm_sq /* may be NULL */, float max_norm, float grad_scale, void* stream);

@@ -730,6 +730,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// Deterministic form: per-block partial sums in a fixed slot each, folded by ONE block in a fixed order.  Data-parallel replicas
+// hold bit-identical gradients after the all-reduce; with the atomic form above the clip coefficient differed in its last bits
+// from rank to rank (fp32 atomics commute only approximately) and the replicas drifted apart by ~1e-10 per step.
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += g[i] * g[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2, const float* __restrict__ gnorm_sq,
@@ -1143,6 +1165,16 @@ extern "C" int qfx_sumsq(const float* g, int64_t n, float* out, void* stream) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_sumsq_det(const float* g, int64_t n, float* out, float* partials, int32_t nslots, void* stream) {
+  if (!g || !out || !partials || n <= 0 || nslots <= 0) return QFX_EINVAL;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > nslots) blocks = nslots;
+  hipLaunchKernelGGL(sumsq_part_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n, partials);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)blocks, out);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

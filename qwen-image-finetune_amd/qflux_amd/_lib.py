@@ -132,7 +132,7 @@ class AttnArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 2        # QFX_ABI_VERSION
+ABI_VERSION = 3        # QFX_ABI_VERSION
 MAX_BATCH = 8          # QFX_MAX_BATCH
 MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
@@ -177,6 +177,7 @@ SYMBOLS = {
     "qfx_mse_token_weighted_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _f, _vp]),
     "qfx_flowmatch_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "qfx_sumsq": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "qfx_sumsq_det": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp]),
     "qfx_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp, _f, _f, _vp]),
     "qfx_prodigy_init_state": (C.c_int, [_vp, C.c_double, _vp]),
     "qfx_prodigy_step": (C.c_int, [C.POINTER(ProdigyArgs), _vp]),

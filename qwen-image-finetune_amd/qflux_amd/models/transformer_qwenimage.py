@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from ..dp import DataParallelMixin
 from ..plan_cache import PlanCache, ladder
 from ..modules import (LoraConfig, LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm, init_lora_, match_target)
 from ..rope import QwenEmbedRope, normalize_img_shapes, qwen_joint_rope
@@ -159,7 +160,7 @@ def _ptr(t):
 
 
 # ----------------------------------------------------------------------------------------------
-class QwenImageTransformer2DModel(nn.Module):
+class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
     """See module docstring.  Reference: transformer_qwenimage.py:497-672."""
 
     _supports_gradient_checkpointing = True
@@ -1606,5 +1607,5 @@ class _QwenDiTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.plan.run_backward(grad_out.contiguous())
+        ctx.plan.model._dp_backward(ctx.plan, grad_out.contiguous())     # + the data-parallel exchange when enabled (dp.py)
         return (None,) * len(ctx.needs_input_grad)

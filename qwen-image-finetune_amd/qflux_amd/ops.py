@@ -259,6 +259,11 @@ def sumsq(g, out):
     L.check(lib.qfx_sumsq(_p(g), g.numel(), _p(out), stream_ptr()), "qfx_sumsq")
 
 
+def sumsq_det(g, out, partials):
+    """Deterministic sum of squares (fixed reduction order): out[0] is overwritten; partials = fp32 workspace."""
+    L.check(lib.qfx_sumsq_det(_p(g), g.numel(), _p(out), _p(partials), partials.numel(), stream_ptr()), "qfx_sumsq_det")
+
+
 _side_streams = {}
 
 

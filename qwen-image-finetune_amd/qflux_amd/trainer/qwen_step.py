@@ -260,7 +260,10 @@ class QwenLoraTrainStep:
                 for w in self._pending:
                     w.wait()
                 self._pending = []
-            else:   # no bucketed backward ran (drop-in autograd path): one all-reduce of the whole flat buffer
+            else:   # no bucketed backward of THIS object ran (drop-in autograd path)
+                dp = getattr(self.dit, "_dp", None)
+                if dp is not None and dp.enabled:
+                    return 1.0      # dit.enable_data_parallel(): loss.backward() already exchanged (overlapped) and averaged (dp.py)
                 dist.all_reduce(self.dit.lora_store.gflat, op=dist.ReduceOp.SUM, group=self.group)
             return 1.0 / self.world
         return 1.0
@@ -272,8 +275,9 @@ class QwenLoraTrainStep:
             self._v = torch.zeros_like(st.pflat)
             self._gnorm = torch.zeros((), dtype=torch.float32, device=st.pflat.device)
         self.global_step += 1
-        self._gnorm.zero_()
-        ops.sumsq(st.gflat, self._gnorm)
+        if getattr(self, "_gparts", None) is None or self._gparts.device != st.pflat.device:
+            self._gparts = torch.zeros(1024, dtype=torch.float32, device=st.pflat.device)
+        ops.sumsq_det(st.gflat, self._gnorm, self._gparts)     # fixed reduction order: every replica computes the same clip coefficient
         if self.optimizer == "prodigy":
             if self._pstate is None or self._ps.numel() != st.pflat.numel():
                 self._ps = torch.zeros_like(st.pflat)
