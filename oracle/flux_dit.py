@@ -357,3 +357,35 @@ def flux_compute_loss(dit: nn.Module, emb: dict, noise: torch.Tensor, t: torch.T
     target = noise - x0
     loss = F.mse_loss(pred, target.to(pred.dtype), reduction="mean")   # MseLoss with weighting=None (mse_loss.py:68-70)
     return (loss, pred) if return_pred else loss
+
+
+def flux_sample(dit: nn.Module, emb: dict, dtype: torch.dtype):
+    """FluxKontextLoraTrainer.sampling_from_embeddings (flux_kontext_trainer.py:902-976) with the initial latents injected; scheduler =
+    restated FlowMatchEulerDiscreteScheduler (dynamic exponential shift; base_trainer.py:1009-1043).  Test infrastructure."""
+    import math
+    steps, cfg = int(emb["num_inference_steps"]), float(emb.get("true_cfg_scale", 1.0))
+    do_cfg = cfg > 1.0 and "negative_pooled_prompt_embeds" in emb
+    ctrl, latents = emb["control_latents"].to(dtype), emb["latents"].to(dtype)
+    ids = torch.cat([emb["latent_ids"], emb["control_ids"]], dim=0)
+    B, n = latents.shape[0], latents.shape[1]
+    sig = torch.linspace(1.0, 1.0 / steps, steps, dtype=torch.float64)
+    m = (1.15 - 0.5) / (4096 - 256)
+    mu = n * m + (0.5 - m * 256)
+    sig = (math.exp(mu) / (math.exp(mu) + (1.0 / sig - 1.0))).to(torch.float32)
+    ts = sig * 1000
+    sig = torch.cat([sig, torch.zeros(1)])
+    guidance = torch.full([B], float(emb.get("guidance", 1.0)), dtype=torch.float32) if getattr(dit, "guidance_embeds", False) else None
+    with torch.no_grad():
+        for i, t in enumerate(ts):
+            x = torch.cat([latents, ctrl], dim=1)
+            tt = t.expand(B).to(dtype) / 1000
+            pred = dit(hidden_states=x, timestep=tt, guidance=guidance, pooled_projections=emb["pooled_prompt_embeds"].to(dtype),
+                       encoder_hidden_states=emb["prompt_embeds"].to(dtype), txt_ids=emb["text_ids"], img_ids=ids,
+                       joint_attention_kwargs={}, return_dict=False)[0][:, :n]
+            if do_cfg:
+                neg = dit(hidden_states=x, timestep=tt, guidance=guidance, pooled_projections=emb["negative_pooled_prompt_embeds"].to(dtype),
+                          encoder_hidden_states=emb["negative_prompt_embeds"].to(dtype), txt_ids=emb["negative_text_ids"], img_ids=ids,
+                          joint_attention_kwargs={}, return_dict=False)[0][:, :n]
+                pred = neg + cfg * (pred - neg)
+            latents = (latents.to(torch.float32) + (float(sig[i + 1]) - float(sig[i])) * pred.to(torch.float32)).to(pred.dtype)
+    return latents

@@ -134,3 +134,57 @@ class QwenSampler:
                 pred = comb * (cond_norm / noise_norm)
             latents = self.schedule.step(pred, float(sig[i]), float(sig[i + 1]), latents)
         return latents
+
+
+class FluxSampler:
+    """FLUX-Kontext validation / sampling loop on the training launch programs (inference mode, LoRA applied).
+
+    Mirrors FluxKontextLoraTrainer.sampling_from_embeddings (src/qflux/trainer/flux_kontext_trainer.py:902-976): guidance-
+    distilled Euler flow-match loop -- `guidance` embedded every step, timestep = bf16(t) / 1000, control tokens concatenated
+    behind the latents, ids = [latent ids | control ids]; optional true CFG WITHOUT the norm rescale of the Qwen loop
+    (`neg + s * (pred - neg)`, :965); scheduler as QwenSampler (prepare_predict_timesteps, base_trainer.py:1009-1043)."""
+
+    def __init__(self, dit, weight_dtype=BF, schedule: FlowMatchEulerSchedule | None = None, scheduler_config=None):
+        self.dit = dit
+        self.weight_dtype = weight_dtype
+        if schedule is None:
+            schedule = FlowMatchEulerSchedule.from_config(scheduler_config) if scheduler_config is not None else FlowMatchEulerSchedule()
+        self.schedule = schedule
+
+    @torch.inference_mode()
+    def sample(self, embeddings: dict) -> torch.Tensor:
+        """embeddings: latents [B,S_t,64] + latent_ids [S_t,3] (initial noise, packed), control_latents [B,S_c,64], control_ids
+        [S_c,3], pooled_prompt_embeds [B,P], prompt_embeds [B,T,J], text_ids [T,3], guidance, num_inference_steps,
+        true_cfg_scale and, for true CFG, negative_pooled_prompt_embeds / negative_prompt_embeds / negative_text_ids.
+        Returns the final packed latents [B,S_t,64]."""
+        dit, dev, dt = self.dit, self.dit.device, self.weight_dtype
+        steps = int(embeddings["num_inference_steps"])
+        cfg = float(embeddings.get("true_cfg_scale", 1.0))
+        do_cfg = cfg > 1.0 and "negative_pooled_prompt_embeds" in embeddings
+        ctrl = embeddings["control_latents"].to(dev, dtype=dt)
+        latents = embeddings["latents"].to(dev, dtype=dt)
+        ids = torch.cat([embeddings["latent_ids"].float().cpu(), embeddings["control_ids"].float().cpu()], dim=0)
+        B, n = latents.shape[0], latents.shape[1]
+        pooled = embeddings["pooled_prompt_embeds"].to(dev, dtype=dt)
+        pe = embeddings["prompt_embeds"].to(dev, dtype=dt)
+        txt_ids = embeddings["text_ids"].float().cpu()
+        guidance = None
+        if dit.config.guidance_embeds:
+            guidance = torch.full([B], float(embeddings.get("guidance", 1.0)), device=dev, dtype=torch.float32)
+        if do_cfg:
+            npooled = embeddings["negative_pooled_prompt_embeds"].to(dev, dtype=dt)
+            npe = embeddings["negative_prompt_embeds"].to(dev, dtype=dt)
+            ntxt_ids = embeddings["negative_text_ids"].float().cpu()
+        timesteps = self.schedule.set_timesteps(steps, n)
+        sig = self.schedule.sigmas
+        for i, t in enumerate(timesteps):
+            x = torch.cat([latents, ctrl], dim=1)
+            ts = (t.expand(B).to(dt) / 1000).to(dev)
+            pred = dit(hidden_states=x, timestep=ts, guidance=guidance, pooled_projections=pooled, encoder_hidden_states=pe,
+                       txt_ids=txt_ids, img_ids=ids, joint_attention_kwargs={}, return_dict=False)[0][:, :n]
+            if do_cfg:
+                neg = dit(hidden_states=x, timestep=ts, guidance=guidance, pooled_projections=npooled, encoder_hidden_states=npe,
+                          txt_ids=ntxt_ids, img_ids=ids, joint_attention_kwargs={}, return_dict=False)[0][:, :n]
+                pred = neg + cfg * (pred - neg)
+            latents = self.schedule.step(pred, float(sig[i]), float(sig[i + 1]), latents)
+        return latents

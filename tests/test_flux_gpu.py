@@ -270,3 +270,45 @@ def test_flux_all_linear_targets():
     assert res["ok"], res
     res = run_flux_step_parity(DEV, verbose=True, hw=(4, 6), T=7, B=1, r=4, targets="all-linear", guidance=False, fused=False)
     assert res["ok"], res
+
+
+@pytest.mark.parametrize("true_cfg", [1.0, 3.0])
+def test_flux_sampling_loop_matches_oracle(true_cfg):
+    """f4: FLUX-Kontext validation sampler (flux_kontext_trainer.py:902-976) -- 4 guidance-distilled Euler steps, optional true CFG
+    without norm rescale -- on the training launch programs (inference mode, LoRA applied) vs the oracle's restatement."""
+    from common import FLUX_TINY, fill_weights
+    from oracle import flux_dit as FO
+    from oracle import qwen_dit as O
+    from qflux_amd.models import FluxTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.sampling import FluxSampler
+    cfg = dict(FLUX_TINY, guidance_embeds=True, joint_attention_dim=64)
+    oracle = FO.OracleFluxDiT(**cfg)
+    O.add_lora(oracle, r=4, lora_alpha=8, adapter_name="a")
+    fill_weights(oracle, seed=6)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    with torch.device(DEV):
+        hip = FluxTransformer2DModel(**cfg)
+    hip.add_adapter(LoraConfig(r=4, lora_alpha=8), "a")
+    hip.load_state_dict(oracle.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(9)
+    B, h, w, T = 2, 4, 6, 7
+    S_t = h * w
+    lat_ids = FO.prepare_latent_image_ids(h, w)
+    ctl_ids = FO.prepare_latent_image_ids(h, w)
+    ctl_ids[:, 0] = 1
+    emb = dict(latents=torch.randn(B, S_t, 64, generator=g), latent_ids=lat_ids, control_latents=torch.randn(B, S_t, 64, generator=g).half().float(),
+               control_ids=ctl_ids, pooled_prompt_embeds=torch.randn(B, cfg["pooled_projection_dim"], generator=g).half().float(),
+               prompt_embeds=torch.randn(B, T, 64, generator=g).half().float(), text_ids=torch.zeros(T, 3), guidance=2.5,
+               num_inference_steps=4, true_cfg_scale=true_cfg)
+    if true_cfg > 1.0:
+        emb.update(negative_pooled_prompt_embeds=torch.randn(B, cfg["pooled_projection_dim"], generator=g).half().float(),
+                   negative_prompt_embeds=torch.randn(B, T, 64, generator=g).half().float(), negative_text_ids=torch.zeros(T, 3))
+    ref = FO.flux_sample(oracle, emb, BF)
+    out = FluxSampler(hip).sample(emb)
+    rel = ((out.float().cpu() - ref.float()).abs().max() / ref.float().abs().max()).item()
+    print(f"flux sampling 4 steps, true_cfg {true_cfg}: rel", rel)
+    assert out.shape == ref.shape and rel < 3e-2
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for n, p in hip.named_parameters() if "lora" in n)
