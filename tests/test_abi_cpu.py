@@ -75,6 +75,24 @@ def test_lr_schedules_host_logic():
     assert get_scheduler("constant")(7) == 1.0
 
 
+def test_optimizer_config_mapping_host_logic():
+    """optimizer.class_path / init_args of the reference's YAMLs (base_trainer.py:884-909) -> fused-step keyword arguments:
+    every optimizer block that occurs under /root/reference/configs is covered (values copied as data, not the files)."""
+    from qflux_amd.trainer import optimizer_kwargs_from_config as f
+    # configs/face_seg_config.yaml:56-59 (and 13 more YAMLs): Adam8bit -> Adam with fp32 moments, no weight decay
+    kw = f("bitsandbytes.optim.Adam8bit", {"lr": 1e-4, "betas": [0.9, 0.999]})
+    assert kw == {"lr": 1e-4, "betas": (0.9, 0.999), "optimizer": "adam8bit", "weight_decay": 0.0}
+    kw = f("torch.optim.AdamW", {"lr": 1e-4, "weight_decay": 0.01, "betas": [0.9, 0.999], "eps": 1e-8})
+    assert kw["optimizer"] == "adamw" and kw["weight_decay"] == 0.01 and kw["eps"] == 1e-8
+    # configs/face_seg_flux_kontext_fp16_prodigy.yaml:41-47
+    kw = f("prodigyopt.Prodigy", {"lr": 1.0, "use_bias_correction": True, "safeguard_warmup": True, "weight_decay": 0.01})
+    assert kw["optimizer"] == "prodigy" and kw["optimizer_args"] == {"use_bias_correction": True, "safeguard_warmup": True} and kw["lr"] == 1.0
+    with pytest.raises(NotImplementedError):
+        f("torch.optim.SGD", {"lr": 0.1})
+    with pytest.raises(NotImplementedError):
+        f("torch.optim.AdamW", {"lr": 1e-4, "maximize": True})
+
+
 def test_ctypes_structs_match_the_c_header_layout(tmp_path):
     """Compile include/qfx.h with gcc and compare sizeof / field offsets of every argument struct with the ctypes mirrors
     (an ABI drift between the header and qflux_amd/_lib.py would otherwise only show up as wrong results on the GPU)."""

@@ -625,6 +625,54 @@ def test_adamw_matches_torch():
     check("adamw", p, p_ref.detach(), 1e-5)
 
 
+def test_adam8bit_alias_is_adam_with_fp32_moments_and_deterministic_norm():
+    """optimizer="adam8bit" (what most of the reference's YAMLs select: bitsandbytes.optim.Adam8bit(lr, betas)) = Adam without
+    weight decay and with FP32 moments -- equal to torch.optim.Adam + clip_grad_norm_ on the same gradients; the global norm uses
+    the deterministic reduction (same bits on every call, hence on every data-parallel replica)."""
+    import torch.nn as nn
+    from qflux_amd.modules import LoraStore, QfxLinear, QfxLoraLinear
+    from qflux_amd.trainer import QwenLoraTrainStep, optimizer_kwargs_from_config
+    ops = _ops()
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            with torch.device(DEV):
+                self.a = QfxLoraLinear(QfxLinear(256, 192), 16, 16, "ad")
+                self.b = QfxLoraLinear(QfxLinear(192, 320), 16, 16, "ad")
+            self._store = LoraStore(self)
+            self._store.rebuild(DEV)
+            self.device = torch.device(DEV)
+
+        @property
+        def lora_store(self):
+            return self._store
+
+    toy = Toy()
+    st = toy.lora_store
+    with torch.no_grad():
+        st.pflat.copy_(randn(st.pflat.numel(), seed=3).to(DEV) * 0.1)
+    step = QwenLoraTrainStep(toy, max_grad_norm=1.0, **optimizer_kwargs_from_config("bitsandbytes.optim.Adam8bit", {"lr": 1e-3, "betas": [0.9, 0.999]}))
+    assert step.optimizer == "adamw" and step.optimizer_alias == "adam8bit" and step.weight_decay == 0.0
+    ref = [p.detach().clone().cpu().requires_grad_(True) for _, p in st.params()]
+    opt = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for k in range(1, 4):
+        g = randn(st.gflat.numel(), seed=10 + k) * k
+        st.gflat.copy_(g.to(DEV))
+        for (_, p, off, n), r in zip(st.entries, ref):
+            r.grad = g[off:off + n].view(r.shape).clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step()
+        step.optimizer_step()
+    for (_, p, off, n), r in zip(st.entries, ref):
+        check("adam8bit_alias", p.detach(), r.detach(), 1e-5)
+    # the deterministic norm: identical bits on repeated evaluation, equal to the fp64 sum to fp32 accuracy
+    gd = (randn(3_000_001, seed=5) * 2).to(DEV)
+    o1, o2, parts = torch.zeros((), device=DEV), torch.zeros((), device=DEV), torch.zeros(1024, device=DEV)
+    ops.sumsq_det(gd, o1, parts); ops.sumsq_det(gd, o2, parts)
+    assert torch.equal(o1, o2) and abs(o1.item() - gd.double().pow(2).sum().item()) / o1.item() < 1e-5
+
+
 @pytest.mark.parametrize("D,rows,R,rpb", [(256, 100, 16, 50), (1024, 77, 48, 77), (3072, 2048, 48, 2048), (3072, 2432, 16, 1216)])
 def test_ln_down_fused_matches_the_two_separate_launches(D, rows, R, rpb):
     """qfx_ln_down_fwd == qfx_ln_modulate_fwd followed by qfx_lora_down (K-extension image, transposed split image, y)."""
