@@ -344,6 +344,14 @@ typedef struct qfx_attn_args {
   uint16_t* dQ; uint16_t* dK; uint16_t* dV; int64_t lddq; int64_t lddk; int64_t lddv;
   const float* key_mask;
   int32_t B; int32_t S; int32_t S_pad; int32_t H; int32_t dh; float scale;
+  /* ABI 3: backward of the QK RMSNorm + RoPE (transformer_qwenimage.py:305-320) fused into the EPILOGUES of qfx_attn_bwd_dq / _dkv
+   * when qk_saved != NULL: the kernels then write d(pre-norm q) / d(pre-norm k) instead of d(q) / d(k) -- the arithmetic of
+   * qfx_qk_norm_rope_bwd on the bf16-rounded attention gradient, same rounding points (norm_flags as there), without the extra
+   * pass over dqkv.  qk_saved: the pre-norm q | k copy [B,S,2*H*dh] qfx_qk_norm_rope_fwd kept (row stride ld_saved, q at +0, k at
+   * +H*dh); rope [S, dh/2, 2] fp32 (+ b * rope_bstride); weights [dh] bf16, *_txt for rows s < T. */
+  const uint16_t* qk_saved; int64_t ld_saved; const float* rope; int64_t rope_bstride;
+  const uint16_t* wq_txt; const uint16_t* wk_txt; const uint16_t* wq_img; const uint16_t* wk_img;
+  int32_t T; int32_t norm_flags; float norm_eps;
 } qfx_attn_args;
 
 int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,V -> O,lse2 */

@@ -293,6 +293,56 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const qfx_attn_args a) {
   }
 }
 
+
+// Backward of QK RMSNorm + RoPE on one gradient row held in the 16x16 accumulator layout (lane (g, li): row li of fragment f,
+// columns 16 d + 4 g + r): the arithmetic of qk_norm_rope_kernel<DH, true> (qfx_elem.hip) on the bf16-rounded attention gradient
+//   dn = [rbf](rbf(dy * conj(rope)) * w) ;  xh = x * rstd ;  out = (dn - xh * mean(dn * xh)) * rstd
+// with the row statistics folded over the four lane groups by two shuffles.  x = the saved pre-norm row, out packed bf16 per d.
+template <int DH>
+__device__ __forceinline__ void norm_rope_bwd_row(const f32x4 (&acc)[DH / 16][2], int f, float out_scale, const bf16_t* xrow,
+                                                  const float* rrow, const bf16_t* wrow, float eps, int flags, u32x2 (&out)[DH / 16]) {
+  constexpr int DF = DH / 16;
+  float xh[DF][4], dn[DF][4];
+  float ss = 0.f;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    const u32x2 ux = *(const u32x2*)(xrow + d * 16);
+    xh[d][0] = __uint_as_float(ux[0] << 16); xh[d][1] = __uint_as_float(ux[0] & 0xffff0000u);
+    xh[d][2] = __uint_as_float(ux[1] << 16); xh[d][3] = __uint_as_float(ux[1] & 0xffff0000u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss += xh[d][r] * xh[d][r];
+  }
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float rstd = rsqrtf(ss / (float)DH + eps);
+  float dot = 0.f;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    const f32x4 cs = *(const f32x4*)(rrow + d * 16);            // (cos, sin) of the pairs (16 d + 4 g)/2 and +1
+    const u32x2 uw = *(const u32x2*)(wrow + d * 16);
+    const float w0 = __uint_as_float(uw[0] << 16), w1 = __uint_as_float(uw[0] & 0xffff0000u);
+    const float w2 = __uint_as_float(uw[1] << 16), w3 = __uint_as_float(uw[1] & 0xffff0000u);
+    const float e0 = rbf(acc[d][f][0] * out_scale), e1 = rbf(acc[d][f][1] * out_scale);
+    const float e2 = rbf(acc[d][f][2] * out_scale), e3 = rbf(acc[d][f][3] * out_scale);
+    const float d0 = rbf(e0 * cs[0] + e1 * cs[1]), d1 = rbf(-e0 * cs[1] + e1 * cs[0]);     // dy * conj(f)
+    const float d2 = rbf(e2 * cs[2] + e3 * cs[3]), d3 = rbf(-e2 * cs[3] + e3 * cs[2]);
+    dn[d][0] = (flags & 1) ? d0 * w0 : rbf(d0 * w0);
+    dn[d][1] = (flags & 1) ? d1 * w1 : rbf(d1 * w1);
+    dn[d][2] = (flags & 1) ? d2 * w2 : rbf(d2 * w2);
+    dn[d][3] = (flags & 1) ? d3 * w3 : rbf(d3 * w3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xh[d][r] *= rstd; dot += dn[d][r] * xh[d][r]; }
+  }
+  dot += __shfl_xor(dot, 16);
+  dot += __shfl_xor(dot, 32);
+  dot /= (float)DH;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    out[d][0] = pack2bf((dn[d][0] - xh[d][0] * dot) * rstd, (dn[d][1] - xh[d][1] * dot) * rstd);
+    out[d][1] = pack2bf((dn[d][2] - xh[d][2] * dot) * rstd, (dn[d][3] - xh[d][3] * dot) * rstd);
+  }
+}
+
 // =============================================================================================
 // dQ: block = 128 queries (4 waves x 32), loop over 64-key tiles (K, V row tiles + K^T column tile)
 template <int DH, int NW>   // NW as in attn_fwd_kernel
@@ -432,8 +482,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_kernel(c
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int q = q0 + f * 16 + li;
-    if (q < S) {
-      bf16_t* op = a.dQ + ((int64_t)b * S + q) * a.lddq + h * DH + 4 * g;
+    const int qc = q < S ? q : S - 1;       // rows past S compute on row S-1 (the shuffles below need every lane) and are not stored
+    bf16_t* op = a.dQ + ((int64_t)b * S + qc) * a.lddq + h * DH + 4 * g;
+    if (a.qk_saved) {       // block-uniform: d(pre-norm q) straight from the accumulators (QK RMSNorm + RoPE backward fused here)
+      u32x2 u[DF];
+      norm_rope_bwd_row<DH>(dq, f, a.scale, a.qk_saved + ((int64_t)b * S + qc) * a.ld_saved + h * DH + 4 * g,
+                            a.rope + (int64_t)b * a.rope_bstride + ((int64_t)qc * (DH / 2) + 2 * g) * 2,
+                            (qc < a.T ? a.wq_txt : a.wq_img) + 4 * g, a.norm_eps, a.norm_flags, u);
+      if (q < S) {
+#pragma unroll
+        for (int d = 0; d < DF; ++d) *(u32x2*)(op + d * 16) = u[d];
+      }
+    } else if (q < S) {
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
         u32x2 u;
@@ -637,15 +697,27 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    if (!keyok[f]) continue;
     bf16_t* kp = a.dK + ((int64_t)b * S + mykey[f]) * a.lddk + h * DH + 4 * g;
     bf16_t* vp = a.dV + ((int64_t)b * S + mykey[f]) * a.lddv + h * DH + 4 * g;
+    if (a.qk_saved) {       // block-uniform: d(pre-norm k) straight from the accumulators (rows past S ride along on row S-1, unstored)
+      u32x2 u[DF];
+      norm_rope_bwd_row<DH>(dk, f, a.scale, a.qk_saved + ((int64_t)b * S + mykey[f]) * a.ld_saved + a.H * DH + h * DH + 4 * g,
+                            a.rope + (int64_t)b * a.rope_bstride + ((int64_t)mykey[f] * (DH / 2) + 2 * g) * 2,
+                            (mykey[f] < a.T ? a.wk_txt : a.wk_img) + 4 * g, a.norm_eps, a.norm_flags, u);
+      if (keyok[f]) {
+#pragma unroll
+        for (int d = 0; d < DF; ++d) *(u32x2*)(kp + d * 16) = u[d];
+      }
+    }
+    if (!keyok[f]) continue;
 #pragma unroll
     for (int d = 0; d < DF; ++d) {
       u32x2 u;
-      u[0] = pack2bf(dk[d][f][0] * a.scale, dk[d][f][1] * a.scale);
-      u[1] = pack2bf(dk[d][f][2] * a.scale, dk[d][f][3] * a.scale);
-      *(u32x2*)(kp + d * 16) = u;
+      if (!a.qk_saved) {
+        u[0] = pack2bf(dk[d][f][0] * a.scale, dk[d][f][1] * a.scale);
+        u[1] = pack2bf(dk[d][f][2] * a.scale, dk[d][f][3] * a.scale);
+        *(u32x2*)(kp + d * 16) = u;
+      }
       u[0] = pack2bf(dv[d][f][0], dv[d][f][1]);
       u[1] = pack2bf(dv[d][f][2], dv[d][f][3]);
       *(u32x2*)(vp + d * 16) = u;
@@ -705,6 +777,7 @@ extern "C" int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream) {
 extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
+  if (a->qk_saved && (!a->rope || !a->wq_txt || !a->wq_img || (a->ld_saved % 4) || a->T < 0)) return QFX_EINVAL;
   if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
   const int nw = 4;   /* see pick_waves */
@@ -723,6 +796,7 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
 extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
+  if (a->qk_saved && (!a->rope || !a->wk_txt || !a->wk_img || (a->ld_saved % 4) || a->T < 0)) return QFX_EINVAL;
   if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
   dim3 grid(((a->S + 255) / 256) * a->H * a->B);

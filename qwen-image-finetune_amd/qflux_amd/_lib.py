@@ -129,6 +129,9 @@ class AttnArgs(C.Structure):
         ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p), ("lddq", C.c_int64), ("lddk", C.c_int64), ("lddv", C.c_int64),
         ("key_mask", C.c_void_p),
         ("B", C.c_int32), ("S", C.c_int32), ("S_pad", C.c_int32), ("H", C.c_int32), ("dh", C.c_int32), ("scale", C.c_float),
+        ("qk_saved", C.c_void_p), ("ld_saved", C.c_int64), ("rope", C.c_void_p), ("rope_bstride", C.c_int64),
+        ("wq_txt", C.c_void_p), ("wk_txt", C.c_void_p), ("wq_img", C.c_void_p), ("wk_img", C.c_void_p),
+        ("T", C.c_int32), ("norm_flags", C.c_int32), ("norm_eps", C.c_float),
     ]
 
 

@@ -554,6 +554,7 @@ class _FluxPlan(_QwenPlan):
         dq2 = A["dqkv"].view(M, 3 * D)
         a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
         a.lddq = a.lddk = a.lddv = 3 * D
+        self._fuse_qk_bwd(a, bb["sqk"], (nq, nk, nq, nk), self.NORM_FLAGS, eps)
         self.sattn_args.append(a)
         p.c(lib.qfx_attn_fwd, C.byref(a))
         if cat is not None:
@@ -661,9 +662,10 @@ class _FluxPlan(_QwenPlan):
         q2 = bb["qkv"].view(M, 3 * D)
         p.c(lib.qfx_attn_bwd_dq, C.byref(a))
         p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
-        nq, nk = w["norms"]
-        p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
-            B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
+        if not a.qk_saved:
+            nq, nk = w["norms"]
+            p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),
+                B, S, T, H, dh, eps, self.NORM_FLAGS, self.rope_bs)
         K2 = 4 * D
         if grp is not None:
             Rp, Kext = grp["Rp"], grp["Kext"]

@@ -714,6 +714,17 @@ class _QwenPlan:
                 else:
                     A[name + "#1"] = torch.zeros_like(src)
 
+    def _fuse_qk_bwd(self, a, sqk, norms, norm_flags, eps):
+        """Backward of the QK RMSNorm + RoPE in the epilogues of qfx_attn_bwd_dq / _dkv (one pass over dqkv and a launch less per
+        block; QFX_FUSE_QKNORM_BWD=0 keeps the separate qfx_qk_norm_rope_bwd launch)."""
+        if os.environ.get("QFX_FUSE_QKNORM_BWD", "1") == "0":
+            return
+        nq_t, nk_t, nq_i, nk_i = norms
+        a.qk_saved, a.ld_saved = _ptr(sqk), 2 * self.D
+        a.rope, a.rope_bstride = _ptr(self.rope), self.rope_bs
+        a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i)
+        a.T, a.norm_flags, a.norm_eps = self.T, norm_flags & 1, eps
+
     def _sb(self, name, par):
         """Scratch buffer `name` of block parity `par` (second copies exist only with side-stream gradient launches)."""
         return self.A[name + "#1"] if (par and self.side_grads) else self.A.get(name)   # v^T scratch exists only with adapters
@@ -1224,6 +1235,7 @@ class _QwenPlan:
             dq2 = self._sb("dqkv", par).view(B * S, 3 * D)
             a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
             a.lddq = a.lddk = a.lddv = 3 * D
+            self._fuse_qk_bwd(a, bb["sqk"], (nq_t, nk_t, nq_i, nk_i), norm_flags, eps)
             self.attn_args.append(a)
             p.c(lib.qfx_attn_fwd, C.byref(a))
             # the text stream of the last block never reaches the output (:661-663): dead compute, skipped
@@ -1437,9 +1449,10 @@ class _QwenPlan:
             q2 = bb["qkv"].view(B * S, 3 * D)
             p.c(lib.qfx_attn_bwd_dq, C.byref(a))
             p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
-            nq_t, nk_t, nq_i, nk_i = w["norms"]
-            p.c(lib.qfx_qk_norm_rope_bwd, _ptr(dqkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
-                _ptr(nk_i), B, S, T, H, dh, eps, norm_flags, self.rope_bs)
+            if not a.qk_saved:      # (else: the backward of the QK norm + RoPE runs in the epilogues of the two kernels above)
+                nq_t, nk_t, nq_i, nk_i = w["norms"]
+                p.c(lib.qfx_qk_norm_rope_bwd, _ptr(dqkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),
+                    _ptr(nk_i), B, S, T, H, dh, eps, norm_flags, self.rope_bs)
             # ---- q/k/v projection backward (+ LoRA), both streams in one launch
             groups = []
             dl = []   # the q/k/v down projections of both streams: one batched launch
