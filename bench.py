@@ -132,7 +132,15 @@ def cpu_baseline(cfg_dims, blocks=2, warmup=1, steps=3):
     sys.path.insert(0, ROOT)
     from oracle import qwen_dit as O
     D_h, H, Jd, S_t, T = cfg_dims
-    cores = min(os.cpu_count() or 1, 64)   # eager CPU GEMMs stop scaling (and start thrashing) beyond ~64 threads
+    try:                                   # all PHYSICAL cores of the box (SMT siblings add nothing to fp32 GEMMs)
+        import psutil
+        cores = psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+    except Exception:  # noqa: BLE001
+        cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))     # ... that this process may run on
+    except AttributeError:
+        pass
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     m = O.OracleQwenDiT(num_layers=blocks, attention_head_dim=D_h, num_attention_heads=H, joint_attention_dim=Jd)

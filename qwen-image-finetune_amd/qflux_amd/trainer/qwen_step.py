@@ -178,8 +178,6 @@ class QwenLoraTrainStep:
         if self.criterion == "mask_edit":
             raise NotImplementedError("capture_graph: the mask_edit criterion takes per-step token weights; use train_step")
         dit = self.dit
-        if getattr(dit, "cond_lora", False):
-            raise NotImplementedError("capture_graph with adapters on the conditioning head is not covered by a test yet; use train_step")
         packed, target, pe, t_in, S_t = self._prepare(embeddings)
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
         dit.lora_store

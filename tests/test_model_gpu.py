@@ -408,25 +408,33 @@ def test_all_linear_targets_match_oracle():
     assert res["ok"], res
 
 
-def test_hipgraph_replay_of_the_step_equals_the_eager_replay():
+@pytest.mark.parametrize("targets", [("to_k", "to_q", "to_v", "to_out.0"), "all-linear"], ids=["attn", "all-linear"])
+def test_hipgraph_replay_of_the_step_equals_the_eager_replay(targets):
     """capture_graph: the DiT part of the step (operand refresh, forward program, loss, backward program with its side-stream
     gradient launches) replayed from one hipGraph gives the losses and LoRA parameters of the Python replay, step after step,
-    with new inputs / noise / timesteps staged through the static buffers; a rebuilt plan invalidates the graph loudly."""
+    with new inputs / noise / timesteps staged through the static buffers; a rebuilt plan invalidates the graph loudly.
+    "all-linear": the conditioning head with adapters is plain launches + memsets since round 3 (cond_hip.py) and is captured too."""
     from common import TINY
     from parity_util import build_pair, tiny_embeddings
     from qflux_amd.trainer import QwenLoraTrainStep
-    _, a = build_pair(dict(TINY), device=DEV)
-    _, b = build_pair(dict(TINY), device=DEV)
-    sa, sb = QwenLoraTrainStep(a, lr=1e-2), QwenLoraTrainStep(b, lr=1e-2)
+    _, a = build_pair(dict(TINY), device=DEV, targets=targets)
+    _, b = build_pair(dict(TINY), device=DEV, targets=targets)
+    # With the conditioning head adapted, d(temb) is an fp32-atomic sum that is then ROUNDED to bf16 (autograd's dtype): the atomics'
+    # run-to-run order flips single bf16 ulps (1e-3 of the embedder gradients, tools/dbg_grad.py), and Adam turns sign flips of
+    # near-zero gradient entries into full +-lr steps -- two EAGER runs differ by that much too (tools/dbg_graph.py).  Hence the
+    # small learning rate and the looser bars of that case; the attention-only case is reproducible to the atomics' 1e-6.
+    cond = targets == "all-linear"
+    lr, tol_l, tol_p = (1e-4, 1e-4, 5e-3) if cond else (1e-2, 1e-6, 1e-6)
+    sa, sb = QwenLoraTrainStep(a, lr=lr), QwenLoraTrainStep(b, lr=lr)
     batches = [tiny_embeddings(seed=s) for s in (11, 12, 13)]
     gstep = sb.capture_graph(batches[0][0])
     assert float(b.lora_store.gflat.abs().max()) == 0.0 and sb.global_step == 0        # capturing is not a step
     for (e, n, u) in batches:
         la = sa.train_step(e, noise=n, u=u).item()
         lb = gstep(e, noise=n, u=u).item()
-        assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)     # the loss sum is an fp32 atomic reduction
+        assert abs(la - lb) <= tol_l * abs(la), (la, lb)     # the loss sum is an fp32 atomic reduction
     rel = ((a.lora_store.pflat - b.lora_store.pflat).abs().max() / a.lora_store.pflat.abs().max()).item()
-    assert rel < 1e-6, rel
+    assert rel < tol_p, rel
     e2, n2, u2 = tiny_embeddings(seed=14, T=9)
     with pytest.raises(ValueError):
         gstep(e2, noise=n2, u=u2)
