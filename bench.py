@@ -124,14 +124,7 @@ def run_profiled(prog, fn_target, hbm=None):
     return evs
 
 
-def cpu_baseline(cfg_dims, blocks=2, warmup=1, steps=3):
-    """The oracle (a CPU restatement of the reference's module graph, fp32 eager PyTorch) timed on this host's cores on a
-    BOUNDED sample (BASELINE.md section 3 protocol): K=2 of the 60 blocks + head/tail at the full sequence length,
-    forward+backward+AdamW on the LoRA params, 1 warm-up step (allocator, thread pool) + 3 timed steps; the per-block time is
-    measured as (K-block step) / K with head/tail included, extrapolated x(60/K)."""
-    sys.path.insert(0, ROOT)
-    from oracle import qwen_dit as O
-    D_h, H, Jd, S_t, T = cfg_dims
+def _physical_cores():
     try:                                   # BASELINE.md section 3: all PHYSICAL cores of the box (SMT siblings add nothing to fp32 GEMMs)
         import psutil
         cores = psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
@@ -141,29 +134,53 @@ def cpu_baseline(cfg_dims, blocks=2, warmup=1, steps=3):
         cores = min(cores, len(os.sched_getaffinity(0)))     # ... that this process may run on
     except AttributeError:
         pass
-    torch.set_num_threads(cores)
-    torch.manual_seed(1234)
-    m = O.OracleQwenDiT(num_layers=blocks, attention_head_dim=D_h, num_attention_heads=H, joint_attention_dim=Jd)
-    O.add_lora(m, r=16, lora_alpha=16, adapter_name="default", seed=0)
-    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
-    emb = dict(image_latents=torch.randn(1, S_t, 64), control_latents=torch.randn(1, S_t, 64),
-               prompt_embeds=torch.randn(1, T, Jd) * 4, prompt_embeds_mask=torch.ones(1, T, dtype=torch.int64),
-               img_shapes=[[(1, 32, 32), (1, 32, 32)]])
-    times = []
-    for i in range(warmup + steps):
-        t0 = time.time()
-        loss = O.qwen_compute_loss(m, emb, torch.randn(1, S_t, 64), torch.rand(1), torch.float32)
-        loss.backward()
-        opt.step()
-        opt.zero_grad()
-        if i >= warmup:
-            times.append(time.time() - t0)
+    return cores
+
+
+def cpu_baseline(cfg_dims, blocks=2, warmup=1, steps=3):
+    """The oracle (a CPU restatement of the reference's module graph, fp32 eager PyTorch) timed on this host's cores on a
+    BOUNDED sample (BASELINE.md section 3 protocol): K=2 of the 60 blocks + head/tail at the full sequence length,
+    forward+backward+AdamW on the LoRA params, 1 warm-up step (allocator, thread pool) + 3 timed steps; the per-block time is
+    measured as (K-block step) / K with head/tail included, extrapolated x(60/K).  Thread counts: ALL physical cores (the
+    protocol) and, when the box has more than 64, also 64 -- eager CPU GEMMs stop scaling (and start thrashing) beyond that;
+    `value` is the FASTER of the two, the other one is reported next to it."""
+    sys.path.insert(0, ROOT)
+    from oracle import qwen_dit as O
+    D_h, H, Jd, S_t, T = cfg_dims
+    phys = _physical_cores()
+    runs = {}
+    for cores in sorted({phys, min(phys, 64)}, reverse=True):
+        torch.set_num_threads(cores)
+        torch.manual_seed(1234)
+        m = O.OracleQwenDiT(num_layers=blocks, attention_head_dim=D_h, num_attention_heads=H, joint_attention_dim=Jd)
+        O.add_lora(m, r=16, lora_alpha=16, adapter_name="default", seed=0)
+        opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        emb = dict(image_latents=torch.randn(1, S_t, 64), control_latents=torch.randn(1, S_t, 64),
+                   prompt_embeds=torch.randn(1, T, Jd) * 4, prompt_embeds_mask=torch.ones(1, T, dtype=torch.int64),
+                   img_shapes=[[(1, 32, 32), (1, 32, 32)]])
+        times = []
+        for i in range(warmup + steps):
+            t0 = time.time()
+            loss = O.qwen_compute_loss(m, emb, torch.randn(1, S_t, 64), torch.rand(1), torch.float32)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            if i >= warmup:
+                times.append(time.time() - t0)
+        runs[cores] = times
+        del m, opt
+    best = min(runs, key=lambda c: sum(runs[c]) / len(runs[c]))
+    times = runs[best]
     per_step = sum(times) / len(times)
     full = per_step * (60.0 / blocks)
-    return {"value": 1.0 / full, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{blocks} of 60 DiT blocks + head/tail, fp32 eager, B=1, 512^2 (S_i={2 * S_t},T={T}), fwd+bwd+AdamW, "
-                      f"{warmup} warm-up + {steps} timed steps of {per_step:.2f} s (min {min(times):.2f}, max {max(times):.2f}), "
-                      f"extrapolated x{60 // blocks}"}
+    out = {"value": 1.0 / full, "unit": "images/s", "cores": best, "kind": "port",
+           "sample": f"{blocks} of 60 DiT blocks + head/tail, fp32 eager, B=1, 512^2 (S_i={2 * S_t},T={T}), fwd+bwd+AdamW, "
+                     f"{warmup} warm-up + {steps} timed steps of {per_step:.2f} s (min {min(times):.2f}, max {max(times):.2f}), "
+                     f"extrapolated x{60 // blocks}", "physical_cores": phys}
+    for c, t in runs.items():
+        if c != best:
+            out["other_thread_counts"] = {str(c): round(1.0 / (sum(t) / len(t) * 60.0 / blocks), 6)}
+    return out
 
 
 def _git_blob_sha1(path):
