@@ -95,6 +95,10 @@ class QwenLoraTrainStep:
         self._pending = []
         self._reduced = False
         self._synced = False      # rank 0's adapter / optimizer state is broadcast before the first step (broadcast_state)
+        # QFX_DP_FORCE=1: run the bucketed exchange on a ONE-rank process group too (the collectives are then identities) -- lets a
+        # one-GPU box execute the real RCCL code path: communicator, RCCL's stream, async handles, ordering against the main and
+        # the side gradient stream (tests/test_dp_gpu.py)
+        self._force_dp = os.environ.get("QFX_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
 
     def _ensure_synced(self):
         if not self._synced:
@@ -162,7 +166,7 @@ class QwenLoraTrainStep:
             loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
         else:
             loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
-        plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
+        plan.run_backward(dpred, on_segment=self._bucket_hook() if ((self.world > 1 or self._force_dp) and sync) else None)
         return loss
 
     # ------------------------------------------------------------------ hipGraph replay of the DiT part of the step
@@ -261,7 +265,7 @@ class QwenLoraTrainStep:
 
     def allreduce_grads(self):
         """Returns the factor the optimizer applies to the summed gradient (1/world)."""
-        if self.world > 1:
+        if self.world > 1 or self._force_dp:
             fin = getattr(self, "_finish_buckets", None)
             if fin is not None:
                 fin()

@@ -190,3 +190,47 @@ def test_dropin_autograd_two_ranks_exchange_inside_backward(targets):
     rel = ((g0 - ref).abs().max() / ref.abs().max()).item()
     print("drop-in 2-rank exchanged gradient vs manual mean: rel", rel, "targets", targets)
     assert rel < 1e-5 and ref.abs().max() > 0
+
+
+def _worker_rccl1(port, q, force):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if force:
+        os.environ["QFX_DP_FORCE"] = "1"
+    torch.cuda.set_device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    hip, tiny_embeddings = _mk("cuda:0")
+    from qflux_amd.trainer import QwenLoraTrainStep
+    step = QwenLoraTrainStep(hip, lr=1e-2, bucket_mb=1e-3)      # tiny buckets: one async RCCL all-reduce per DiT block
+    assert step._force_dp == force
+    losses = []
+    for s_ in (11, 12, 13):
+        emb, noise, u = tiny_embeddings(seed=s_)
+        losses.append(step.train_step(emb, noise=noise, u=u).item())
+    if force:
+        assert step.broadcast_state() is None and step.check_replicas()
+    torch.cuda.synchronize()
+    q.put((force, hip.lora_store.pflat.detach().cpu().numpy(), losses))
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_on_one_rank_equals_the_plain_step():
+    """RCCL ("nccl" backend) executes the exchange on a one-GPU box: a ONE-rank communicator with QFX_DP_FORCE=1 runs the bucketed
+    async all-reduces (identities) on RCCL's own stream behind the segmented backward -- ordered against the main stream and the
+    side gradient stream only by the events the step records -- plus broadcast_state / check_replicas; three optimisation steps
+    must equal the same steps without any exchange up to the fp32 atomics' order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for force in (True, False):
+        q = ctx.Queue()
+        p = ctx.Process(target=_worker_rccl1, args=(38500 + (os.getpid() % 2000) + int(force), q, force))
+        p.start()
+        f, flat, losses = q.get(timeout=300)
+        p.join(60)
+        res[f] = (torch.from_numpy(flat), losses)
+    rel = ((res[True][0] - res[False][0]).abs().max() / res[False][0].abs().max()).item()
+    print("RCCL one-rank exchange vs plain step: param rel", rel, "losses", res[True][1], res[False][1])
+    assert rel < 1e-5 and all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(res[True][1], res[False][1]))
