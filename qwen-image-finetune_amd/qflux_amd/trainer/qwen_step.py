@@ -571,7 +571,7 @@ def init_distributed_from_env():
         local = 0
     if torch.cuda.is_available():
         torch.cuda.set_device(local)   # before the process group: RCCL binds to the current device
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("QFX_BENCH_INIT_PG") == "1") and not dist.is_initialized():     # (one-rank group: tools/rccl_one_rank.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("QFX_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
