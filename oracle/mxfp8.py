@@ -5,7 +5,8 @@ TE fp8 / bnb int8 / NF4 linears -- third-party engines, absent offline).  What i
 implements: OCP MX-FP8 operands (Microscaling Formats specification v1.0: element type e4m3, one E8M0 scale per 32 consecutive
 elements along K, scale exponent = floor(log2(max|v|)) - emax(e4m3) with emax = 8, elements = RNE(v / 2^e) saturated to +-448) on
 BOTH operands of the base linear in the forward pass; bias, bf16 output rounding and the LoRA branch unchanged; the backward uses
-the un-quantised bf16 operands (dX = dY W, adapters on the bf16 activations).  parity unpinned against the reference's engines.
+the un-quantised bf16 operands (dX = dY W, adapters on the bf16 activations) unless backward=True ("mxfp8-fb": dY and W^T quantised
+along out_features).  parity unpinned against the reference's engines.
 """
 from __future__ import annotations
 
@@ -62,11 +63,12 @@ def eligible(name: str, lin: nn.Linear) -> bool:
 
 def quantize_oracle(model: nn.Module, predicate=eligible, backward: bool = False):
     """Patch the forward of every eligible frozen nn.Linear (the base layers of adapted linears included).  backward=True: the dX
-    GEMMs of the double-stream blocks contract MX-FP8 operands as well (the FLUX single blocks' fused dX contraction stays bf16)."""
+    GEMMs contract MX-FP8 operands as well -- double-stream blocks and FLUX single blocks alike (there the MI355X path sums the
+    q/k/v/proj_mlp products in one contraction over the concatenated K: same operand bytes, fp32 instead of bf16 partial sums)."""
     n = 0
     for name, m in model.named_modules():
         if isinstance(m, nn.Linear) and "lora_" not in name and predicate(name, m):
-            qb = bool(backward) and not name.startswith("single_transformer_blocks")
+            qb = bool(backward)
             m.forward = (lambda x, m=m, qb=qb: _QLinearFn.apply(x, m.weight, m.bias, qb))
             n += 1
     return n

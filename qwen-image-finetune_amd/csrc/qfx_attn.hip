@@ -189,8 +189,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       float m = mx[f];
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
+      {   // cross-lane maximum over the four 16-lane groups on the VALU (v_permlane16_swap / v_permlane32_swap): no LDS crossbar trip
+        const uint32_t u0 = __float_as_uint(m);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(u0, u0, false, false);
+        m = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
+        const uint32_t u1 = __float_as_uint(m);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+        m = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+      }
       m *= cs;
       const float mnew = fmaxf(mrow[f], m);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
@@ -233,6 +239,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
   stage_rows_n<DH, NW>(smem, Kb, a.ldk, 0, S, w, lane);
   stage_rows_n<DH, NW>(smem + TB, Vb, a.ldv, 0, S, w, lane);
   __syncthreads();
+#if defined(QFX_ATTN_TIMING)
+  uint64_t tq = 0, tp = 0, tb = 0;
+#endif
   for (int jt = 0; jt < ntiles; ++jt) {
     const char* sK = smem + (jt & 1) * 2 * TB;
     const char* sV = sK + TB;
@@ -241,10 +250,29 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
       stage_rows_n<DH, NW>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
       stage_rows_n<DH, NW>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
     }
+#if defined(QFX_ATTN_TIMING)
+    const uint64_t t0 = __builtin_readcyclecounter();
+    qk(sK);
+    asm volatile("s_nop 0" ::: "memory");
+    const uint64_t t1 = __builtin_readcyclecounter();
+    sm_pv(sV, jt * 64);
+    const uint64_t t2 = __builtin_readcyclecounter();
+    __syncthreads();
+    const uint64_t t3 = __builtin_readcyclecounter();
+    tq += t1 - t0; tp += t2 - t1; tb += t3 - t2;
+#else
     qk(sK);
     sm_pv(sV, jt * 64);
     __syncthreads();
+#endif
   }
+#if defined(QFX_ATTN_TIMING)
+  if (lane == 0 && blockIdx.x < 16) {
+    float* dbg = a.lse2 + ((int64_t)a.B * a.H) * a.S_pad;      // caller over-allocates lse2 by 16*8*4 floats in the timing build
+    dbg[(blockIdx.x * 8 + w) * 4 + 0] = (float)tq; dbg[(blockIdx.x * 8 + w) * 4 + 1] = (float)tp;
+    dbg[(blockIdx.x * 8 + w) * 4 + 2] = (float)tb; dbg[(blockIdx.x * 8 + w) * 4 + 3] = (float)ntiles;
+  }
+#endif
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     float l = lrow[f];

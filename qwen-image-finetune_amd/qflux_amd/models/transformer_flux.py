@@ -700,8 +700,13 @@ class _FluxPlan(_QwenPlan):
             self._grad(p, Vt=sb["V"], R=lo.Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1)
             K2 += lo.Kext
         # d(norm_x) = [dq|dk|dv] Wqkv + [d mlp | LoRA v] [W_mlp ; A]
-        self._gemm(p, A1=dq2, lda1=3 * D, B1=w["qkvT"], K1=3 * D, A2=A["A2"], lda2=ldA2, B2=w["B2"], ldb2=w["B2"].stride(0), K2=K2,
-                   M=M, N=D, C_=A["dxm_j"], ldc=D, seg2_plain=1)
+        if getattr(self.model, "_quant", None) == "mxfp8-fb" and D % 128 == 0 and D >= 1024:
+            # low-precision trunk: the four frozen contractions as one MX-FP8 GEMM over K = 3D + 4D, adapters as its bf16 K-extension
+            self._gemm_mxfp8_cat(p, [(dq2, 3 * D, 3 * D, w["qkvT"]), (A["A2"], ldA2, 4 * D, w["B2"])], M=M, N=D, C_=A["dxm_j"], ldc=D,
+                                 ext=(A["A2"][:, 4 * D:], ldA2, w["B2"][:, 4 * D:], w["B2"].stride(0), K2 - 4 * D))
+        else:
+            self._gemm(p, A1=dq2, lda1=3 * D, B1=w["qkvT"], K1=3 * D, A2=A["A2"], lda2=ldA2, B2=w["B2"], ldb2=w["B2"].stride(0), K2=K2,
+                       M=M, N=D, C_=A["dxm_j"], ldc=D, seg2_plain=1)
         if self.cond:   # d(shift, scale, gate) of the single block's AdaLayerNormZeroSingle
             dm = A["dsmods"][i]
             self._mod_grad(p, dy=A["dxm_j"], x=x, rows=M, rpb=S, dshift=dm[:, 0:D], dscale=dm[:, D:2 * D], dgate=dm[:, 2 * D:3 * D],

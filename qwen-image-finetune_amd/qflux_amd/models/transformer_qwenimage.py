@@ -898,9 +898,10 @@ class _QwenPlan:
     @staticmethod
     def _fp8_ok(g):
         A1, lda1, a_map, rpb, B1 = g._src
-        # whole weight tensors only (a row slice of the FLUX single block's proj_out^T stays bf16 like the rest of that block's backward)
-        return (isinstance(B1, torch.Tensor) and B1.dim() == 2 and B1.is_contiguous() and B1.storage_offset() == 0 and g.K1 % 128 == 0
-                and g.K1 >= 1024 and g.N >= 1024 and B1.shape == (g.N, g.K1) and not g.seg2_plain)
+        # a weight [N, K1] or the first N rows of a taller contiguous one (the FLUX single block's proj_out^T is contracted in two row
+        # ranges): MX blocks run along K, so a row range quantises to the same bytes as the rows of the whole matrix
+        return (isinstance(B1, torch.Tensor) and B1.dim() == 2 and B1.is_contiguous() and g.K1 % 128 == 0 and g.K1 >= 1024
+                and g.N >= 1024 and B1.shape[1] == g.K1 and B1.shape[0] >= g.N and g.ldb1 == g.K1 and not g.seg2_plain)
 
     def _gemm_group_mxfp8(self, prog, groups):
         """Forward GEMMs of the block linears on the block-scaled FP8 MFMA (model.quantize = "mxfp8", the MI355X analogue of
@@ -918,9 +919,9 @@ class _QwenPlan:
         persistent = tiles >= 160 and len(groups) <= 6
         for gi_, g in enumerate(groups):
             A1, lda1, a_map, rpb, B1 = g._src
-            key = (B1.data_ptr(), tuple(B1.shape))
+            key = (B1.data_ptr(), (g.N, g.K1))
             if key not in cache:
-                cache[key] = ops.quant_mxfp8(B1)
+                cache[key] = ops.quant_mxfp8(B1[:g.N])
             wq, ws = cache[key]
             akey = (A1.data_ptr(), lda1, a_map, g.M)
             if akey in preq:
@@ -968,6 +969,43 @@ class _QwenPlan:
                 prog.keep.append(f)
                 prog.c(lib.qfx_gemm_mxfp8, C.byref(f))
         self._preq_next = produced
+
+    def _gemm_mxfp8_cat(self, prog, parts, *, M, N, C_, ldc, ext=None):
+        """C = sum_i X_i W_i^T (+ the bf16 LoRA K-extension `ext` = (A2, lda2, B2, ldb2, K2)) as ONE MX-FP8 contraction over the
+        concatenated K of `parts` = [(X_i [M, K_i] bf16, row stride, K_i, W_i^T as [N, >= K_i] bf16)]: the operands are quantised
+        side by side into one byte buffer / one tile-major scale array (K_i % 128 == 0: MX blocks and scale tiles never straddle a
+        seam), the weights once (cached on the model).  Used for dX contractions that sum several frozen linears ("mxfp8-fb")."""
+        from .. import ops
+        Kt = sum(K for _, _, K, _ in parts)
+        cache = self.model.__dict__.setdefault("_wq_cache", {})
+        key = ("cat", N) + tuple((Wt.data_ptr(), K) for _, _, K, Wt in parts)
+        if key not in cache:
+            cache[key] = ops.quant_mxfp8(torch.cat([Wt[:N, :K] for _, _, K, Wt in parts], dim=1).contiguous())
+        wq, ws = cache[key]
+        scratch = self.__dict__.setdefault("_q8", {})
+        slot = ("cat", M, Kt)
+        if slot not in scratch:
+            scratch[slot] = (self.buf(M, Kt, dtype=torch.uint8), self.buf(Kt // 128, M, 4, dtype=torch.uint8))
+        xq, xs = scratch[slot]
+        col = 0
+        for X, ldx, K, _ in parts:
+            assert K % 128 == 0
+            qa = L.QuantArgs()
+            qa.X, qa.ldx, qa.M, qa.K = _ptr(X), ldx, M, K
+            qa.Q, qa.ldq, qa.S, qa.lds = xq.data_ptr() + col, Kt, xs.data_ptr() + (col // 128) * M * 4, 0
+            qa.rows_per_batch, qa.x_batch_rows, qa.x_row_off = M, 0, 0
+            prog.keep.append(qa)
+            prog.c(lib.qfx_quant_mxfp8, C.byref(qa))
+            col += K
+        kw = {}
+        if ext is not None and ext[4] > 0:
+            kw = dict(A2=ext[0], lda2=ext[1], B2=ext[2], ldb2=ext[3], K2=ext[4])
+        g = self._gargs(A1=xq, lda1=Kt, B1=wq, K1=Kt, M=M, N=N, C_=C_, ldc=ldc, **kw)
+        f = L.GemmFp8Args()
+        C.memmove(C.byref(f.g), C.byref(g), C.sizeof(L.GemmArgs))
+        f.sa, f.ldsa, f.sb, f.ldsb = _ptr(xs), 0, _ptr(ws), 0
+        prog.keep.append((f, wq, ws))
+        prog.c(lib.qfx_gemm_mxfp8, C.byref(f))
 
     def _down(self, prog, *, X, ldx, M, K, W_hi, W_lo, ldw, R, U=None, ldu=0, ext=None, ld_ext=0, Ut=None, group_R=None,
               group_stride=0, rpb=None, x_map=(0, 0), defer=None, xq=None):

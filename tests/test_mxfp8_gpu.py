@@ -268,7 +268,8 @@ def test_gemm_mxfp8_grouped_persistent_all_epilogues():
 
 def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
     """FLUX double + single block of width 1024 with the MX-FP8 trunk (forward + dX GEMMs): the single block's proj_out runs as one
-    MX-FP8 contraction over the kept [attn | gelu(mlp)] buffer; the single block's backward stays bf16 (oracle: per-module flag)."""
+    MX-FP8 contraction over the kept [attn | gelu(mlp)] buffer; its backward as three -- d(attn) and d(mlp) against row ranges of
+    proj_out^T, d(norm_x) over the concatenated K of q/k/v/proj_mlp with the adapters as the bf16 K-extension."""
     import os
     from oracle import flux_dit as FO
     from oracle import mxfp8 as QX
@@ -339,6 +340,15 @@ def test_flux_mxfp8_trunk_step_matches_fp8_emulating_oracle():
         elif c[0] is not None and c[0].__name__ == "qfx_gemm_mxfp8_grouped":
             n_fp8 += c[1][1]
     assert n_fp8 == nq       # the same 18 linears run on the scaled MFMA in the HIP forward
+    names = [c[0].__name__ for c in plan.bwd.calls if c[0] is not None]
+    dq = [i for i, n_ in enumerate(names) if n_ == "qfx_attn_bwd_dq"]          # [single block, double block]
+    assert len(dq) == 2
+    head, tail = names[:dq[0]], names[dq[0]:dq[1]]
+    # single block: d(attn) / d(mlp) against two row ranges of proj_out^T before its attention backward (the only bf16 GEMM up to
+    # there is the K = 64 output projection), then the q/k/v/proj_mlp contraction over the concatenated K, all on the scaled MFMA
+    assert head.count("qfx_gemm_mxfp8") == 2 and head.count("qfx_gemm_bf16") == 1 and "qfx_gemm_grouped" not in head, head
+    k = tail.index("qfx_gemm_mxfp8")
+    assert tail[k - 2:k] == ["qfx_quant_mxfp8"] * 2 and "qfx_gemm_bf16" not in tail[:k] and "qfx_gemm_grouped" not in tail[:k], tail
     print(f"flux mxfp8-fb: loss {loss_h:.5f} / {loss_o.item():.5f}, pred rel {e:.4f}, worst LoRA grad rel {gw:.4f}")
     # width-1024 weights of std 0.03 make this a noisy net: the fp8 trunk moves the prediction by `gap` (8 % of its maximum, the
     # bf16 paths agree to 1 %).  The HIP path must sit well inside that distance from the fp8-emulating oracle -- element flips at
