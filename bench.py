@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--no-batch2", action="store_true", help="skip the secondary per-GPU-batch-2 measurement")
     ap.add_argument("--no-fp8", action="store_true", help="skip the secondary MX-FP8 trunk measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary drop-in (autograd + torch optimizer) measurement")
+    ap.add_argument("--no-hostfed", action="store_true", help="skip the secondary disk-cache + PCIe inclusive measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args.gpus))
@@ -413,6 +414,43 @@ def main():
                                   "note": "dit(...)[0] -> MSE -> loss.backward() -> clip_grad_norm_ -> torch.optim.AdamW.step() -> zero_grad(), "
                                           "the reference's loop body (base_trainer.py:508-561) on the drop-in module; `value` above is the fused step"}
         del opt
+        step.zero_grad()
+    if world == 1 and B == 1 and not args.no_hostfed:
+        # secondary line: the step fed the way a training job feeds it -- the reference's on-disk embedding cache (fp16 .pt files,
+        # SURVEY 8f1) -> PrefetchLoader (worker thread, pinned staging, upload on a side stream) -> train_step.  `value` above is
+        # measured with the batch already resident in HBM; this is the disk + PCIe inclusive rate of the same step.
+        import shutil
+        import tempfile
+        from qflux_amd.data import CachedEmbeddingDataset, PrefetchLoader, convert_img_shapes_to_latent_space, write_cache_sample
+        root = tempfile.mkdtemp(prefix="qfx_bench_cache_")
+        try:
+            g = torch.Generator().manual_seed(0)
+            for i in range(16):
+                write_cache_sample(root, f"{i:032x}", dict(image_latents=torch.randn(S_t, 64, generator=g), control_latents=torch.randn(S_t, 64, generator=g),
+                                                          prompt_embeds=torch.randn(T, Jd, generator=g) * 4, prompt_embeds_mask=torch.ones(T)),
+                                   img_shapes=[(3, args.res, args.res), (3, args.res, args.res)])
+            loader = PrefetchLoader(CachedEmbeddingDataset(root), batch_size=1, device=dev)
+            nh = max(8, min(args.steps, 16))
+            done, t1, nbytes = 0, None, 0
+            while done < nh + 4:
+                for b_ in loader:
+                    e_ = dict(image_latents=b_["image_latents"], control_latents=b_["control_latents"], prompt_embeds=b_["prompt_embeds"],
+                              prompt_embeds_mask=b_["prompt_embeds_mask"].long(), img_shapes=convert_img_shapes_to_latent_space(b_["img_shapes"]))
+                    step.train_step(e_)
+                    done += 1
+                    if done == 4:
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                        nbytes = sum(v.numel() * v.element_size() for v in b_.values() if isinstance(v, torch.Tensor))
+                    if done >= nh + 4:
+                        break
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - t1) / nh
+            out["host_fed"] = {"value": round(1.0 / dth, 4), "unit": "images/s", "ms_per_step": round(dth * 1e3, 3), "steps": nh,
+                               "vs_resident": round(dth * 1e3 / ms_per_step, 4), "host_bytes_per_step": int(nbytes),
+                               "note": "16-sample on-disk cache in the reference's layout -> CachedEmbeddingDataset -> PrefetchLoader "
+                                       "(pinned staging, side-stream H2D) -> QwenLoraTrainStep.train_step; disk + PCIe inclusive"}
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
         step.zero_grad()
     if world == 1 and B == 1 and not args.no_batch2:
         # secondary line: the reference's own default micro-batch for this config is 2 (configs/face_seg_config.yaml:31, and its

@@ -20,6 +20,7 @@ import json
 import os
 import random
 import threading
+import time
 
 import torch
 import torch.nn.functional as F
@@ -136,7 +137,7 @@ class PrefetchLoader:
     side stream while the training step consumes batch n."""
 
     def __init__(self, dataset, batch_size: int, device, rank: int = 0, world: int = 1, shuffle: bool = True, seed: int = 1234,
-                 workers: int = 4, prefetch: int = 2, drop_last: bool = True, keys_to_device=None):
+                 workers: int = 2, prefetch: int = 3, drop_last: bool = True, keys_to_device=None):
         self.ds, self.bs, self.device = dataset, batch_size, torch.device(device)
         self.rank, self.world, self.shuffle, self.seed = rank, world, shuffle, seed
         self.workers, self.prefetch, self.drop_last = workers, prefetch, drop_last
@@ -178,17 +179,24 @@ class PrefetchLoader:
         batches = self.indices()
         depth = max(1, self.prefetch)
         slots = {}
-        cv = threading.Condition()
-        state = {"next": 0, "consumed": 0, "stop": False, "staged_max": 0, "error": None}
-        self.stats = state          # staged_max = the largest number of host batches ever staged at once (tests read it)
+        # one lock, two wait queues: a consumed batch frees ONE slot and wakes ONE reader; a staged batch wakes the consumer.  (With
+        # a single condition + notify_all every take() woke all readers: four of them thrashing the GIL under the launch thread
+        # cost the step 3 % -- tools/hostfed_probe.py.)
+        lock = threading.Lock()
+        space, ready = threading.Condition(lock), threading.Condition(lock)
+        cv = ready
+        state = {"next": 0, "consumed": 0, "stop": False, "staged_max": 0, "error": None, "wait_s": 0.0, "upload_s": 0.0}
+        # staged_max = the largest number of host batches ever staged at once (tests read it); wait_s = time the consumer spent
+        # blocked on a batch the readers had not finished; upload_s = host time of issuing the uploads
+        self.stats = state
 
         def work():
             # back-pressure: batch i is read only once i < consumed + depth, so at most `depth` collated (pinned) batches exist
             # on the host at any time however fast the disk readers are
             while True:
-                with cv:
+                with lock:
                     while not state["stop"] and state["next"] < len(batches) and state["next"] >= state["consumed"] + depth:
-                        cv.wait()
+                        space.wait()
                     if state["stop"] or state["next"] >= len(batches):
                         return
                     i = state["next"]
@@ -196,15 +204,16 @@ class PrefetchLoader:
                 try:
                     hb = self._host_batch(batches[i])
                 except BaseException as e:   # noqa: BLE001  (surfaced in the consumer thread)
-                    with cv:
+                    with lock:
                         state["error"] = e
                         state["stop"] = True
-                        cv.notify_all()
+                        space.notify_all()
+                        ready.notify_all()
                     return
-                with cv:
+                with lock:
                     slots[i] = hb
                     state["staged_max"] = max(state["staged_max"], len(slots))
-                    cv.notify_all()
+                    ready.notify_all()
 
         threads = [threading.Thread(target=work, daemon=True) for _ in range(min(self.workers, max(1, len(batches))))]
         for t in threads:
@@ -214,25 +223,30 @@ class PrefetchLoader:
 
         def take(i):
             with cv:
-                while i not in slots and state["error"] is None:
-                    cv.wait()
+                if i not in slots and state["error"] is None:
+                    t_w = time.perf_counter()
+                    while i not in slots and state["error"] is None:
+                        cv.wait()
+                    state["wait_s"] += time.perf_counter() - t_w
                 if state["error"] is not None:
                     raise state["error"]
                 hb = slots.pop(i)
                 state["consumed"] = i + 1
-                cv.notify_all()
+                space.notify()
             return hb
 
         def upload(i):
             hb = take(i)
             if not use_cuda:
                 return hb, None
+            t_u = time.perf_counter()
             ev = torch.cuda.Event()
             with torch.cuda.stream(side):
                 db = {k: (_to_device(v, self.device) if (self.keys_to_device is None or k in self.keys_to_device) else v)
                       for k, v in hb.items()}
                 ev.record(side)
             db["_host"] = hb     # keep the pinned buffers alive until the copy has been consumed
+            state["upload_s"] += time.perf_counter() - t_u
             return db, ev
 
         try:
@@ -249,8 +263,9 @@ class PrefetchLoader:
                 cur.pop("_host", None)
                 yield cur
         finally:
-            with cv:
+            with lock:
                 state["stop"] = True
-                cv.notify_all()
+                space.notify_all()
+                ready.notify_all()
             for t in threads:
                 t.join()
