@@ -50,3 +50,72 @@ def test_flux_step_shape_fuzz_vs_oracle(seed):
     res = run_flux_step_parity(DEV, verbose=False, **case)
     print(case, {k: res[k] for k in ("loss_rel", "pred_rel", "grad_rel_worst", "grad_worst_name") if k in res})
     assert res["ok"], (case, res)
+
+
+def _flux_multires_case(seed):
+    rnd = random.Random(3000 + seed)
+    g = torch.Generator().manual_seed(3000 + seed)
+    B = rnd.choice([1, 2, 3, 4])
+    T = rnd.choice([1, 5, 7, 16])
+    dims = [1, 2, 3, 4, 5, 6]
+    samples, lens = [], []
+    for _ in range(B):
+        h, w = rnd.choice(dims), rnd.choice(dims)
+        ctl = [(rnd.choice(dims), rnd.choice(dims)) for _ in range(rnd.choice([1, 1, 2]))]
+        n_t, n_c = h * w, sum(a * b for a, b in ctl)
+        lens.append(n_t + n_c)
+        samples.append(dict(image_latents=torch.randn(n_t, 64, generator=g).half(), control_latents=torch.randn(n_c, 64, generator=g).half(),
+                            hw=(h, w), control_hw=ctl, noise=torch.randn(n_t, 64, generator=g).to(torch.bfloat16),
+                            t=torch.rand((), generator=g).to(torch.bfloat16)))
+    txt = dict(text_ids=torch.zeros(T, 3), pooled_prompt_embeds=torch.randn(B, 16, generator=g).half(),
+               prompt_embeds=torch.randn(B, T, 64, generator=g).half())
+    return samples, txt, lens, dict(r=rnd.choice([2, 4, 8]), fused=rnd.random() < 0.6,
+                                    targets=tuple(sorted(rnd.sample(_FLUX_TARGETS, rnd.choice([2, 4, 13])))))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_flux_multires_step_shape_fuzz_vs_oracle(seed):
+    """cfg #5 class of inputs: ragged batches (every sample its own target grid and 1-2 control grids), right-padded, additive key
+    mask, per-sample RoPE; padded output rows exactly zero; loss / prediction / every adapter gradient vs the oracle restatement of
+    the reference's custom model (transformer_flux_custom.py)."""
+    from common import FLUX_TINY, fill_weights
+    from oracle import flux_dit as FO
+    from oracle import qwen_dit as O
+    from parity_util import relmax
+    from qflux_amd.models import FluxTransformer2DModel
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import FluxKontextTrainStep
+    BF = torch.bfloat16
+    samples, txt, lens, opt = _flux_multires_case(seed)
+    cfg = dict(FLUX_TINY, guidance_embeds=True, joint_attention_dim=64)
+    oracle = FO.OracleFluxDiT(**cfg)
+    O.add_lora(oracle, r=opt["r"], lora_alpha=2 * opt["r"], adapter_name="a", target_modules=opt["targets"])
+    fill_weights(oracle, seed=6 + seed)
+    for n, p in oracle.named_parameters():
+        if "lora" not in n:
+            p.data = p.data.to(BF)
+    with torch.device(DEV):
+        hip = FluxTransformer2DModel(**cfg)
+    hip.add_adapter(LoraConfig(r=opt["r"], lora_alpha=2 * opt["r"], target_modules=list(opt["targets"])), "a")
+    hip.load_state_dict(oracle.state_dict(), strict=True)
+    so = [dict(s, control_latents=s["control_latents"].to(BF)) for s in samples]
+    loss_o, pred_o = FO.flux_compute_loss_multires(oracle, so, txt, BF, return_pred=True)
+    loss_o.float().backward()
+    step = FluxKontextTrainStep(hip)
+    if opt["fused"]:
+        loss_h = step.forward_backward_multires(samples, txt)
+    else:
+        loss_h = step.compute_loss_multires(samples, txt)
+        loss_h.backward()
+    plans = [p for k, p in hip._plans.items() if "multires" in k]
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    worst = max([relmax(p.grad, og[n]) for n, p in hip.named_parameters() if "lora" in n and og[n] is not None] + [0.0])
+    e_pred = None
+    if plans:      # a batch whose samples all share one shape takes the shared-RoPE program (transformer_flux_custom.py:262-273)
+        out = plans[0].A["out"].view(len(samples), -1, 64)
+        e_pred = relmax(out[:, :pred_o.shape[1]], pred_o)
+        for b, Ln in enumerate(lens):
+            assert out[b, Ln:].numel() == 0 or out[b, Ln:].abs().max().item() == 0.0
+    print(dict(B=len(samples), T=txt["prompt_embeds"].shape[1], lens=lens, **opt), "loss", loss_o.item(), loss_h.item(), "pred", e_pred, "grad", worst)
+    assert abs(loss_h.item() - loss_o.item()) / abs(loss_o.item()) < 2e-2
+    assert (e_pred is None or e_pred < 2e-2) and worst < 8e-2
