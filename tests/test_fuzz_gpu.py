@@ -119,3 +119,50 @@ def test_flux_multires_step_shape_fuzz_vs_oracle(seed):
     print(dict(B=len(samples), T=txt["prompt_embeds"].shape[1], lens=lens, **opt), "loss", loss_o.item(), loss_h.item(), "pred", e_pred, "grad", worst)
     assert abs(loss_h.item() - loss_o.item()) / abs(loss_o.item()) < 2e-2
     assert (e_pred is None or e_pred < 2e-2) and worst < 8e-2
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_qwen_multires_forward_backward_shape_fuzz_vs_oracle(seed):
+    """Qwen multi-resolution model (transformer_qwen_custom.py:384-573) on random ragged batches: per-sample shape lists of 2-3
+    images, ragged text lengths, right-padded to the batch maximum with the padding mask.  Valid rows vs the oracle, padded rows
+    exactly zero, every adapter gradient."""
+    from common import TINY
+    from parity_util import build_pair
+    BF = torch.bfloat16
+    rnd = random.Random(4000 + seed)
+    g = torch.Generator().manual_seed(4000 + seed)
+    B = rnd.choice([2, 3, 4])
+    dims = [1, 2, 3, 4, 5, 6, 8]
+    shapes = [[(1, rnd.choice(dims), rnd.choice(dims)) for _ in range(rnd.choice([2, 2, 3]))] for _ in range(B)]
+    n_img = [sum(f * h * w for f, h, w in sh) for sh in shapes]
+    S_max, T = max(n_img), rnd.choice([4, 9, 17])
+    lens = [rnd.randint(1, T) for _ in range(B)]
+    lens[rnd.randrange(B)] = T
+    full = torch.zeros(B, T + S_max, dtype=torch.bool)
+    x = torch.zeros(B, S_max, 64)
+    pe = torch.zeros(B, T, TINY["joint_attention_dim"])
+    for b in range(B):
+        full[b, :lens[b]] = True
+        full[b, T:T + n_img[b]] = True
+        x[b, :n_img[b]] = torch.randn(n_img[b], 64, generator=g)
+        pe[b, :lens[b]] = torch.randn(lens[b], TINY["joint_attention_dim"], generator=g) * 4
+    x, pe = x.to(BF), pe.to(BF)
+    tt = torch.rand(B, generator=g)
+    tgt = torch.randn(B, S_max, TINY["out_channels"] * 4, generator=g)
+    valid = full[:, T:]
+    r = rnd.choice([2, 4, 8])
+    targets = tuple(sorted(rnd.sample(_QWEN_TARGETS, rnd.choice([2, 4, 12]))))
+    oracle, hip = build_pair(dict(TINY), r=r, device=DEV, targets=targets, seed=2 + seed)
+    out_o = oracle(hidden_states=x, encoder_hidden_states=pe, timestep=tt, img_shapes=shapes, txt_seq_lens=lens, attention_mask=full)[0]
+    (((out_o.float() - tgt) ** 2) * valid.unsqueeze(-1)).sum().div(valid.sum() * tgt.shape[-1]).backward()
+    out_h = hip(hidden_states=x.to(DEV), encoder_hidden_states=pe.to(DEV), timestep=tt.to(DEV), img_shapes=shapes, txt_seq_lens=lens,
+                attention_mask=full, return_dict=False)[0]
+    (((out_h.float() - tgt.to(DEV)) ** 2) * valid.to(DEV).unsqueeze(-1)).sum().div(valid.sum().item() * tgt.shape[-1]).backward()
+    oh = out_h.float().cpu()
+    assert (~valid).sum() == 0 or oh[~valid].abs().max().item() == 0.0
+    e = ((oh - out_o.float())[valid].abs().max() / out_o.float()[valid].abs().max()).item()
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    worst = max([((p.grad.cpu() - og[n]).abs().max() / og[n].abs().max()).item() for n, p in hip.named_parameters()
+                 if "lora" in n and og[n] is not None and og[n].abs().max() > 0] + [0.0])
+    print(dict(B=B, T=T, lens=lens, n_img=n_img, r=r, targets=targets), "pred rel", e, "grad worst", worst)
+    assert e < 2e-2 and worst < 8e-2
