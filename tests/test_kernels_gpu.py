@@ -584,6 +584,105 @@ def test_attention_fwd_bwd(dh, S, mask):
     check(f"attn_dv_{dh}_{S}", dqkv[:, :, 2 * D:], g[:, :, 2 * D:], 2e-2)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_attention_shape_fuzz(seed):
+    """Random sequence lengths around every tile edge of the three kernels (32 queries per wave, 64-key tiles, 128 / 256-query
+    blocks, ragged tails of 1..63), batch 1-3, 1-5 heads, both head dims, with / without the additive key mask."""
+    import random
+    rnd = random.Random(500 + seed)
+    dh = rnd.choice([64, 128])
+    S = rnd.choice([1, 2, 31, 33, 63, 65, 127, 129, 191, 255, 257, 383, 385, 511, 513, 700, 1025])
+    Bn, H = rnd.choice([1, 2, 3]), rnd.choice([1, 2, 5])
+    _attention_case(dh, S, rnd.random() < 0.4 and Bn >= 2 and S > 8, Bn, H)
+
+
+def _attention_case(dh, S, mask, Bn, H):
+    ops = _ops()
+    D = H * dh
+    qkv, do, km, S_pad = _attn_case(dh, S, Bn, H, mask)
+    scale = 1.0 / math.sqrt(dh)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, :, i * D:(i + 1) * D].reshape(Bn, S, H, dh).transpose(1, 2) for i in range(3))
+    am = km[:, None, None, :] if km is not None else None
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=am).transpose(1, 2).reshape(Bn, S, D)
+    o.backward(do.float())
+    qd = qkv.to(DEV)
+    ld = 3 * D
+    Q, K, V = qd[:, :, :D], qd[:, :, D:2 * D], qd[:, :, 2 * D:]
+    Vt = ops.transpose_heads(V, ld, Bn, S, S_pad, H, dh)
+    O = torch.empty(Bn, S, D, dtype=BF, device=DEV)
+    lse2 = torch.zeros(Bn, H, S_pad, dtype=torch.float32, device=DEV)
+    kmd = km.to(DEV) if km is not None else None
+    a = ops.attn_args(Bn, S, S_pad, H, dh, scale, Q=Q, K=K, V=V, ldq=ld, ldk=ld, ldv=ld, Vt=Vt, O=O, ldo=D, lse2=lse2,
+                      key_mask=kmd.data_ptr() if kmd is not None else None)
+    ops.attn_call("qfx_attn_fwd", a)
+    tag = f"fuzz_{dh}_{S}_{Bn}_{H}_{int(mask)}"
+    check(f"attn_fwd_{tag}", O, o, 1e-2)
+    dOd = do.to(DEV)
+    Qt = ops.transpose_heads(Q, ld, Bn, S, S_pad, H, dh)
+    Kt = ops.transpose_heads(K, ld, Bn, S, S_pad, H, dh)
+    dOt = ops.transpose_heads(dOd, D, Bn, S, S_pad, H, dh)
+    dsum = torch.zeros(Bn, H, S_pad, dtype=torch.float32, device=DEV)
+    dqkv = torch.zeros(Bn, S, 3 * D, dtype=BF, device=DEV)
+    a.Qt, a.Kt, a.dO, a.lddo, a.dOt, a.dsum = Qt.data_ptr(), Kt.data_ptr(), dOd.data_ptr(), D, dOt.data_ptr(), dsum.data_ptr()
+    a.dQ, a.dK, a.dV = dqkv[:, :, :D].data_ptr(), dqkv[:, :, D:2 * D].data_ptr(), dqkv[:, :, 2 * D:].data_ptr()
+    a.lddq = a.lddk = a.lddv = ld
+    ops.attn_call("qfx_attn_bwd_prep", a)
+    ops.attn_call("qfx_attn_bwd_dq", a)
+    ops.attn_call("qfx_attn_bwd_dkv", a)
+    g = x.grad
+    check(f"attn_dq_{tag}", dqkv[:, :, :D], g[:, :, :D], 2e-2)
+    check(f"attn_dk_{tag}", dqkv[:, :, D:2 * D], g[:, :, D:2 * D], 2e-2)
+    check(f"attn_dv_{tag}", dqkv[:, :, 2 * D:], g[:, :, 2 * D:], 2e-2)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gemm_shape_and_epilogue_fuzz(seed):
+    """Random problem sizes around the tile edges of both tile shapes (M from 1 row up, N and K in steps of 8 / 64), every epilogue,
+    with / without bias, LoRA K-extension (bf16 mid-rounding of the base output) and a row mask, vs the fp32 product with the
+    eager graph's rounding points."""
+    import random
+    ops = _ops()
+    rnd = random.Random(900 + seed)
+    M = rnd.choice([1, 7, 16, 100, 255, 257, 384, 511, 1000, 2432])
+    N = rnd.choice([64, 128, 192, 320, 1024, 3072, 6144])
+    K = 64 * rnd.choice([1, 2, 3, 5, 16, 48])
+    K2 = rnd.choice([0, 0, 64, 128])
+    epi = rnd.choice([0, 1, 2, 3])
+    use_bias = rnd.random() < 0.6
+    a, b = randn(M, K, seed=seed).to(BF), randn(N, K, seed=seed + 1, scale=0.2).to(BF)
+    bias = randn(N, seed=seed + 2).to(BF) if use_bias else None
+    base = a.float() @ b.float().t() + (bias.float() if use_bias else 0.0)
+    kw = {}
+    if K2:
+        a2, b2 = randn(M, K2, seed=seed + 3).to(BF), randn(N, K2, seed=seed + 4, scale=0.1).to(BF)
+        h = rb(rb(base) + a2.float() @ b2.float().t())
+        kw.update(a2=a2.to(DEV), b2=b2.to(DEV))
+    else:
+        h = rb(base)
+    if epi == 0:
+        ref = h
+    elif epi == 1:       # GELU: C = h, C2 = gelu(h)
+        ref = h
+        out2 = torch.empty(M, N, dtype=BF, device=DEV)
+        kw.update(out2=out2)
+    elif epi == 2:       # gate * y + residual
+        gate, res = randn(1, N, seed=seed + 5).to(BF), randn(M, N, seed=seed + 6).to(BF)
+        ref = rb(res.float() + rb(gate.float() * h))
+        kw.update(gate=gate.to(DEV), aux=res.to(DEV))
+    else:                # dGELU: y * gelu'(aux)
+        hx = randn(M, N, seed=seed + 7).to(BF)
+        hh = hx.float().requires_grad_(True)
+        F.gelu(hh, approximate="tanh").sum().backward()
+        ref = rb(h * hh.grad)
+        kw.update(aux=hx.to(DEV))
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV) if use_bias else None, epi=epi, **kw)
+    tag = f"gemm_fuzz_{M}x{N}x{K}+{K2}_epi{epi}"
+    check(tag, out, ref, 1.5e-2)
+    if epi == 1:
+        check(tag + "_gelu", kw["out2"], rb(F.gelu(h, approximate="tanh")), 1.5e-2)
+
+
 # ------------------------------------------------------------------------------------------ criterion / optimizer
 def test_flowmatch_and_mse():
     ops = _ops()
