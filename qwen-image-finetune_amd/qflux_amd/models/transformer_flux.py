@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -652,8 +653,12 @@ class _FluxPlan(_QwenPlan):
         dq2 = A["dqkv"].view(M, 3 * D)
         # d[attn | mlp] = (gate*dx) W_out : attention part -> dO, mlp part through gelu' -> A2[:, :4D]   (+ proj_out's adapter)
         kwa, kwm = {}, {}
+        # the block's weight-gradient problems (up to 8) go out as batched launches right before the LayerNorm backward overwrites
+        # dyg_j -- their operands (dyg_j, dqkv, A2, v^T scratch, the block's kept buffers) stay intact until then; one launch each
+        # they were 8 x 38 latency-bound launches on the main stream (the FLUX programs keep their gradients there)
+        gl = [] if os.environ.get("QFX_FLUX_SINGLE_BATCH", "1") != "0" else None     # None: one launch per problem (A/B switch)
         if wo.lora is not None:
-            kwo = self._site_bwd(p, wo, bb["site_out"], A["dyg_j"], D, M, bb["cat"], 5 * D)
+            kwo = self._site_bwd(p, wo, bb["site_out"], A["dyg_j"], D, M, bb["cat"], 5 * D, defer=gl)
             kwa = dict(kwo, B2=wo.lora.WeT[:D])
             kwm = dict(kwo, B2=wo.lora.WeT[D:])
         self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT, K1=D, M=M, N=D, C_=dao2, ldc=D, **kwa)
@@ -671,24 +676,28 @@ class _FluxPlan(_QwenPlan):
             Rp, Kext = grp["Rp"], grp["Kext"]
             Vth, Vtl = A["Vt_j"]
             Uth, Utl = bb["Uqkv"]
+            dl = [] if gl is not None else None     # the q / k / v down projections of dqkv: one launch
             for sec in range(3):
                 lo = w["qkv"][sec].lora
                 if lo is None:
                     continue
                 sl = slice(sec * Rp, (sec + 1) * Rp)
                 self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=M, K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=Rp,
-                           Ut=(Vth[sl], Vtl[sl]), ext=A["A2"][:, 4 * D + sec * Kext:], ld_ext=ldA2)
+                           Ut=(Vth[sl], Vtl[sl]), ext=A["A2"][:, 4 * D + sec * Kext:], ld_ext=ldA2, defer=dl)
                 self._grad(p, Vt=(Uth[sl], Utl[sl]), R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D, M=M, K=D, G=lo.gB, g_sr=1,
-                           g_sc=lo.r, out_scale=lo.scale)
+                           g_sc=lo.r, out_scale=lo.scale, defer=gl)
+            if dl:
+                self._flush_batch(p, dl, L.LoraDownArgs, lib.qfx_lora_down_batch)
             los = [w["qkv"][sec].lora for sec in range(3)]
             if all(l is not None for l in los):
                 self._grad(p, Vt=(Vth[:3 * Rp], Vtl[:3 * Rp]), R=3 * Rp, r_valid=los[0].r, group_R=Rp, X=bb["xm"], ldx=D, M=M, K=D,
-                           G=[l.gA for l in los], g_sr=D, g_sc=1)
+                           G=[l.gA for l in los], g_sr=D, g_sc=1, defer=gl)
             else:
                 for sec, lo in enumerate(los):
                     if lo is not None:
                         sl = slice(sec * Rp, (sec + 1) * Rp)
-                        self._grad(p, Vt=(Vth[sl], Vtl[sl]), R=Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1)
+                        self._grad(p, Vt=(Vth[sl], Vtl[sl]), R=Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1,
+                                   defer=gl)
             K2 = 4 * D + 3 * Kext
         if ml.lora is not None:
             # proj_mlp's adapter: v = d(mlp pre-act) (sB)^T goes into the last K-extension columns of A2; dB / dA as for any site
@@ -696,8 +705,9 @@ class _FluxPlan(_QwenPlan):
             sb = bb["site_mlp"]
             self._down(p, X=A["A2"], ldx=ldA2, M=M, K=4 * D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp, Ut=sb["V"],
                        ext=A["A2"][:, K2:], ld_ext=ldA2)
-            self._grad(p, Vt=sb["U"], R=lo.Rp, r_valid=lo.r, X=A["A2"], ldx=ldA2, M=M, K=4 * D, G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale)
-            self._grad(p, Vt=sb["V"], R=lo.Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1)
+            self._grad(p, Vt=sb["U"], R=lo.Rp, r_valid=lo.r, X=A["A2"], ldx=ldA2, M=M, K=4 * D, G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale,
+                       defer=gl)
+            self._grad(p, Vt=sb["V"], R=lo.Rp, r_valid=lo.r, X=bb["xm"], ldx=D, M=M, K=D, G=lo.gA, g_sr=D, g_sc=1, defer=gl)
             K2 += lo.Kext
         # d(norm_x) = [dq|dk|dv] Wqkv + [d mlp | LoRA v] [W_mlp ; A]
         if getattr(self.model, "_quant", None) == "mxfp8-fb" and D % 128 == 0 and D >= 1024:
@@ -711,6 +721,8 @@ class _FluxPlan(_QwenPlan):
             dm = A["dsmods"][i]
             self._mod_grad(p, dy=A["dxm_j"], x=x, rows=M, rpb=S, dshift=dm[:, 0:D], dscale=dm[:, D:2 * D], dgate=dm[:, 2 * D:3 * D],
                            dxo=dJ_out, y=bb["y"], out_bs=3 * D, row_mask=self.rmask["joint"])
+        if gl:
+            self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
         if i > 0:
             gp = A["smods"][i - 1][:, 2 * D:3 * D]
             p.c(lib.qfx_ln_modulate_bwd, _ptr(A["dxm_j"]), _ptr(x), _ptr(mod[:, D:2 * D]), 3 * D, _ptr(dJ_out), _ptr(gp), 3 * D,

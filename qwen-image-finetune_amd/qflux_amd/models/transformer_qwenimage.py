@@ -1147,17 +1147,19 @@ class _QwenPlan:
                    ext=sb["ext"], ld_ext=sb["ext"].stride(0), rpb=rpb, x_map=x_map)
         return dict(A2=sb["ext"], lda2=sb["ext"].stride(0), B2=lo.We, ldb2=lo.We.stride(0), K2=lo.Kext)
 
-    def _site_bwd(self, p, lw, sb, dY, ldy, M, Xin, ldxin, rpb=None, dy_map=(0, 0), x_map=(0, 0), WeT=None):
-        """v = dy (sB)^T, dB += dy^T u, dA += v^T x; returns the K-extension arguments of the site's dX GEMM."""
+    def _site_bwd(self, p, lw, sb, dY, ldy, M, Xin, ldxin, rpb=None, dy_map=(0, 0), x_map=(0, 0), WeT=None, defer=None):
+        """v = dy (sB)^T, dB += dy^T u, dA += v^T x; returns the K-extension arguments of the site's dX GEMM.  defer: list that
+        collects the two weight-gradient problems for a batched launch by the caller (who keeps dY / Xin / the site buffers intact
+        until it flushes)."""
         if lw.lora is None:
             return {}
         lo = lw.lora
         self._down(p, X=dY, ldx=ldy, M=M, K=lw.N, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo, ldw=lo.Bt_hi.stride(0), R=lo.Rp, Ut=sb["V"],
                    ext=sb["extb"], ld_ext=sb["extb"].stride(0), rpb=rpb, x_map=dy_map)
         self._grad(p, Vt=sb["U"], R=lo.Rp, r_valid=lo.r, X=dY, ldx=ldy, M=M, K=lw.N, G=lo.gB, g_sr=1, g_sc=lo.r, out_scale=lo.scale,
-                   rpb=rpb, x_map=dy_map)
+                   rpb=rpb, x_map=dy_map, defer=defer)
         self._grad(p, Vt=sb["V"], R=lo.Rp, r_valid=lo.r, X=Xin, ldx=ldxin, M=M, K=lo.A_hi.shape[1], G=lo.gA, g_sr=lo.A_hi.shape[1], g_sc=1,
-                   rpb=rpb, x_map=x_map)
+                   rpb=rpb, x_map=x_map, defer=defer)
         WeT = lo.WeT if WeT is None else WeT
         return dict(A2=sb["extb"], lda2=sb["extb"].stride(0), B2=WeT, ldb2=WeT.stride(0), K2=lo.Kext)
 
