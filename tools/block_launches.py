@@ -7,6 +7,10 @@ from qflux_amd.modules import LoraConfig
 which = sys.argv[1] if len(sys.argv) > 1 else "qwen"
 targets = sys.argv[2] if len(sys.argv) > 2 else ""
 dev = torch.device("cuda", 0)
+if targets == "regex":
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tfg", os.path.join(ROOT, "tests", "test_flux_gpu.py")); m_ = importlib.util.module_from_spec(spec); spec.loader.exec_module(m_)
+    targets = m_._REFERENCE_REGEX
 kw = {} if not targets else dict(target_modules=targets)
 if which == "qwen":
     from qflux_amd.models import QwenImageTransformer2DModel
@@ -48,4 +52,8 @@ for ent in plan.bwd.calls[prev:a]:
     if ent[0] is None: names.append("py"); continue
     n = ent[0].__name__ + (f"[{ent[1][1]}]" if "batch" in ent[0].__name__ or "grouped" in ent[0].__name__ else "") + ("@side" if len(ent) > 2 else "")
     names.append(n)
-print(f"backward of the middle block: {len([n for n in names if n != 'py'])} launches\n  " + "\n  ".join(names))
+print(f"backward segment up to the middle block's mark: {len([n for n in names if n != 'py'])} launches\n  " + "\n  ".join(names))
+fm = [i for i, e in enumerate(plan.fwd.calls) if e[0] is not None and e[0].__name__.startswith("qfx_attn_fwd")]
+seg = plan.fwd.calls[fm[-2] + 1:fm[-1] + 1] if len(fm) >= 2 else plan.fwd.calls
+fn = [("py" if e[0] is None else e[0].__name__ + (f"[{e[1][1]}]" if "batch" in e[0].__name__ or "grouped" in e[0].__name__ else "")) for e in seg]
+print(f"forward, attention to attention (one block): {len([n for n in fn if n != 'py'])} launches\n  " + "\n  ".join(fn))
