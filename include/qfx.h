@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QFX_ABI_VERSION 3
+#define QFX_ABI_VERSION 4
 
 #define QFX_OK 0
 #define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
@@ -237,6 +237,9 @@ typedef struct qfx_mod_grad_args {
   const float* row_mask; int32_t rows; int32_t D; int32_t rows_per_batch; float eps;
 } qfx_mod_grad_args;
 int qfx_mod_grad(const qfx_mod_grad_args* a, void* stream);
+/* ABI 4: n <= QFX_MAX_LN_BATCH problems of one width class (ceil(D / 512) equal) in ONE launch -- the image and the text stream of a
+ * block (the 384-row text problem otherwise pays a dispatch gap and a latency chain of its own for 48 blocks of work). */
+int qfx_mod_grad_batch(const qfx_mod_grad_args* list, int32_t n, void* stream);
 
 /* dyg = bf16(gate[b] * dx) only (used where no LayerNorm precedes). */
 int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg,

@@ -224,12 +224,22 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
 // the LayerNorm kernels), accumulates its column sums in registers, the four waves combine in LDS and the block issues ONE fp32
 // atomic per column and output.  HBM-bound (reads dy, x [, dxo, y] once).
 constexpr int MG_RPW = 2;
+// Batched: up to QFX_MAX_LN_BATCH problems of one width share a launch (the image and the text stream of a block: the 384-row text
+// problem otherwise pays a full dispatch gap + latency chain for 48 blocks of work); blockIdx.x walks the problems' row chunks.
+struct ModGradBatch { qfx_mod_grad_args a[QFX_MAX_LN_BATCH]; int start[QFX_MAX_LN_BATCH + 1]; int n; };
 template <int NP>
-__global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a) {
+__global__ __launch_bounds__(256) void mod_grad_kernel(const ModGradBatch bt) {
   constexpr int NS = NP <= 6 ? 4 : 2;         // LDS slabs: one per wave (144 KiB at NP = 6; the kernel runs one block per CU anyway), two beyond
   __shared__ float sacc[NS][3][NP * 512];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.y;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < QFX_MAX_LN_BATCH; ++i)
+    if (i < bt.n && (int)blockIdx.x >= bt.start[i]) pi = i;
+  const qfx_mod_grad_args& a = pi == 0 ? bt.a[0] : (pi == 1 ? bt.a[1] : (pi == 2 ? bt.a[2] : bt.a[3]));
+  const int bx = (int)blockIdx.x - bt.start[pi];
+  if ((int64_t)b * a.rows_per_batch >= a.rows) return;      // grid.y is sized for the problem with the most samples
   const int D = a.D;
   const bool has_gate = a.dgate != nullptr;
   float as[NP][8], ac[NP][8], ag[NP][8];
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const qfx_mod_grad_args a
   // wave a chain of 8 x 3 dependent memory round trips.  Two rows per wave fill the chip four times over (one global atomic per
   // column and block: 4x the atomics, still < 10 us of them), and all four streams of a row (x, dy, dxo, y) are requested
   // together, packed.  (114 -> 45 us per launch with the plain LDS combine below; 29 -> 10 ms of an all-linear step.)
-  const int r_lo = blockIdx.x * (4 * MG_RPW) + w * MG_RPW;
+  const int r_lo = bx * (4 * MG_RPW) + w * MG_RPW;
   for (int rr = 0; rr < MG_RPW; ++rr) {
     const int rl = r_lo + rr;
     if (rl >= a.rows_per_batch) break;            // wave-uniform
@@ -1007,25 +1017,44 @@ extern "C" int qfx_ln_modulate_bwd(const uint16_t* dy, const uint16_t* x, const 
   return qfx_ln_modulate_bwd_batch(&a, 1, stream);
 }
 
-extern "C" int qfx_mod_grad(const qfx_mod_grad_args* a, void* stream) {
-  if (!a || !a->dy || !a->x || !a->dshift || !a->dscale) return QFX_EINVAL;
-  if (a->rows <= 0 || a->D <= 0 || (a->D % 8) || a->D > MAXP * 512 || a->rows_per_batch <= 0) return QFX_EINVAL;
-  if ((a->ld_dy % 8) || (a->ld_x % 8)) return QFX_EINVAL;
-  if ((a->dgate != nullptr) != (a->dxo != nullptr) || (a->dgate != nullptr) != (a->y != nullptr)) return QFX_EINVAL;
-  if (a->dgate && ((a->ld_dxo % 8) || (a->ld_y % 8))) return QFX_EINVAL;
-  const int B = (a->rows + a->rows_per_batch - 1) / a->rows_per_batch;
-  dim3 grid((a->rows_per_batch + 4 * MG_RPW - 1) / (4 * MG_RPW), B);
+extern "C" int qfx_mod_grad_batch(const qfx_mod_grad_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > QFX_MAX_LN_BATCH) return QFX_EINVAL;
+  ModGradBatch bt;
+  int blocks = 0, Bmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const qfx_mod_grad_args* a = &list[i];
+    if (!a->dy || !a->x || !a->dshift || !a->dscale) return QFX_EINVAL;
+    if (a->rows <= 0 || a->D <= 0 || (a->D % 8) || a->D > MAXP * 512 || a->rows_per_batch <= 0) return QFX_EINVAL;
+    if ((a->ld_dy % 8) || (a->ld_x % 8)) return QFX_EINVAL;
+    if ((a->dgate != nullptr) != (a->dxo != nullptr) || (a->dgate != nullptr) != (a->y != nullptr)) return QFX_EINVAL;
+    if (a->dgate && ((a->ld_dxo % 8) || (a->ld_y % 8))) return QFX_EINVAL;
+    if ((a->D + 511) / 512 != (list[0].D + 511) / 512) return QFX_EINVAL;      /* one register-array size per launch */
+    bt.a[i] = *a;
+    bt.start[i] = blocks;
+    blocks += (a->rows_per_batch + 4 * MG_RPW - 1) / (4 * MG_RPW);
+    const int B = (a->rows + a->rows_per_batch - 1) / a->rows_per_batch;
+    Bmax = B > Bmax ? B : Bmax;
+  }
+  for (int i = n; i <= QFX_MAX_LN_BATCH; ++i) bt.start[i] = blocks;
+  for (int i = n; i < QFX_MAX_LN_BATCH; ++i) bt.a[i] = list[0];
+  bt.n = n;
+  dim3 grid(blocks, Bmax);
   hipStream_t s = (hipStream_t)stream;
-  switch ((a->D + 511) / 512) {
-    case 1: hipLaunchKernelGGL(mod_grad_kernel<1>, grid, dim3(256), 0, s, *a); break;
-    case 2: hipLaunchKernelGGL(mod_grad_kernel<2>, grid, dim3(256), 0, s, *a); break;
-    case 3: hipLaunchKernelGGL(mod_grad_kernel<3>, grid, dim3(256), 0, s, *a); break;
-    case 4: hipLaunchKernelGGL(mod_grad_kernel<4>, grid, dim3(256), 0, s, *a); break;
-    case 5: case 6: hipLaunchKernelGGL(mod_grad_kernel<6>, grid, dim3(256), 0, s, *a); break;
-    default: hipLaunchKernelGGL(mod_grad_kernel<8>, grid, dim3(256), 0, s, *a); break;
+  switch ((list[0].D + 511) / 512) {
+    case 1: hipLaunchKernelGGL(mod_grad_kernel<1>, grid, dim3(256), 0, s, bt); break;
+    case 2: hipLaunchKernelGGL(mod_grad_kernel<2>, grid, dim3(256), 0, s, bt); break;
+    case 3: hipLaunchKernelGGL(mod_grad_kernel<3>, grid, dim3(256), 0, s, bt); break;
+    case 4: hipLaunchKernelGGL(mod_grad_kernel<4>, grid, dim3(256), 0, s, bt); break;
+    case 5: case 6: hipLaunchKernelGGL(mod_grad_kernel<6>, grid, dim3(256), 0, s, bt); break;
+    default: hipLaunchKernelGGL(mod_grad_kernel<8>, grid, dim3(256), 0, s, bt); break;
   }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
+}
+
+extern "C" int qfx_mod_grad(const qfx_mod_grad_args* a, void* stream) {
+  if (!a) return QFX_EINVAL;
+  return qfx_mod_grad_batch(a, 1, stream);
 }
 
 extern "C" int qfx_gate_mul(const uint16_t* dx, const uint16_t* gate, int64_t gate_bstride, uint16_t* dyg, int32_t rows,

@@ -135,7 +135,7 @@ class AttnArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 3        # QFX_ABI_VERSION
+ABI_VERSION = 4        # QFX_ABI_VERSION
 MAX_BATCH = 8          # QFX_MAX_BATCH
 MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
@@ -159,6 +159,7 @@ SYMBOLS = {
     "qfx_ln_down_fwd": (C.c_int, [C.POINTER(LnDownArgs), C.c_int32, _vp]),
     "qfx_ln_modulate_bwd_batch": (C.c_int, [C.POINTER(LnBwdArgs), C.c_int32, _vp]),
     "qfx_mod_grad": (C.c_int, [C.POINTER(ModGradArgs), _vp]),
+    "qfx_mod_grad_batch": (C.c_int, [C.POINTER(ModGradArgs), C.c_int32, _vp]),
     "qfx_gate_mul": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "qfx_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f, _vp]),
     "qfx_mod_gemv": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

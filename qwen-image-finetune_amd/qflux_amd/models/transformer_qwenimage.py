@@ -1117,7 +1117,9 @@ class _QwenPlan:
         prog.keep.append(a)
         prog.c(lib.qfx_lora_grad, C.byref(a))
 
-    def _mod_grad(self, prog, *, dy, x, rows, rpb, dshift, dscale, out_bs, dgate=None, dxo=None, y=None, row_mask=None, ld=None):
+    def _mod_grad(self, prog, *, dy, x, rows, rpb, dshift, dscale, out_bs, dgate=None, dxo=None, y=None, row_mask=None, ld=None,
+                  defer=None):
+        """defer: list collecting the problem for ONE batched launch (_flush_mod_grad) -- the image and text stream of a block."""
         a = L.ModGradArgs()
         D = self.D
         ld = D if ld is None else ld
@@ -1125,8 +1127,20 @@ class _QwenPlan:
         a.dxo, a.ld_dxo, a.y, a.ld_y = _ptr(dxo), ld, _ptr(y), ld
         a.dshift, a.dscale, a.dgate, a.out_bstride = _ptr(dshift), _ptr(dscale), _ptr(dgate), out_bs
         a.row_mask, a.rows, a.D, a.rows_per_batch, a.eps = _ptr(row_mask), rows, D, rpb, 1e-6
+        if defer is not None:
+            defer.append(a)
+            return
         prog.keep.append(a)
         prog.c(lib.qfx_mod_grad, C.byref(a))
+
+    @staticmethod
+    def _flush_mod_grad(prog, pending):
+        for i in range(0, len(pending), L.MAX_LN_BATCH):
+            chunk = pending[i:i + L.MAX_LN_BATCH]
+            arr = (L.ModGradArgs * len(chunk))(*chunk)
+            prog.keep.append(arr)
+            prog.c(lib.qfx_mod_grad_batch, arr, len(chunk))
+        pending.clear()
 
     # ------------------------------------------------------------------ stand-alone adapted linears (embedders, output projection ...)
     def _site_alloc(self, lw, M):
@@ -1451,11 +1465,14 @@ class _QwenPlan:
             if ge:
                 self._flush_batch(p, ge, L.LoraGradArgs, lib.qfx_lora_grad_batch)
             if dmods is not None:   # d(shift2, scale2, gate2): dy = d(xm2) (fc1 dX output), LN input x1, gate side dx2 * y2
+                mg = [] if os.environ.get("QFX_MOD_GRAD_BATCH", "1") != "0" else None     # None: one launch per stream (A/B switch)
                 for s, _ in live:
                     dm = dmods[s]
                     self._mod_grad(p, dy=A["dxm"][s], x=bb["x1"][s], rows=rows[s], rpb=rpb[s], dshift=dm[:, 3 * D:4 * D],
                                    dscale=dm[:, 4 * D:5 * D], dgate=dm[:, 5 * D:6 * D], dxo=dx2[s], y=bb["y2"][s], out_bs=6 * D,
-                                   row_mask=self.rmask[s])
+                                   row_mask=self.rmask[s], defer=mg)
+                if mg:
+                    self._flush_mod_grad(p, mg)
             self._side_join(p, keep=1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
@@ -1540,12 +1557,15 @@ class _QwenPlan:
             if i > 0:
                 self._gemm_group(p, groups)
                 if dmods is not None:   # d(shift1, scale1, gate1): dy = d(xm1) (q/k/v dX output), LN input x_in, gate side dx1 * y1
+                    mg = [] if os.environ.get("QFX_MOD_GRAD_BATCH", "1") != "0" else None
                     for s, sidx in STREAMS:
                         dm = dmods[s]
                         dead = last and s == "txt"     # no out-projection / residual gradient on the last block's text tail
                         self._mod_grad(p, dy=A["dxm"][s], x=x_in[s], rows=rows[s], rpb=rpb[s], dshift=dm[:, 0:D], dscale=dm[:, D:2 * D],
                                        dgate=None if dead else dm[:, 2 * D:3 * D], dxo=None if dead else A["dx1"][s],
-                                       y=None if dead else bb["y1"][s], out_bs=6 * D, row_mask=self.rmask[s])
+                                       y=None if dead else bb["y1"][s], out_bs=6 * D, row_mask=self.rmask[s], defer=mg)
+                    if mg:
+                        self._flush_mod_grad(p, mg)
                 lnl = []
                 for s, sidx in STREAMS:
                     dres = None if (last and s == "txt") else A["dx1"][s]

@@ -683,6 +683,66 @@ def test_gemm_shape_and_epilogue_fuzz(seed):
         check(tag + "_gelu", kw["out2"], rb(F.gelu(h, approximate="tanh")), 1.5e-2)
 
 
+def test_mod_grad_batch_matches_column_sums_and_single_launches():
+    """qfx_mod_grad(_batch): d(shift) = sum_rows dy, d(scale) = sum_rows dy * bf16(LN(x)), d(gate) = sum_rows dxo * y per sample --
+    two problems of different row counts in ONE launch (one without the gate side, one with a row mask) vs fp32 torch and vs
+    the same problems launched one by one."""
+    import ctypes as C_
+    from qflux_amd import _lib as L
+    ops = _ops()
+    D, Bn = 1024, 2
+    g = torch.Generator().manual_seed(77)
+    probs = []
+    for rpb, gate, masked in ((40, True, False), (9, False, True)):
+        rows = Bn * rpb
+        dy = torch.randn(rows, D, generator=g).to(BF); x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(BF)
+        dxo = torch.randn(rows, D, generator=g).to(BF); y = torch.randn(rows, D, generator=g).to(BF)
+        mask = torch.ones(rows)
+        if masked:
+            mask[3] = 0; mask[rpb + 5] = 0
+        probs.append(dict(rpb=rpb, rows=rows, gate=gate, dy=dy, x=x, dxo=dxo, y=y, mask=mask if masked else None))
+
+    def run(batched):
+        outs, args, keep = [], [], []
+        for pr in probs:
+            o = torch.zeros(Bn, 3 * D, device=DEV)
+            a = L.ModGradArgs()
+            t = {k: pr[k].to(DEV) for k in ("dy", "x", "dxo", "y")}
+            keep.append(t)
+            a.dy, a.ld_dy, a.x, a.ld_x = t["dy"].data_ptr(), D, t["x"].data_ptr(), D
+            if pr["gate"]:
+                a.dxo, a.ld_dxo, a.y, a.ld_y = t["dxo"].data_ptr(), D, t["y"].data_ptr(), D
+                a.dgate = o.data_ptr() + 2 * D * 4
+            a.dshift, a.dscale, a.out_bstride = o.data_ptr(), o.data_ptr() + D * 4, 3 * D
+            if pr["mask"] is not None:
+                mk = pr["mask"].to(DEV); keep.append(mk); a.row_mask = mk.data_ptr()
+            a.rows, a.D, a.rows_per_batch, a.eps = pr["rows"], D, pr["rpb"], 1e-6
+            outs.append(o); args.append(a)
+        if batched:
+            arr = (L.ModGradArgs * len(args))(*args)
+            L.check(L.lib.qfx_mod_grad_batch(arr, len(args), ops.stream_ptr()), "batch")
+        else:
+            for a in args:
+                L.check(L.lib.qfx_mod_grad(C_.byref(a), ops.stream_ptr()), "single")
+        torch.cuda.synchronize()
+        return [o.cpu() for o in outs]
+
+    ob, os_ = run(True), run(False)
+    for pi, pr in enumerate(probs):
+        xf, dyf = pr["x"].float(), pr["dy"].float()
+        xh = rb((xf - xf.mean(-1, keepdim=True)) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + 1e-6))
+        m = (pr["mask"] if pr["mask"] is not None else torch.ones(pr["rows"])).unsqueeze(-1)
+        ref_shift = (dyf * m).view(Bn, pr["rpb"], D).sum(1)
+        ref_scale = (dyf * xh * m).view(Bn, pr["rpb"], D).sum(1)
+        check(f"mod_grad_shift_{pi}", ob[pi][:, :D], ref_shift, 1e-4)
+        check(f"mod_grad_scale_{pi}", ob[pi][:, D:2 * D], ref_scale, 2e-3)
+        if pr["gate"]:
+            check(f"mod_grad_gate_{pi}", ob[pi][:, 2 * D:], (pr["dxo"].float() * pr["y"].float() * m).view(Bn, pr["rpb"], D).sum(1), 1e-4)
+        else:
+            assert ob[pi][:, 2 * D:].abs().max() == 0
+        assert (ob[pi] - os_[pi]).abs().max().item() <= 1e-5 * ob[pi].abs().max().item()      # fp32 atomics: order only
+
+
 # ------------------------------------------------------------------------------------------ criterion / optimizer
 def test_flowmatch_and_mse():
     ops = _ops()
