@@ -330,7 +330,12 @@ def main():
     # ---- data-parallel exchange: what the bucketed all-reduce costs on top of the step, and how much of it the backward hides
     dp = None
     if world > 1:
-        replicas_ok = bool(step.check_replicas())   # adapter weights + optimizer state identical on every rank after the timed steps
+        try:      # adapter weights + optimizer state identical on every rank after the timed steps (every rank reaches the same verdict)
+            replicas_ok = bool(step.check_replicas())
+        except RuntimeError as e:
+            replicas_ok = False
+            if rank == 0:
+                print(f"[bench] replica check failed: {e}", file=sys.stderr)
         gflat = dit.lora_store.gflat
         k2 = max(2, min(args.steps, 10))
         step.world = 1                      # same step without the gradient exchange (measurement only: replicas would diverge)
