@@ -41,6 +41,8 @@ class LoraGradSync:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.enabled = True
+        self.exchanged = False     # set by finish(): the flat gradient currently holds the exchanged + averaged sum (cleared by the
+                                   # trainer step's zero_grad / by the next local-only backward)
         self._pending, self._finish = [], None
 
     def hook(self):
@@ -87,6 +89,7 @@ class LoraGradSync:
         self._pending = []
         if average and self.world > 1:
             self.dit.lora_store.gflat.mul_(1.0 / self.world)
+        self.exchanged = True
 
 
 class DataParallelMixin:
@@ -116,6 +119,8 @@ class DataParallelMixin:
         """The autograd node's backward: launch program + (when enabled) the overlapped exchange."""
         dp = self._dp
         if dp is None or not dp.enabled:
+            if dp is not None:
+                dp.exchanged = False       # local-only gradients were just added on top of whatever the buffer held
             plan.run_backward(grad_out)
             return
         plan.run_backward(grad_out, on_segment=dp.hook())

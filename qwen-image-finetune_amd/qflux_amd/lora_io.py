@@ -55,6 +55,23 @@ def get_lora_state_dict(model, style: str = "diffusers", prefix: str = "transfor
     return out
 
 
+def get_peft_model_state_dict(model, state_dict: dict | None = None, adapter_name: str = "default") -> dict:
+    """peft.utils.get_peft_model_state_dict for a LoRA config with bias="none" (third party, restated -- parity unpinned), i.e. what
+    BaseTrainer.save_lora feeds to convert_state_dict_to_diffusers (base_trainer.py:870-872):
+        config = model.peft_config[adapter_name]                                  (KeyError for an unknown adapter, like peft)
+        keep   = {k: v for k, v in model.state_dict().items() if "lora_" in k}   (bias == "none")
+        keep   = {k: v for k in keep if "lora_" in k and adapter_name in k}
+        return {k.replace(f".{adapter_name}", ""): v}
+    The drop-in DiTs satisfy the same rule under the real function: `peft_config[adapter_name]` exists after add_adapter and the
+    state-dict keys are `<module>.lora_A.<adapter>.weight` / `<module>.lora_B.<adapter>.weight`."""
+    cfg = model.peft_config[adapter_name]
+    if getattr(cfg, "bias", "none") != "none" or getattr(cfg, "use_dora", False):
+        raise NotImplementedError("only LoRA configs with bias='none' and no DoRA are produced by the reference (base_trainer.py:932-937)")
+    sd = model.state_dict() if state_dict is None else state_dict
+    keep = {k: v for k, v in sd.items() if "lora_" in k and adapter_name in k}
+    return {k.replace(f".{adapter_name}", ""): v for k, v in keep.items()}
+
+
 def save_lora_weights(model, save_folder: str, style: str = "diffusers") -> str:
     os.makedirs(save_folder, exist_ok=True)
     path = os.path.join(save_folder, WEIGHT_NAME)

@@ -18,6 +18,7 @@ import math
 import os
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from .. import _lib as L
@@ -307,7 +308,22 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         self._adapter_name = adapter_name
         for pn, p in self.named_parameters():
             p.requires_grad_("lora" in pn)
+        # diffusers' PeftAdapterMixin.add_adapter keeps the config under `peft_config[adapter_name]`: peft's
+        # get_peft_model_state_dict(model, adapter_name=...) -- what BaseTrainer.save_lora calls on the unwrapped DiT
+        # (base_trainer.py:870-872) -- reads `.peft_type`, `.bias`, `.use_dora`, `.target_modules` ... from it and then filters
+        # model.state_dict() by "lora_" + adapter name.  A real peft.LoraConfig passes through untouched; the stand-in
+        # (modules.LoraConfig) carries the same fields.
+        if not isinstance(getattr(self, "peft_config", None), dict):
+            self.peft_config = {}
+        self.peft_config[adapter_name] = cfg
+        self._hf_peft_config_loaded = True
         self._invalidate()
+        # The reference wraps its LoRA container in DDP right after this call (base_trainer.py:384-393); the kernels write dA / dB
+        # straight into the flat gradient buffer, so the model exchanges them itself.  Under an initialised multi-rank process
+        # group that happens without an extra line in the trainer (no-op otherwise; call enable_data_parallel(...) again to
+        # choose a process group / bucket size).
+        if self._dp is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.enable_data_parallel()
         return names
 
     _LORA_SUFFIXES = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj", "attn.add_k_proj",
@@ -339,7 +355,22 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         return any(isinstance(m, QfxLoraLinear) for m in self._cond_modules())
 
     def set_adapter(self, adapter_name):
+        """PeftAdapterMixin.set_adapter (base_trainer.py:940-941): make `adapter_name` the active adapter of every wrapped linear.
+        Plans bake adapter pointers, rank and scaling in at build time, so a change of the active adapter drops them."""
+        if isinstance(adapter_name, (list, tuple)):
+            if len(adapter_name) != 1:
+                raise NotImplementedError("one active adapter at a time")
+            adapter_name = adapter_name[0]
+        wrapped = [m for m in self.modules() if isinstance(m, QfxLoraLinear)]
+        if wrapped and not any(adapter_name in m.lora_A for m in wrapped):
+            raise ValueError(f"Adapter {adapter_name!r} not found (known: {sorted({k for m in wrapped for k in m.lora_A})})")
+        changed = self._adapter_name != adapter_name
+        for m in wrapped:
+            if adapter_name in m.lora_A and m.active_adapter != adapter_name:
+                m.active_adapter, changed = adapter_name, True
         self._adapter_name = adapter_name
+        if changed:
+            self._invalidate()
 
     def merge_adapter(self):
         """PeftAdapterMixin.merge_adapter as BaseTrainer.merge_lora calls it (base_trainer.py:413-416): fold every adapter into its

@@ -96,6 +96,14 @@ class LoraConfig:
         self.r, self.lora_alpha = int(r), float(lora_alpha)
         self.init_lora_weights = init_lora_weights
         self.target_modules = target_modules
+        # the fields peft.utils.get_peft_model_state_dict reads off `model.peft_config[adapter_name]` (peft is duck-typed on them)
+        self.peft_type, self.task_type = "LORA", None
+        self.bias, self.use_dora, self.is_prompt_learning = "none", False, False
+        self.modules_to_save = None
+
+    def __repr__(self):
+        return (f"LoraConfig(r={self.r}, lora_alpha={self.lora_alpha}, init_lora_weights={self.init_lora_weights!r}, "
+                f"target_modules={self.target_modules!r})")
 
 
 def match_target(name: str, target_modules) -> bool:

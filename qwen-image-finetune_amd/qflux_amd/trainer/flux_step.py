@@ -63,6 +63,7 @@ class FluxKontextTrainStep(QwenLoraTrainStep):
             loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
         else:
             loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
+        self._mark_unexchanged()
         plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
         return loss
 
@@ -148,6 +149,7 @@ def _forward_backward_multires(self, samples, txt, grad_scale=1.0, sync=True):
     pred = plan.run_forward((b["inp"], b["pooled"], b["guidance"]), b["pe"], b["timestep"])
     loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, b["target"], b["tok_w"].contiguous(), b["n_t_max"], 1.0 / (b["n_valid"] + 1e-12),
                                                  gscale=grad_scale)
+    self._mark_unexchanged()
     plan.run_backward(dpred, on_segment=self._bucket_hook() if (self.world > 1 and sync) else None)
     return loss
 

@@ -46,7 +46,7 @@ def map_mask_to_latent(image_mask: torch.Tensor) -> torch.Tensor:
 
 
 class QwenLoraTrainStep:
-    def __init__(self, dit, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_grad_norm=1.0,
+    def __init__(self, dit, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=None, max_grad_norm=1.0,
                  weight_dtype=BF, process_group=None, criterion="mse", forground_weight=2.0, background_weight=1.0,
                  bucket_mb=24.0, optimizer="adamw", optimizer_args=None):
         """optimizer: "adamw" (torch.optim.AdamW semantics, lr/betas/eps/weight_decay above) or "prodigy" (prodigyopt.Prodigy, the
@@ -59,6 +59,8 @@ class QwenLoraTrainStep:
             raise ValueError(f"unknown criterion {criterion!r}")
         if optimizer not in ("adamw", "adam", "adam8bit", "prodigy"):
             raise ValueError(f"unknown optimizer {optimizer!r}")
+        # weight_decay=None = "the optimizer class's own default": 0.01 for AdamW (torch.optim.AdamW), 0 for Adam / Adam8bit / Prodigy
+        # keeps its explicit value (the reference's Prodigy configs pass 0.01).  An EXPLICIT value is never reinterpreted.
         if optimizer in ("adam", "adam8bit"):
             # bitsandbytes.optim.Adam8bit -- what most of the reference's YAMLs select (configs/face_seg_config.yaml:56-59:
             # lr + betas only) -- is Adam with blockwise 8-bit quantised moments, a device to fit 24-48 GB cards.  The LoRA state
@@ -66,10 +68,13 @@ class QwenLoraTrainStep:
             # code book; optimizer.bin then holds fp32 exp_avg / exp_avg_sq in torch.optim.Adam's layout, not bnb's state1 / state2 /
             # absmax blocks).  Adam's weight decay is the L2 form (added to the gradient), not AdamW's decoupled one: only the
             # configs' weight_decay = 0 is mapped.
-            if weight_decay not in (0, 0.0, 0.01):
-                raise NotImplementedError("Adam / Adam8bit with L2 weight decay (the reference's configs use none)")
+            if weight_decay is not None and float(weight_decay) != 0.0:
+                raise NotImplementedError(f"{optimizer} with L2 weight decay {weight_decay} (bnb adds wd * p to the gradient; the fused "
+                                          "kernel implements AdamW's decoupled form only; the reference's configs use none)")
             weight_decay = 0.0
             self.optimizer_alias, optimizer = optimizer, "adamw"
+        if weight_decay is None:
+            weight_decay = 0.01 if optimizer == "adamw" else 0.0
         self.optimizer = optimizer
         self.optimizer_args = dict(beta3=None, decouple=True, use_bias_correction=False, safeguard_warmup=False, d0=1e-6,
                                    d_coef=1.0, growth_rate=float("inf"))
@@ -95,14 +100,19 @@ class QwenLoraTrainStep:
         self._pending = []
         self._reduced = False
         self._synced = False      # rank 0's adapter / optimizer state is broadcast before the first step (broadcast_state)
+        self._synced_version = None
         # QFX_DP_FORCE=1: run the bucketed exchange on a ONE-rank process group too (the collectives are then identities) -- lets a
         # one-GPU box execute the real RCCL code path: communicator, RCCL's stream, async handles, ordering against the main and
         # the side gradient stream (tests/test_dp_gpu.py)
         self._force_dp = os.environ.get("QFX_DP_FORCE", "0") == "1" and dist.is_available() and dist.is_initialized()
 
     def _ensure_synced(self):
-        if not self._synced:
-            self._synced = True
+        """Rank 0's adapter + optimizer state reaches every rank before the first step AND again whenever the model's adapter set
+        was rebuilt since (dit._version moves on add_adapter / load_lora_adapter / load_state_dict / .to()): a re-injected or
+        re-loaded adapter must not depend on every rank having produced identical weights."""
+        ver = getattr(self.dit, "_version", 0)
+        if not self._synced or self._synced_version != ver:
+            self._synced, self._synced_version = True, ver
             if self.world > 1:
                 self.dit.lora_store
                 self.broadcast_state()
@@ -166,6 +176,7 @@ class QwenLoraTrainStep:
             loss, dpred = ops.mse_token_weighted_fwd_bwd(pred, target, tw, S_t, 1.0 / (B * S_t), gscale=grad_scale)
         else:
             loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t, gscale=grad_scale)
+        self._mark_unexchanged()       # local gradients are added below: whatever exchange a drop-in backward did before is stale
         plan.run_backward(dpred, on_segment=self._bucket_hook() if ((self.world > 1 or self._force_dp) and sync) else None)
         return loss
 
@@ -185,6 +196,7 @@ class QwenLoraTrainStep:
         packed, target, pe, t_in, S_t = self._prepare(embeddings)
         plan = dit.get_plan(packed.shape[0], packed.shape[1], pe.shape[1], embeddings["img_shapes"], None)
         dit.lora_store
+        self._ensure_synced()      # outside the capture: a job driven only by the captured step still starts from rank 0's state
         version = dit._version
         static = [torch.empty_like(t) for t in (packed, target, pe, t_in)]
         for d, s_ in zip(static, (packed, target, pe, t_in)):
@@ -217,6 +229,8 @@ class QwenLoraTrainStep:
                 raise ValueError("capture_graph: batch shape differs from the captured one")
             for d, s_ in zip(static, ins[:4]):
                 d.copy_(s_)
+            self._ensure_synced()
+            self._mark_unexchanged()
             graph.replay()
             self._finish_buckets = None
             self.optimizer_step(grad_scale=self.allreduce_grads())
@@ -273,10 +287,13 @@ class QwenLoraTrainStep:
                 for w in self._pending:
                     w.wait()
                 self._pending = []
-            else:   # no bucketed backward of THIS object ran (drop-in autograd path)
+            else:   # no bucketed backward of THIS object ran (drop-in autograd path, or the hipGraph replay)
                 dp = getattr(self.dit, "_dp", None)
-                if dp is not None and dp.enabled:
-                    return 1.0      # dit.enable_data_parallel(): loss.backward() already exchanged (overlapped) and averaged (dp.py)
+                if dp is not None and dp.exchanged:
+                    # dit.enable_data_parallel(): the LAST loss.backward() since zero_grad already exchanged (overlapped) and averaged
+                    # the accumulated gradient (dp.py sets the flag in finish(); merely being enabled proves nothing -- the captured
+                    # graph replays plan.run_backward directly and never passes through the autograd node's exchange)
+                    return 1.0
                 dist.all_reduce(self.dit.lora_store.gflat, op=dist.ReduceOp.SUM, group=self.group)
             return 1.0 / self.world
         return 1.0
@@ -305,8 +322,14 @@ class QwenLoraTrainStep:
                        self.weight_decay, self.global_step, gnorm_sq=self._gnorm, max_norm=self.max_grad_norm,
                        grad_scale=grad_scale)
 
+    def _mark_unexchanged(self):
+        dp = getattr(self.dit, "_dp", None)
+        if dp is not None:
+            dp.exchanged = False
+
     def zero_grad(self):
         self.dit.lora_store.gflat.zero_()
+        self._mark_unexchanged()
 
     # ------------------------------------------------------------------ optimizer / resume state (base_trainer.py:827-875,944-1002)
     def state_dict(self):
@@ -430,14 +453,25 @@ class QwenLoraTrainStep:
         have = torch.tensor([float(self._m is not None), float(self._pstate is not None), float(self.global_step)], device=dev)
         dist.broadcast(have, src=src, group=self.group)
         st = self.dit.lora_store
-        if have[0].item() and self._m is None:
-            self._m, self._v = torch.zeros_like(st.pflat), torch.zeros_like(st.pflat)
-            self._gnorm = torch.zeros((), dtype=torch.float32, device=dev)
-        if have[1].item() and self._pstate is None:
-            self._ps, self._p0 = torch.zeros_like(st.pflat), torch.zeros_like(st.pflat)
-            self._pstate = torch.zeros(L_PRODIGY_STATE, dtype=torch.float64, device=dev)
+        have_m, have_p = bool(have[0].item()), bool(have[1].item())
+        # the buffer list is derived from the AGREED flags on every rank (same collectives in the same order everywhere): buffers
+        # rank `src` has are created where missing, buffers it lacks are dropped locally (a rank that had stepped before must not
+        # carry moments the others do not have)
+        if have_m:
+            if self._m is None or self._m.numel() != st.pflat.numel():
+                self._m, self._v = torch.zeros_like(st.pflat), torch.zeros_like(st.pflat)
+                self._gnorm = torch.zeros((), dtype=torch.float32, device=dev)
+        else:
+            self._m = self._v = None
+        if have_p:
+            if self._pstate is None or self._ps is None or self._ps.numel() != st.pflat.numel():
+                self._ps, self._p0 = torch.zeros_like(st.pflat), torch.zeros_like(st.pflat)
+                self._pstate = torch.zeros(L_PRODIGY_STATE, dtype=torch.float64, device=dev)
+        else:
+            self._ps = self._p0 = self._pstate = None
         self.global_step = int(have[2].item())
-        for _, t in self._state_buffers():
+        bufs = [st.pflat] + ([self._m, self._v] if have_m else []) + ([self._ps, self._p0, self._pstate] if have_p else [])
+        for t in bufs:
             dist.broadcast(t, src=src, group=self.group)
 
     def check_replicas(self, what: str = "adapter weights"):

@@ -333,3 +333,66 @@ def test_world4_ragged_buckets_equal_step_counts_identical_reduced_gradients(tmp
     assert all(r[2] == 3 for r in res)
     for s in range(3):
         assert len({r[3][s] for r in res}) == 1, [r[3][s] for r in res]     # same reduced gradient sum, gathered loss and scale on all ranks
+
+
+def _worker_advice_r3(rank, world, port, q):
+    """(a) allreduce_grads() must not infer "already exchanged" from dit._dp being enabled (the captured-graph step and
+    forward_backward never pass through the autograd node's exchange): only LoraGradSync.finish() vouches for it, and zero_grad /
+    a local-only backward withdraw it; (b) broadcast_state() issues the SAME collectives on every rank when a non-src rank holds
+    optimizer buffers src lacks (they are dropped); (c) the rank-0 broadcast repeats when the model's adapter set was rebuilt."""
+    sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qflux_amd.dp import LoraGradSync
+    from qflux_amd.trainer import QwenLoraTrainStep
+    toy = _toy_model(with_cond=False)
+    toy._dp = LoraGradSync(toy)            # what dit.enable_data_parallel() installs (add_adapter does it under a process group)
+    toy._version = 0
+    st = toy.lora_store
+    step = QwenLoraTrainStep(toy)
+    ok = True
+    # (a) enabled, but no exchange ran: the full all-reduce must happen and the factor is 1/world
+    st.gflat.fill_(float(rank + 1))
+    f = step.allreduce_grads()
+    tot = float(sum(range(1, world + 1)))
+    ok = ok and f == 1.0 / world and bool(st.gflat.eq(tot).all())
+    # after a drop-in backward's finish() the gradient IS exchanged and averaged: no second reduction
+    step.zero_grad()
+    ok = ok and toy._dp.exchanged is False
+    st.gflat.fill_(float(rank + 1))
+    toy._dp.hook()                          # arms finish()
+    toy._dp.finish(average=True)
+    ok = ok and toy._dp.exchanged is True and bool(st.gflat.eq(tot / world).all())
+    f = step.allreduce_grads()
+    ok = ok and f == 1.0 and bool(st.gflat.eq(tot / world).all())
+    step.zero_grad()
+    ok = ok and toy._dp.exchanged is False
+    # (b) a NON-src rank carries moments, src has none: same collective sequence everywhere, the stray buffers are dropped
+    if rank == 1:
+        step._m = torch.full_like(st.pflat, 3.0)
+        step._v = torch.full_like(st.pflat, 4.0)
+    with torch.no_grad():
+        st.pflat.fill_(float(10 + rank))
+    step.broadcast_state()
+    ok = ok and step._m is None and step._v is None and bool(st.pflat.eq(10.0).all())
+    ok = ok and step.check_replicas()
+    # (c) _ensure_synced: once per model version
+    step._synced = False
+    with torch.no_grad():
+        st.pflat.fill_(float(20 + rank))
+    step._ensure_synced()
+    ok = ok and bool(st.pflat.eq(20.0).all())
+    with torch.no_grad():
+        st.pflat.fill_(float(30 + rank))
+    step._ensure_synced()                   # same version: no broadcast
+    ok = ok and bool(st.pflat.eq(30.0 + rank).all())
+    toy._version += 1                       # load_lora_adapter / add_adapter / .to() bump it
+    step._ensure_synced()
+    ok = ok and bool(st.pflat.eq(30.0).all())
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_advice_r3_exchange_flag_broadcast_symmetry_and_resync_world2():
+    assert _spawn(_worker_advice_r3, 2, 37500) == [(0, True), (1, True)]

@@ -104,3 +104,61 @@ def test_from_pretrained_reads_a_diffusers_layout_checkpoint(tmp_path, sharded):
             assert torch.equal(a, b), n
     with pytest.raises(FileNotFoundError):
         QwenImageTransformer2DModel.from_pretrained("Qwen/Qwen-Image-Edit", subfolder="transformer")
+
+
+def test_peft_config_state_dict_rule_and_set_adapter():
+    """What the reference's UNCHANGED trainer touches around the adapter: `peft_config[adapter_name]` for
+    peft.get_peft_model_state_dict (base_trainer.py:870-872), set_adapter (base_trainer.py:940-941)."""
+    from qflux_amd.lora_io import get_lora_state_dict, get_peft_model_state_dict
+    from qflux_amd.modules import LoraConfig
+    q, f = _models()
+    cfg = LoraConfig(r=4, lora_alpha=8, target_modules=["to_k", "to_q", "to_v", "to_out.0"])
+    q.add_adapter(cfg, adapter_name="lora_edit")
+    assert q.peft_config == {"lora_edit": cfg} and q._hf_peft_config_loaded
+    assert (cfg.peft_type, cfg.bias, cfg.use_dora, cfg.is_prompt_learning) == ("LORA", "none", False, False)
+    # peft's filtering rule on the drop-in's state dict == the PEFT-style file this repo writes (adapter name stripped)
+    sd = get_peft_model_state_dict(q, adapter_name="lora_edit")
+    want = get_lora_state_dict(q, style="peft")
+    assert set(sd) == set(want) and len(sd) == 2 * 4 * TINY["num_layers"]
+    assert "transformer_blocks.0.attn.to_q.lora_A.weight" in sd and all(".lora_edit" not in k for k in sd)
+    for k in sd:
+        assert torch.equal(sd[k].cpu(), want[k])
+    with pytest.raises(KeyError):
+        get_peft_model_state_dict(q, adapter_name="nope")
+    # an arbitrary config object is kept as is (a real peft.LoraConfig passes through: only r / lora_alpha / init_lora_weights /
+    # target_modules are read here, the rest is peft's business)
+    class Foreign:
+        r, lora_alpha, init_lora_weights, target_modules = 4, 4, "gaussian", ["to_q"]
+        peft_type, bias, use_dora = "LORA", "none", False
+    fc = Foreign()
+    f.add_adapter(fc, adapter_name="x")
+    assert f.peft_config["x"] is fc
+    # set_adapter: known adapter = no-op for the plans (same version); unknown adapter raises like peft; a switch invalidates
+    v = q._version
+    q.set_adapter("lora_edit")
+    assert q._version == v
+    q.set_adapter(["lora_edit"])
+    assert q._version == v
+    with pytest.raises(ValueError):
+        q.set_adapter("other")
+    m = q.transformer_blocks[0].attn.to_q
+    m.lora_A["second"] = type(m.lora_A["lora_edit"])(torch.zeros_like(m.A), True)
+    m.lora_B["second"] = type(m.lora_B["lora_edit"])(torch.zeros_like(m.B), True)
+    m.r["second"], m.lora_alpha["second"], m.scaling["second"] = 4, 8, 2.0
+    q.set_adapter("second")
+    assert m.active_adapter == "second" and q._version == v + 1          # cached plans (baked adapter pointers) are gone
+
+
+def test_optimizer_weight_decay_is_never_reinterpreted():
+    """an explicit weight_decay is honoured or refused, never silently replaced; None = the optimizer class's default."""
+    from qflux_amd.trainer import QwenLoraTrainStep
+    q, _ = _models()
+    assert QwenLoraTrainStep(q).weight_decay == 0.01                                   # torch.optim.AdamW default
+    assert QwenLoraTrainStep(q, weight_decay=0.05).weight_decay == 0.05
+    assert QwenLoraTrainStep(q, optimizer="adam8bit").weight_decay == 0.0             # bnb Adam8bit default
+    assert QwenLoraTrainStep(q, optimizer="adam", weight_decay=0.0).weight_decay == 0.0
+    assert QwenLoraTrainStep(q, optimizer="prodigy").weight_decay == 0.0              # prodigyopt default
+    assert QwenLoraTrainStep(q, optimizer="prodigy", weight_decay=0.01).weight_decay == 0.01
+    for opt in ("adam", "adam8bit"):
+        with pytest.raises(NotImplementedError):
+            QwenLoraTrainStep(q, optimizer=opt, weight_decay=0.01)                     # bnb would apply L2 decay: refuse, do not drop it
