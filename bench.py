@@ -89,9 +89,13 @@ def hbm_bytes_of_call(name, args):
         return sum(2 * x.rows * x.D * (3 + (1 if x.dres else 0) + (1 if x.dyg else 0)) for x in structs(args[0], args[1]))
     if name == "qfx_mod_gemv":               # (temb, B, K, W, bias, nmat, N, silu, out)
         return 2 * args[5] * args[6] * args[2]
-    if name in ("qfx_qk_norm_rope_fwd", "qfx_qk_norm_rope_bwd"):   # q and k rows of the joint buffer, read + written (+ saved copy)
+    if name in ("qfx_qk_norm_rope_fwd", "qfx_qk_norm_rope_bwd"):
+        # q and k rows of the joint buffer.  Forward (out of place since round 2): ONE read of the pre-norm rows + ONE write of the
+        # normalised / rotated rows = 2 passes (profiles/r03_pmc_hbm.json: 33.7 + 29.9 MB per launch; the round-3 line counted 3 and
+        # overstated the rate by 1.5x -- VERDICT r3 weak #4).  Stand-alone backward (unused since its fusion into the attention
+        # epilogues): gradient read + saved rows read + gradient written = 3.
         Bq, Sq, Hq, dh = args[7], args[8], args[10], args[11]
-        return 2 * Bq * Sq * 2 * Hq * dh * 3
+        return 2 * Bq * Sq * 2 * Hq * dh * (2 if name.endswith("fwd") else 3)
     return None
 
 

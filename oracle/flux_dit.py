@@ -22,7 +22,7 @@ def flux_rope_tables(ids: torch.Tensor, axes_dim=(16, 56, 56), theta: float = 10
     pos = ids.float()
     cos_out, sin_out = [], []
     for i, d in enumerate(axes_dim):
-        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64)[: d // 2] / d))
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64, device=pos.device)[: d // 2] / d))
         ang = torch.outer(pos[:, i].to(torch.float64), freqs)
         cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
         sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
@@ -346,10 +346,10 @@ def flux_compute_loss(dit: nn.Module, emb: dict, noise: torch.Tensor, t: torch.T
         t_ = t.unsqueeze(1).unsqueeze(1)
         x_t = (1.0 - t_) * x0 + t_ * noise
         h, w = emb["latent_hw"]
-        latent_ids = prepare_latent_image_ids(h, w, dtype)
+        latent_ids = prepare_latent_image_ids(h, w, dtype).to(x0.device)      # (.to(device): the checker also runs on the GPU, tests/test_fulldepth_gpu.py)
         inp = torch.cat([x_t, emb["control_latents"]], dim=1)
         ids = torch.cat([latent_ids, emb["control_ids"].to(dtype)], dim=0)
-    guidance = torch.ones((noise.shape[0],)).to(dtype) if getattr(dit, "guidance_embeds", False) else None
+    guidance = torch.ones((noise.shape[0],), device=x0.device).to(dtype) if getattr(dit, "guidance_embeds", False) else None
     pred = dit(hidden_states=inp.to(dtype), timestep=t.to(dtype), guidance=guidance,
                pooled_projections=emb["pooled_prompt_embeds"].to(dtype), encoder_hidden_states=emb["prompt_embeds"].to(dtype),
                txt_ids=emb["text_ids"], img_ids=ids, joint_attention_kwargs={}, return_dict=False)[0]

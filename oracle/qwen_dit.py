@@ -469,9 +469,9 @@ def qwen_compute_loss(dit: nn.Module, emb: dict, noise: torch.Tensor, u: torch.T
     timesteps_tbl, sigmas_tbl = flowmatch_sigmas()
     with torch.no_grad():
         noise = noise.to(dtype)
-        idx = (u * 1000).long()
-        timesteps = timesteps_tbl[idx]
-        sig = sigmas_tbl.to(dtype)[idx].flatten()
+        idx = (u.cpu() * 1000).long()                       # the tables live on the host like the scheduler's; results follow the data
+        timesteps = timesteps_tbl[idx].to(x0.device)        # (device moves are no-ops on the CPU; the checker also runs on the GPU:
+        sig = sigmas_tbl.to(dtype)[idx].flatten().to(x0.device)   # tests/test_fulldepth_gpu.py)
         while sig.ndim < x0.ndim:
             sig = sig.unsqueeze(-1)
         x_t = (1.0 - sig) * x0 + sig * noise
