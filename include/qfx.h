@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QFX_ABI_VERSION 4
+#define QFX_ABI_VERSION 5
 
 #define QFX_OK 0
 #define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
@@ -429,6 +429,15 @@ int qfx_stream_create_cu_masked(int32_t n_cus, void** stream_out);
 int qfx_stream_destroy(void* stream);
 /* debug: out[2*b] = HW_ID register, out[2*b+1] = XCC_ID register of the CU block b ran on (blocks spin ~0.1 ms) */
 int qfx_debug_where(uint32_t* out, int32_t n_blocks, void* stream);
+
+/* ---- tuning: tile-geometry policy of the persistent GEMM (qfx_gemm_grouped / large qfx_gemm_bf16; ABI 5).  Every launch picks
+ * its tile from rounds-over-256-CUs x relative tile time among the enabled geometries "256x128", "256x256" (rounds 1-3), "160x192",
+ * "160x256", "160x384" (round 4: M = 2048 image + 384 text rows tile into 13 + 3 M-tiles of 160 = whole rounds of 256 tiles).
+ * tiles: NULL / "" = keep, "all", "legacy" (the two 256-row tiles), or a comma list of names; eff: NULL = keep, or five
+ * comma-separated per-flop efficiencies relative to 256x128 in the order above.  Process-wide; the defaults come from the
+ * environment (QFX_GEMM_TILES / QFX_GEMM_EFF) at the first launch.  Results do not depend on the geometry (same K order per
+ * output element); only speed does.  Returns QFX_EINVAL for an unparsable argument. ---- */
+int qfx_gemm_tune(const char* tiles, const char* eff);
 
 /* ---- debug: lane mapping of ds_read_b64_tr_b16 (64 lanes x 4 bf16 in, same out) ---- */
 int qfx_debug_tr_read(const uint16_t* in, uint16_t* out, void* stream);

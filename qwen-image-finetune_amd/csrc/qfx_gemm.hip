@@ -16,6 +16,9 @@
 // 8-byte bf16x4 stores / bias / gate / residual accesses in the epilogue.
 // blockIdx -> tile mapping is XCD-aware (each XCD walks a contiguous chunk of the tile list).
 #include "qfx_common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -208,32 +211,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 
 
 // =============================================================================================
-// gemm256: 256x128x64 tiles, WARP-SPECIALISED and PERSISTENT.  One 640-thread block per CU:
-//   * waves 0..7  = compute (4x2, each 64x64 = 4x4 MFMA 16x16x32): ds_read_b128 + MFMA + epilogue only;
+// gemm256: WARP-SPECIALISED and PERSISTENT tiles.  One 640-thread block per CU:
+//   * waves 0..7  = compute: ds_read_b128 + MFMA 16x16x32 + epilogue only;
 //   * waves 8..9  = loaders: all LDS-DMA (global_load_lds_dwordx4) for the block, running up to two K tiles ahead
-//                   through a 3-stage ring and straight across output-tile boundaries.
+//                   through the stage ring and straight across output-tile boundaries.
 // One s_barrier per K tile joins the two roles ("tile f landed" + "everyone is done with tile f-1").  The compute
 // waves never wait on vmcnt, so their epilogue stores drain under the next tile's main loop, and the next tile's
 // first stages are already in LDS when the epilogue ends.  Measured (tools/gemm_lab/ws.hip vs abl.hip, warm,
 // paired): +12..21 % on the DiT shapes over the same tile with DMA issued from the compute waves.
 // Grid = whole rounds over <= 256 CUs (multiple of 8 so that bid % 8 stays the XCD); grouped launch: up to
 // QFX_MAX_GROUPS independent problems (image/text streams, q/k/v) share one tile list.
-constexpr int BM2 = 256;
-// Tile width TN = 128: 8 compute waves 4x2 (64x64 each), 3-stage ring of 48 KiB.  TN = 256: 8 compute waves 2x4 (128x64 each,
-// 128 accumulator VGPRs, fragments streamed one at a time to stay inside the 168-VGPR budget of 10 waves per CU), 2-stage ring
-// of 64 KiB: a third less LDS-DMA and a quarter less fragment traffic per flop -- +8..10 % where the tile count still fills
-// whole rounds (N = 12288 problems), measured against the 128-wide form in tools/gemm_lab/ws256.hip.
-template <int TN> struct TileCfg {
-  static constexpr int STAGE = (BM2 + TN) * BK * 2;
-  static constexpr int NST = TN == 128 ? 3 : 2;
-  static constexpr int WRN = TN == 128 ? 4 : 2;     // compute waves along M
-  static constexpr int WCN = 8 / WRN;               // ... along N (64 columns each)
-  static constexpr int MI = BM2 / WRN / 16;         // 16-row MFMA fragments per wave
-};
+//
+// Tile geometries (BMT x TN, K tile 64; compute waves WRN x WCN, each MI x NI fragments of 16 x 16):
+//   256 x 128  4 x 2 waves of 64 x 64   3-stage ring (48 KiB)   rotated K loop            -- rounds 1-3
+//   256 x 256  2 x 4 waves of 128 x 64  2-stage ring (64 KiB)   streaming K loop (+9 % per flop: a third less LDS-DMA, a
+//                                                                 quarter less fragment traffic)
+//   160 x 192  2 x 4 waves of 80 x 48   3-stage ring (44 KiB)   rotated K loop            -- round 4: the DiT's M is
+//   160 x 256  2 x 4 waves of 80 x 64   2-stage ring (52 KiB)   streaming K loop             2048 image + 384 text rows with
+//   160 x 384  2 x 4 waves of 80 x 96   2-stage ring (68 KiB)   streaming K loop             DIFFERENT weights per stream.
+// Why 160 rows: with 256-row tiles a B = 1 step runs 8 + 2 M-tiles (the second text tile half empty: 5 % padding) x 24 N-tiles
+// = 240 tiles on 256 CUs (6 % idle) -- every narrow launch is ONE round of one 32768-element tile per CU.  160 rows give
+// 13 + 3 = 16 M-tiles x 16 N-tiles of 192 = exactly 256 tiles of 30720 elements (-6.25 % per CU; 2 % padding on the image
+// stream) and 16 x 32 x (160 x 384) = 512 = two full rounds for the N = 12288 launches.  The launcher picks the geometry per
+// launch from rounds x relative tile time (qfx_gemm_grouped).
 constexpr int NLD = 2;                            // loader waves
 constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
 constexpr int QFX_NUM_CU = 256;                   // MI355X
+template <int BMT, int TN> struct TileCfg {
+  static constexpr bool WIDE = TN >= 256;           // 2-stage ring + streaming K loop
+  static constexpr int STAGE = (BMT + TN) * BK * 2;
+  static constexpr int NST = WIDE ? 2 : 3;
+  static constexpr int WRN = (BMT == 256 && TN == 128) ? 4 : 2;     // compute waves along M
+  static constexpr int WCN = 8 / WRN;               // ... along N
+  static constexpr int MI = BMT / WRN / 16;         // 16-row MFMA fragments per wave
+  static constexpr int NI = TN / WCN / 16;          // 16-column fragments per wave
+  static constexpr int NG = NI == 6 ? 3 : NI;       // fragments per epilogue staging pass (<= 64 columns = 128 B per staged row)
+  static constexpr int NGRP = NI / NG;
+  static_assert(BMT % (WRN * 16) == 0 && TN % (WCN * 16) == 0 && NI % NG == 0, "tile / wave layout");
+  static_assert(NST * STAGE + 8 * STG_BYTES <= 160 * 1024, "LDS budget");
+};
 
 struct GroupedArgs {
   qfx_gemm_args g[QFX_MAX_GROUPS];
@@ -259,7 +276,7 @@ struct GroupedArgs {
 typedef const QFX_AS4 GroupedArgs KGroupedArgs;
 typedef const QFX_AS4 qfx_gemm_args KArgs;
 
-template <int TN>
+template <int BMT, int TN>
 __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
@@ -271,23 +288,24 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
   // supertile order: consecutive tile ids walk 8 M-tiles before the next N-tile, so the ~32 tiles an XCD runs at
   // a time form an 8(M) x 4(N) patch that shares A rows and B rows in that XCD's L2.
   const int M = ga.g[gi].M, N = ga.g[gi].N;
-  const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + TN - 1) / TN;
+  const int tiles_m = (M + BMT - 1) / BMT, tiles_n = (N + TN - 1) / TN;
   constexpr int GM = 8;
   const int per = GM * tiles_n, sg = lt / per, first = sg * GM;
   const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
   const int in = lt - sg * per;
-  m0 = (first + in % gsz) * BM2;
+  m0 = (first + in % gsz) * BMT;
   n0 = (in / gsz) * TN;
 }
 
 typedef __attribute__((ext_vector_type(8))) int v8i32;
 
-template <int EPI, int TN, bool FP8 = false>
+template <int EPI, int BMT, int TN, bool FP8 = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArgs ga_by_value) {
-  static_assert(!(FP8 && TN != 128), "the MX-FP8 instantiation uses the 256x128 tile (the wide tile's streaming loop has no registers for 8-VGPR operands)");
-  using TC = TileCfg<TN>;
-  constexpr int STAGE_BYTES = TC::STAGE, NSTAGE = TC::NST, MI = TC::MI;
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];  // 160 KiB (TN=128) / 144 KiB
+  static_assert(!(FP8 && !(BMT == 256 && TN == 128)), "the MX-FP8 instantiation uses the 256x128 tile (the streaming loops have no registers for 8-VGPR operands)");
+  using TC = TileCfg<BMT, TN>;
+  constexpr int STAGE_BYTES = TC::STAGE, NSTAGE = TC::NST, MI = TC::MI, NI = TC::NI, NG = TC::NG, NGRP = TC::NGRP;
+  constexpr int WCOLS = 16 * NI;   // columns per compute wave
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];
   KGroupedArgs& ga = *(KGroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // == ga_by_value (sole explicit argument)
 
   const int tid = threadIdx.x;
@@ -298,8 +316,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   if (w >= 8) {
     // ================================================================ loader waves
     const int lw = w - 8;
-    constexpr int NA = 32 / NLD, NB = (TN / 8) / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
-    static_assert(NLD == 2 && (NA + NB == 24 || NSTAGE == 2), "vmcnt immediate below assumes 24 pieces per K tile per loader wave");
+    constexpr int NA = (BMT / 8) / NLD, NB = (TN / 8) / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
+    static_assert(NLD == 2 && (BMT / 8) % NLD == 0 && (TN / 8) % NLD == 0 && NA + NB < 64, "loader split / vmcnt immediate");
     const int srow = lane >> 3, schunk = lane & 7;
     // source column incl. the bank swizzle chunk ^ ((row>>1)&7); with NLD == 2 it is the same for every piece
     const int sc = (schunk ^ ((lw * 4 + (srow >> 1)) & 7)) * 8;
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     int ilda2 = 0, ildb2 = 0;
     auto setp = [&](int bid) {
       int gi;
-      tile_coord<TN>(ga, nwg, bid, gi, im0, in0);
+      tile_coord<BMT, TN>(ga, nwg, bid, gi, im0, in0);
       KArgs& p = ga.g[gi];
       int1 = p.K1 / BK; intt = int1 + p.K2 / BK;
       iA2 = p.A2; iB2 = p.B2; ilda2 = p.lda2; ildb2 = p.ldb2; iM = p.M; iN = p.N;
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         }
       }
       char* sA = smem + ist * STAGE_BYTES;
-      char* sB = sA + BM2 * BK * 2;
+      char* sB = sA + BMT * BK * 2;
       const int koff = (it < int1 ? it : it - int1) * BK;
 #pragma unroll
       for (int i = 0; i < NA; ++i) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
@@ -359,11 +377,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     if (more && NSTAGE > 2) { issue(); ++ahead; }    // a 2-stage ring holds one K tile ahead only
     for (int wbid = blockIdx.x; wbid < nwg; wbid += gridDim.x) {
       int gi, m0, n0;
-      tile_coord<TN>(ga, nwg, wbid, gi, m0, n0);
+      tile_coord<BMT, TN>(ga, nwg, wbid, gi, m0, n0);
       const int ntw = ga.g[gi].K1 / BK + ga.g[gi].K2 / BK;
       for (int t = 0; t < ntw; ++t) {
-        // the oldest K tile in flight must have landed; the one issued after it may still be in flight
-        if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        // the oldest K tile in flight must have landed; the one issued after it (NA + NB pieces) may still be in flight
+        if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NA + NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         --ahead;
@@ -379,27 +397,32 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   constexpr int WROWS = 16 * MI;   // rows per compute wave
   char* stg = smem + NSTAGE * STAGE_BYTES + w * STG_BYTES;
   int buf = 0;
+  // lane-constant fragment offsets: the swizzle depends on li only (wave / fragment rows advance in multiples of 16), the k-step
+  // flips chunk bit 2, i.e. XOR 64 on the byte offset
+  const int swl = (li >> 1) & 7;
+  const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
+  const int offB0 = BMT * BK * 2 + (wc * WCOLS + li) * (BK * 2) + ((g ^ swl) << 4);
   for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
     int gi, m0, n0;
-    tile_coord<TN>(ga, nwg, bid, gi, m0, n0);
+    tile_coord<BMT, TN>(ga, nwg, bid, gi, m0, n0);
     KArgs& p = ga.g[gi];
     const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // TN = 128 -- rotated K loop: the second k-step of K tile t-1 is issued AFTER barrier t, under the first fragment reads
+    // narrow tiles -- rotated K loop: the second k-step of K tile t-1 is issued AFTER barrier t, under the first fragment reads
     // of tile t, so the matrix pipe does not drain while the post-barrier ds_reads are in flight (+2..6 % in the lab).
-    // TN = 256 -- streaming loop: per k-step the four B fragments stay resident and the eight A fragments pass through a
-    // three-deep ring, two reads ahead of the MFMAs that consume them (128 accumulators leave no room to double-buffer).
+    // wide tiles -- streaming loop: per k-step the NI B fragments stay resident and the MI A fragments pass through a
+    // three-deep ring, two reads ahead of the MFMAs that consume them (the accumulators leave no room to double-buffer).
     auto round_base = [&]() {
       // base nn.Linear output is a bf16 tensor in the reference: round (acc + bias) before the LoRA add
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wc * WCOLS + ni * 16 + 4 * g;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias != nullptr && n + 3 < p.N) {
           const bf16x4 bb = *(const bf16x4*)(p.bias + n);
@@ -430,9 +453,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       for (int i = 0; i < MI; ++i) sca[i] = *(const uint32_t*)(sap + aoff(i));
 #pragma unroll
       for (int i = 0; i < 4; ++i) scb[i] = *(const uint32_t*)(sbp + boff(i));
-      const int swl = (li >> 1) & 7;
-      const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
-      const int offB0 = BM2 * BK * 2 + (wc * 64 + li) * (BK * 2) + ((g ^ swl) << 4);
       for (int t = 0; t < nt1; ++t) {
         // this lane group's scale bytes of tile t; the dwords of tile t+1 are requested right away into the same registers
         int sav[MI], sbv[4];
@@ -500,60 +520,98 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         }
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
       }
-    } else if constexpr (TN == 128) {
-      bf16x8 a0[4], b0[4], a1[4], b1[4];
+    } else if constexpr (!TC::WIDE) {
+      bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
       for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of tile t-1 has returned: its stage may be refilled
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const char* sA = smem + buf * STAGE_BYTES;
-        const char* sB = sA + BM2 * BK * 2;
-        auto rdA = [&](int kk, int mi) {
-          const int row = wr * WROWS + mi * 16 + li; const int chunk = kk * 4 + g;
-          return *(const bf16x8*)(sA + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
-        };
-        auto rdB = [&](int kk, int ni) {
-          const int row = wc * 64 + ni * 16 + li; const int chunk = kk * 4 + g;
-          return *(const bf16x8*)(sB + row * (BK * 2) + ((chunk ^ ((row >> 1) & 7)) << 4));
-        };
-        // a compute wave whose rows all lie past M (the text stream's half-empty second tile: 128 of 2560 rows per launch) keeps
+        const char* st = smem + buf * STAGE_BYTES;
+        auto rdA = [&](int kk, int mi) { return *(const bf16x8*)(st + ((offA0 + mi * (16 * BK * 2)) ^ (kk << 6))); };
+        auto rdB = [&](int kk, int ni) { return *(const bf16x8*)(st + ((offB0 + ni * (16 * BK * 2)) ^ (kk << 6))); };
+        // a compute wave whose rows all lie past M (the text stream's last, partly empty tile) keeps
         // the barrier protocol but issues no fragment reads / MFMAs: nothing of it is ever stored, and under the package power
         // cap the saved energy is time (sustained step 99.79 -> 99.25 ms, tools/step_lib_ab.py; invisible in burst timings)
         if (wave_dead) { buf = buf + 1 == NSTAGE ? 0 : buf + 1; continue; }
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) { a0[i] = rdA(0, i); b0[i] = rdB(0, i); }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a0[i] = rdA(0, i);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) b0[i] = rdB(0, i);
         __builtin_amdgcn_sched_barrier(0);
         if (t > 0) {
-  #pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-  #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
           if (mid_round && t == nt1) round_base();
         }
         __builtin_amdgcn_sched_barrier(0);
-  #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-  #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-          a1[mi] = rdA(1, mi); b1[mi] = rdB(1, mi);
+          a1[mi] = rdA(1, mi);
+          if (mi < NI) b1[mi] = rdB(1, mi);
           __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NI > MI) {
+#pragma unroll
+          for (int ni = MI; ni < NI; ++ni) b1[ni] = rdB(1, ni);
         }
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
       }
-      if (!wave_dead)
-  #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-  #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+      if (!wave_dead) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+      }
+    } else if constexpr (NI > MI) {
+      // 80 x 96 wave tile: the MI = 5 A fragments stay resident and the NI = 6 B fragments stream one read ahead (120 accumulators +
+      // 20 + 8 operand registers; the mirrored form of the loop below -- 24 resident + a three-deep ring -- spills inside the loop)
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + buf * STAGE_BYTES;
+        if (wave_dead) { buf ^= 1; continue; }   // see the narrow-tile loop
+        // the fragment offsets are re-derived from the lane id per K tile (six VALU operations): kept across the loop, the four
+        // address registers are what the allocator spills at 120 accumulators (a scratch reload per K tile and its vmcnt wait)
+        int l2;   // lane id without a live register (asm volatile: not hoisted, not spilled)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+        const int g2 = l2 >> 4, li2 = l2 & 15, sw2 = (li2 >> 1) & 7;
+        const int oA = (wr * WROWS + li2) * (BK * 2) + ((g2 ^ sw2) << 4);
+        const int oB = BMT * BK * 2 + (wc * WCOLS + li2) * (BK * 2) + ((g2 ^ sw2) << 4);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const char* pA = st + (oA ^ (kk << 6));
+          const char* pB = st + (oB ^ (kk << 6));
+          bf16x8 a[MI];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(pA + mi * (16 * BK * 2));
+          bf16x8 fb0 = *(const bf16x8*)(pB), fb1;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+#if !defined(QFX_GEMM_B_RING1)
+            if (ni + 1 < NI) fb1 = *(const bf16x8*)(pB + (ni + 1) * (16 * BK * 2));
+#endif
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, a[mi], acc[mi][ni], 0, 0, 0);
+#if defined(QFX_GEMM_B_RING1)
+            if (ni + 1 < NI) fb1 = *(const bf16x8*)(pB + (ni + 1) * (16 * BK * 2));
+#endif
+            fb0 = fb1;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (mid_round && t == nt1 - 1) round_base();
+        buf ^= 1;
+      }
     } else {
-      // lane-constant fragment offsets: the swizzle depends on li only (rows advance in multiples of 16), the k-step flips
-      // chunk bit 2, i.e. XOR 64 on the byte offset
-      const int swl = (li >> 1) & 7;
-      const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
-      const int offB0 = BM2 * BK * 2 + (wc * 64 + li) * (BK * 2) + ((g ^ swl) << 4);
       for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -564,15 +622,15 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         for (int kk = 0; kk < 2; ++kk) {
           const char* pA = st + (offA0 ^ (kk << 6));
           const char* pB = st + (offB0 ^ (kk << 6));
-          bf16x8 b[4];
+          bf16x8 b[NI];
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8*)(pB + ni * (16 * BK * 2));
+          for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8*)(pB + ni * (16 * BK * 2));
           bf16x8 fa0 = *(const bf16x8*)(pA), fa1 = *(const bf16x8*)(pA + 16 * BK * 2), fa2;
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             if (mi + 2 < MI) fa2 = *(const bf16x8*)(pA + (mi + 2) * (16 * BK * 2));
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], fa0, acc[mi][ni], 0, 0, 0);
             fa0 = fa1; fa1 = fa2;
             __builtin_amdgcn_sched_barrier(0);
@@ -583,15 +641,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     }
 
-    // ---- epilogue (no block barrier): per 16-row pass the wave stages bf16(acc + bias) -- the nn.Linear output, first
-    // rounding point of every epilogue -- in its private 2 KiB of LDS (8-byte unit u = ni*4+g of row li stored at
-    // u ^ 2*(li>>1): conflict-free writes, 16-byte pairs stay adjacent) and reads it back row-contiguous, so global
-    // accesses are full 128-byte row segments instead of 8-byte pieces scattered over 16 rows.
+    // ---- epilogue (no block barrier): per 16-row pass and group of NG column fragments the wave stages bf16(acc + bias) -- the
+    // nn.Linear output, first rounding point of every epilogue -- in its private 2 KiB of LDS (8-byte unit u = nn*4+g of row li
+    // stored at u ^ 2*(li>>1): conflict-free writes, 16-byte pairs stay adjacent) and reads it back row-contiguous, so global
+    // accesses are row segments of 16 * NG * 2 bytes (128 B; 96 B for the 48-column groups) instead of 8-byte pieces scattered
+    // over 16 rows.
     const bool bias_pending = (p.bias != nullptr) && (nt2 == 0 || p.seg2_plain);
-    float bv[4][4];
+    float bv[NI][4];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + 4 * g;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wc * WCOLS + ni * 16 + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[ni][r] = 0.f;
       if (bias_pending && n + 3 < p.N) {
@@ -600,17 +659,20 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         for (int r = 0; r < 4; ++r) bv[ni][r] = bf2f((bf16_t)bb[r]);
       }
     }
-    const int ch = lane & 7;
-    const int n = n0 + wc * 64 + ch * 8;
-    const bool n_ok = n + 7 < p.N;
-    float gt[8];
-    int last_b = -1;
+    constexpr int CH = 2 * NG;                 // 16-byte chunks per staged row (8, or 6 for the 48-column groups)
+    constexpr int SLOTS = 16 * CH;             // chunk slots per staging pass: 128 (two full lane passes) or 96 (64 + 32)
+    constexpr bool GATE_CACHE = (NGRP == 1);   // the gate vector of the lane's columns stays in registers across the tile
+    constexpr int NGC = (64 % CH == 0) ? 1 : 2;   // CH = 8: the lane's chunk (lane & 7) is the same in both passes; CH = 6: one vector per pass
+    float gt[NGC][8];
+    int last_b[NGC];
+#pragma unroll
+    for (int i = 0; i < NGC; ++i) last_b[i] = -1;
     // MX-FP8 instantiation: the output the next GEMM contracts over (gelu(h) / dh / y) can leave the epilogue quantised -- the 8
     // lanes of a row hold 64 consecutive columns = 2 MX blocks of 4 lanes; same arithmetic as quant_mxfp8_kernel on the
     // bf16-rounded values, so the result is bit-identical to quantising the bf16 tensor in a separate pass.
     uint8_t* cq = nullptr; uint8_t* cs = nullptr; int64_t ldcq = 0; int cq_rows = 0; bool cq_only = false;
     if constexpr (FP8) { cq = ga.cq[gi]; cs = ga.cs[gi]; ldcq = ga.ldcq[gi]; cq_rows = ga.cq_rows[gi]; cq_only = ga.cq_only[gi] != 0; }
-    auto quant_store = [&](const u32x4& packed, int64_t crow) {
+    auto quant_store = [&](const u32x4& packed, int64_t crow, int n, int ch) {
       float v[8];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(packed[q] << 16); v[2 * q + 1] = __uint_as_float(packed[q] & 0xffff0000u); }
@@ -636,70 +698,98 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       const int kb = n >> 5;
       if ((ch & 3) == 0) cs[((int64_t)(kb >> 2) * cq_rows + crow) * 4 + (kb & 3)] = (uint8_t)(e + 127);
     };
+    // read-back slot of this lane in the two lane passes over a staged 16-row group: row, 16-byte chunk, LDS offset, first column
+    // (derived from a lane id the optimiser cannot see through: hoisted out of the persistent tile loop these lane constants
+    // would sit in registers across the K loop, which has none to spare)
+    int srow_[2], sch_[2], soff_[2], ncol_[2];
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int slot = j * 64 + ln;
+      srow_[j] = slot / CH; sch_[j] = slot - srow_[j] * CH;
+      soff_[j] = srow_[j] * 128 + ((sch_[j] ^ (srow_[j] >> 1)) << 4);
+      ncol_[j] = n0 + wc * WCOLS + sch_[j] * 8;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        u32x2 u;
-        u[0] = pack2bf(acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]);
-        u[1] = pack2bf(acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]);
-        *(u32x2*)(stg + li * 128 + (((ni * 4 + g) ^ ((li >> 1) << 1)) << 3)) = u;
-      }
+      for (int gq = 0; gq < NGRP; ++gq) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = (lane >> 3) + 8 * j;
-        const u32x4 yv = *(const u32x4*)(stg + row * 128 + ((ch ^ (row >> 1)) << 4));
-        const int m = m0 + wr * WROWS + mi * 16 + row;
-        if (m >= p.M || !n_ok) continue;
-        const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
-        if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
-          const u32x4 z = {0u, 0u, 0u, 0u};
-          *(u32x4*)(p.C + crow * p.ldc + n) = z;
-          if constexpr (FP8 && EPI != QFX_EPI_GATE_RES) { if (cq) quant_store(z, crow); }
-          if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
-          if constexpr (EPI == QFX_EPI_GATE_RES) { if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = z; }
-          continue;
+        for (int nn = 0; nn < NG; ++nn) {
+          const int ni = gq * NG + nn;
+          u32x2 u;
+          u[0] = pack2bf(acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]);
+          u[1] = pack2bf(acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]);
+          *(u32x2*)(stg + li * 128 + (((nn * 4 + g) ^ ((li >> 1) << 1)) << 3)) = u;
         }
-        float y[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { y[2 * q] = __uint_as_float(yv[q] << 16); y[2 * q + 1] = __uint_as_float(yv[q] & 0xffff0000u); }
-        if constexpr (EPI == QFX_EPI_NONE) {
-          if (!cq_only) *(u32x4*)(p.C + crow * p.ldc + n) = yv;
-          if constexpr (FP8) { if (cq) quant_store(yv, crow); }
-        } else if constexpr (EPI == QFX_EPI_GELU) {
-          u32x4 o2;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
-          *(u32x4*)(p.C + crow * p.ldc + n) = yv;
-          if (!cq_only) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
-          if constexpr (FP8) { if (cq) quant_store(o2, crow); }
-        } else if constexpr (EPI == QFX_EPI_GATE_RES) {
-          const int bidx = m / p.rows_per_batch;
-          if (bidx != last_b) {
-            const u32x4 gv = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { gt[2 * q] = __uint_as_float(gv[q] << 16); gt[2 * q + 1] = __uint_as_float(gv[q] & 0xffff0000u); }
-            last_b = bidx;
+        for (int j = 0; j < 2; ++j) {
+          if (SLOTS < 128 && j * 64 + ln >= SLOTS) continue;
+          const int row = srow_[j], ch = sch_[j];
+          const u32x4 yv = *(const u32x4*)(stg + soff_[j]);
+          const int m = m0 + wr * WROWS + mi * 16 + row;
+          const int n = ncol_[j] + gq * (16 * NG);
+          if (m >= p.M || n + 7 >= p.N) continue;
+          const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+          if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *(u32x4*)(p.C + crow * p.ldc + n) = z;
+            if constexpr (FP8 && EPI != QFX_EPI_GATE_RES) { if (cq) quant_store(z, crow, n, ch); }
+            if constexpr (EPI == QFX_EPI_GELU) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = z;
+            if constexpr (EPI == QFX_EPI_GATE_RES) { if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = z; }
+            continue;
           }
-          const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
-          u32x4 o;
+          float y[8];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float r0 = __uint_as_float(rv[q] << 16), r1 = __uint_as_float(rv[q] & 0xffff0000u);
-            o[q] = pack2bf(r0 + rbf(gt[2 * q] * y[2 * q]), r1 + rbf(gt[2 * q + 1] * y[2 * q + 1]));
-          }
-          *(u32x4*)(p.C + crow * p.ldc + n) = o;
-          if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yv;   // pre-gate linear output (rows UNMAPPED), kept for d(gate)
-        } else {  // QFX_EPI_DGELU
-          const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
-          u32x4 o;
+          for (int q = 0; q < 4; ++q) { y[2 * q] = __uint_as_float(yv[q] << 16); y[2 * q + 1] = __uint_as_float(yv[q] & 0xffff0000u); }
+          if constexpr (EPI == QFX_EPI_NONE) {
+            if (!cq_only) *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+            if constexpr (FP8) { if (cq) quant_store(yv, crow, n, ch); }
+          } else if constexpr (EPI == QFX_EPI_GELU) {
+            u32x4 o2;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float h0 = __uint_as_float(hv[q] << 16), h1 = __uint_as_float(hv[q] & 0xffff0000u);
-            o[q] = pack2bf(y[2 * q] * gelu_tanh_grad_f(h0), y[2 * q + 1] * gelu_tanh_grad_f(h1));
+            for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
+            *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+            if (!cq_only) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
+            if constexpr (FP8) { if (cq) quant_store(o2, crow, n, ch); }
+          } else if constexpr (EPI == QFX_EPI_GATE_RES) {
+            const int bidx = m / p.rows_per_batch;
+            float gl[8];
+            const int jc = NGC == 1 ? 0 : j;
+            if (!GATE_CACHE || bidx != last_b[jc]) {
+              const u32x4 gv = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { gl[2 * q] = __uint_as_float(gv[q] << 16); gl[2 * q + 1] = __uint_as_float(gv[q] & 0xffff0000u); }
+              if (GATE_CACHE) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gt[jc][q] = gl[q];
+                last_b[jc] = bidx;
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) gl[q] = gt[jc][q];
+            }
+            const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float r0 = __uint_as_float(rv[q] << 16), r1 = __uint_as_float(rv[q] & 0xffff0000u);
+              o[q] = pack2bf(r0 + rbf(gl[2 * q] * y[2 * q]), r1 + rbf(gl[2 * q + 1] * y[2 * q + 1]));
+            }
+            *(u32x4*)(p.C + crow * p.ldc + n) = o;
+            if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yv;   // pre-gate linear output (rows UNMAPPED), kept for d(gate)
+          } else {  // QFX_EPI_DGELU
+            const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float h0 = __uint_as_float(hv[q] << 16), h1 = __uint_as_float(hv[q] & 0xffff0000u);
+              o[q] = pack2bf(y[2 * q] * gelu_tanh_grad_f(h0), y[2 * q + 1] * gelu_tanh_grad_f(h1));
+            }
+            if (!cq_only) *(u32x4*)(p.C + crow * p.ldc + n) = o;
+            if constexpr (FP8) { if (cq) quant_store(o, crow, n, ch); }
           }
-          if (!cq_only) *(u32x4*)(p.C + crow * p.ldc + n) = o;
-          if constexpr (FP8) { if (cq) quant_store(o, crow); }
         }
       }
     }
@@ -728,62 +818,139 @@ int validate(const qfx_gemm_args* a) {
   return QFX_OK;
 }
 
-}  // namespace
+// ---- tile geometry choice ------------------------------------------------------------------------------------------------
+// cost(geometry) = rounds over the 256 CUs x relative time of one tile.  The relative tile times are the tile areas scaled by a
+// measured per-flop efficiency (256x128 = 1): the 256-wide tiles move a third less LDS-DMA and a quarter less fragment traffic
+// per flop (+9 %: round 1); the 160-row tiles were measured in round 4 (profiles/r04_gemm_tiles.json).  QFX_GEMM_TILES selects
+// the candidate set ("legacy" = the 256-row tiles of rounds 1-3; a comma list of BMTxTN names; default: all); QFX_GEMM_EFF
+// overrides the five efficiency factors (A/B experiments).  Both are read once per process.
+struct Geo { int bmt, tn; double area, eff; bool on; };
+Geo g_geo[5] = {
+    {256, 128, 1.0, 1.00, true},
+    {256, 256, 2.0, 1.09, true},
+    {160, 192, 0.9375, 0.985, true},
+    {160, 256, 1.25, 1.04, true},
+    {160, 384, 1.875, 1.06, true},
+};
+bool g_geo_init = false;
 
-extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream) {
-  if (!groups || n <= 0 || n > QFX_MAX_GROUPS) return QFX_EINVAL;
-  GroupedArgs ga;
-  long t128 = 0, t256 = 0;
-  bool can256 = true;
-  for (int i = 0; i < n; ++i) {
-    const int rc = validate(&groups[i]);
-    if (rc) return rc;
-    if (groups[i].epi != groups[0].epi) return QFX_EINVAL;
-    if (!ok256(&groups[i])) return QFX_EINVAL;  /* 16-byte epilogue accesses */
-    const long tm = (groups[i].M + BM2 - 1) / BM2;
-    t128 += tm * ((groups[i].N + 127) / 128);
-    t256 += tm * ((groups[i].N + 255) / 256);
-    can256 = can256 && (groups[i].N % 256) == 0;
+int geo_set(const char* tiles, const char* eff) {
+  if (tiles && *tiles) {
+    const std::string v(tiles);
+    if (v == "legacy") { for (int i = 0; i < 5; ++i) g_geo[i].on = i < 2; }
+    else if (v == "all") { for (auto& gg : g_geo) gg.on = true; }
+    else {
+      bool on[5], any = false;
+      for (int i = 0; i < 5; ++i) {
+        char name[32];
+        snprintf(name, sizeof name, "%dx%d", g_geo[i].bmt, g_geo[i].tn);
+        on[i] = v.find(name) != std::string::npos;
+        any = any || on[i];
+      }
+      if (!any) return QFX_EINVAL;
+      for (int i = 0; i < 5; ++i) g_geo[i].on = on[i];
+    }
   }
-  // Tile width: rounds over the 256 CUs x relative time per tile (a 256-wide tile is 2 / 1.09 of a 128-wide one: measured
-  // +9 % per flop).  N = 12288 problems (960 vs 480 tiles: 4 vs 2 rounds) take the wide tile; the N = 3072 ones (240 tiles, one
-  // round either way) and the 3-round q/k/v launch keep the narrow one.
-  const double cost128 = (double)((t128 + QFX_NUM_CU - 1) / QFX_NUM_CU);
-  const double cost256 = (double)((t256 + QFX_NUM_CU - 1) / QFX_NUM_CU) * (2.0 / 1.09);
-  const int tn = (can256 && cost256 < cost128) ? 256 : 128;
+  if (eff && *eff) {
+    double e[5];
+    if (sscanf(eff, "%lf,%lf,%lf,%lf,%lf", &e[0], &e[1], &e[2], &e[3], &e[4]) != 5) return QFX_EINVAL;
+    for (int i = 0; i < 5; ++i) if (!(e[i] > 0.1 && e[i] < 10.0)) return QFX_EINVAL;
+    for (int i = 0; i < 5; ++i) g_geo[i].eff = e[i];
+  }
+  return QFX_OK;
+}
+
+void geo_init() {
+  if (g_geo_init) return;
+  g_geo_init = true;
+  (void)geo_set(getenv("QFX_GEMM_TILES"), getenv("QFX_GEMM_EFF"));     // an unparsable environment value keeps the defaults
+}
+
+template <int E, bool FP8>
+void launch_geo(int gi, int grid, hipStream_t s, const GroupedArgs& ga) {
+  if constexpr (FP8) {
+    hipLaunchKernelGGL((gemm256_kernel<E, 256, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga);
+  } else {
+    switch (gi) {
+      case 0: hipLaunchKernelGGL((gemm256_kernel<E, 256, 128>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+      case 1: hipLaunchKernelGGL((gemm256_kernel<E, 256, 256>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+      case 2: hipLaunchKernelGGL((gemm256_kernel<E, 160, 192>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+      case 3: hipLaunchKernelGGL((gemm256_kernel<E, 160, 256>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+      default: hipLaunchKernelGGL((gemm256_kernel<E, 160, 384>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+    }
+  }
+}
+
+template <bool FP8>
+int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo, int epi, hipStream_t s) {
+  const int bmt = g_geo[geo].bmt, tn = g_geo[geo].tn;
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
-    ga.g[i] = groups[i];
     ga.tile_start[i] = tiles;
-    tiles += ((groups[i].M + BM2 - 1) / BM2) * ((groups[i].N + tn - 1) / tn);
+    tiles += ((probs[i]->M + bmt - 1) / bmt) * ((probs[i]->N + tn - 1) / tn);
   }
   for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
   ga.n = n;
-  hipStream_t s = (hipStream_t)stream;
   // balanced persistent grid: whole rounds over <= 256 CUs, multiple of 8 (one residue class per XCD)
   const int rounds = (tiles + QFX_NUM_CU - 1) / QFX_NUM_CU;
   int grid = (((tiles + rounds - 1) / rounds) + 7) & ~7;
   if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
   if (grid > tiles) grid = tiles;
-#define QFX_LAUNCH256(E) \
-  do { if (tn == 256) hipLaunchKernelGGL((gemm256_kernel<E, 256>), dim3(grid), dim3(WS_THREADS), 0, s, ga); \
-       else hipLaunchKernelGGL((gemm256_kernel<E, 128>), dim3(grid), dim3(WS_THREADS), 0, s, ga); } while (0)
-  switch (groups[0].epi) {
-    case QFX_EPI_NONE: QFX_LAUNCH256(QFX_EPI_NONE); break;
-    case QFX_EPI_GELU: QFX_LAUNCH256(QFX_EPI_GELU); break;
-    case QFX_EPI_GATE_RES: QFX_LAUNCH256(QFX_EPI_GATE_RES); break;
-    default: QFX_LAUNCH256(QFX_EPI_DGELU); break;
+  switch (epi) {
+    case QFX_EPI_NONE: launch_geo<QFX_EPI_NONE, FP8>(geo, grid, s, ga); break;
+    case QFX_EPI_GELU: launch_geo<QFX_EPI_GELU, FP8>(geo, grid, s, ga); break;
+    case QFX_EPI_GATE_RES: launch_geo<QFX_EPI_GATE_RES, FP8>(geo, grid, s, ga); break;
+    default: launch_geo<QFX_EPI_DGELU, FP8>(geo, grid, s, ga); break;
   }
-#undef QFX_LAUNCH256
   QFX_CHECK_LAUNCH();
   return QFX_OK;
+}
+
+}  // namespace
+
+extern "C" int qfx_gemm_tune(const char* tiles, const char* eff) {
+  geo_init();
+  return geo_set(tiles, eff);
+}
+
+extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream) {
+  if (!groups || n <= 0 || n > QFX_MAX_GROUPS) return QFX_EINVAL;
+  GroupedArgs ga;
+  const qfx_gemm_args* probs[QFX_MAX_GROUPS];
+  bool n256 = true;
+  for (int i = 0; i < n; ++i) {
+    const int rc = validate(&groups[i]);
+    if (rc) return rc;
+    if (groups[i].epi != groups[0].epi) return QFX_EINVAL;
+    if (!ok256(&groups[i])) return QFX_EINVAL;  /* 16-byte epilogue accesses */
+    n256 = n256 && (groups[i].N % 256) == 0;
+    ga.g[i] = groups[i];
+    probs[i] = &groups[i];
+  }
+  geo_init();
+  // e.g. B = 1, N = 3072: 240 tiles of 256x128 (one round, cost 1.0) vs 256 tiles of 160x192 (one round, 0.9375 / eff);
+  // N = 12288: 480 tiles of 256x256 (two rounds of 240) vs 512 tiles of 160x384 (two full rounds); the q/k/v launch: 720 vs 768
+  // narrow tiles (three rounds either way).
+  int best = -1;
+  double best_cost = 0.0;
+  for (int c = 0; c < 5; ++c) {
+    const Geo& gg = g_geo[c];
+    if (!gg.on) continue;
+    if (gg.tn >= 256 && !n256) continue;     // the wide tiles keep whole tiles along N (round-1 contract)
+    long t = 0;
+    for (int i = 0; i < n; ++i) t += (long)((groups[i].M + gg.bmt - 1) / gg.bmt) * ((groups[i].N + gg.tn - 1) / gg.tn);
+    const double cost = (double)((t + QFX_NUM_CU - 1) / QFX_NUM_CU) * gg.area / gg.eff;
+    if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+  }
+  if (best < 0) best = 0;
+  return launch_grouped<false>(ga, probs, n, best, groups[0].epi, (hipStream_t)stream);
 }
 
 // MX-FP8 operands on the warp-specialised persistent kernel (256x128 tiles): see GroupedArgs for how they reach the loaders.
 extern "C" int qfx_gemm_mxfp8_grouped(const qfx_gemm_fp8_args* list, int32_t n, void* stream) {
   if (!list || n <= 0 || n > QFX_MAX_GROUPS) return QFX_EINVAL;
   GroupedArgs ga;
-  int tiles = 0;
+  const qfx_gemm_args* probs[QFX_MAX_GROUPS];
   for (int i = 0; i < n; ++i) {
     qfx_gemm_args g = list[i].g;
     if (!g.A1 || !g.B1 || !g.C || !list[i].sa || !list[i].sb) return QFX_EINVAL;
@@ -801,35 +968,20 @@ extern "C" int qfx_gemm_mxfp8_grouped(const qfx_gemm_fp8_args* list, int32_t n, 
       return QFX_EINVAL;
     }
     ga.g[i] = g;
+    probs[i] = &ga.g[i];
     ga.sa[i] = list[i].sa; ga.sb[i] = list[i].sb;
     ga.cq[i] = list[i].cq; ga.cs[i] = list[i].cs; ga.ldcq[i] = list[i].ldcq; ga.cq_rows[i] = list[i].cq_rows; ga.cq_only[i] = list[i].cq_only;
-    ga.tile_start[i] = tiles;
-    tiles += ((g.M + BM2 - 1) / BM2) * ((g.N + 127) / 128);
   }
-  for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
   for (int i = n; i < QFX_MAX_GROUPS; ++i) { ga.sa[i] = nullptr; ga.sb[i] = nullptr; ga.cq[i] = nullptr; ga.cs[i] = nullptr; ga.ldcq[i] = 0; ga.cq_rows[i] = 0; ga.cq_only[i] = 0; }
-  ga.n = n;
-  hipStream_t s = (hipStream_t)stream;
-  const int rounds = (tiles + QFX_NUM_CU - 1) / QFX_NUM_CU;
-  int grid = (((tiles + rounds - 1) / rounds) + 7) & ~7;
-  if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
-  if (grid > tiles) grid = tiles;
-  switch (list[0].g.epi) {
-    case QFX_EPI_NONE: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_NONE, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-    case QFX_EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_GELU, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-    case QFX_EPI_GATE_RES: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_GATE_RES, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-    default: hipLaunchKernelGGL((gemm256_kernel<QFX_EPI_DGELU, 128, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-  }
-  QFX_CHECK_LAUNCH();
-  return QFX_OK;
+  return launch_grouped<true>(ga, probs, n, 0, list[0].g.epi, (hipStream_t)stream);
 }
 
 extern "C" int qfx_gemm_bf16(const qfx_gemm_args* a, void* stream) {
   if (!a) return QFX_EINVAL;
   const int rc = validate(a);
   if (rc) return rc;
-  // large problems: 256x128 tiles / 3-stage ring; small ones keep the 128x128 kernel (more tiles, 2 blocks per CU)
-  const int tiles256 = ((a->M + BM2 - 1) / BM2) * ((a->N + BN - 1) / BN);
+  // large problems: persistent tiles; small ones keep the 128x128 kernel (more tiles, 2 blocks per CU)
+  const int tiles256 = ((a->M + 255) / 256) * ((a->N + BN - 1) / BN);
   if (tiles256 >= 160 && ok256(a)) return qfx_gemm_grouped(a, 1, stream);
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   hipStream_t s = (hipStream_t)stream;

@@ -135,7 +135,7 @@ class AttnArgs(C.Structure):
     ]
 
 
-ABI_VERSION = 4        # QFX_ABI_VERSION
+ABI_VERSION = 5        # QFX_ABI_VERSION
 MAX_BATCH = 8          # QFX_MAX_BATCH
 MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
@@ -188,6 +188,7 @@ SYMBOLS = {
     "qfx_stream_create_cu_masked": (C.c_int, [_i32, C.POINTER(C.c_void_p)]),
     "qfx_stream_destroy": (C.c_int, [_vp]),
     "qfx_debug_where": (C.c_int, [_vp, _i32, _vp]),
+    "qfx_gemm_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
     "qfx_debug_tr_read": (C.c_int, [_vp, _vp, _vp]),
     "qfx_abi_version": (C.c_int, []),
     "qfx_build_arch": (C.c_char_p, []),

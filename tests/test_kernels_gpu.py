@@ -207,6 +207,96 @@ def test_gemm_wide_tile_all_epilogues():
         check(f"gemm_wide_grouped_{i}", it[2], rf, 1e-2)
 
 
+GEOMETRIES = ("256x128", "256x256", "160x192", "160x256", "160x384")
+
+
+@pytest.mark.parametrize("geo", GEOMETRIES)
+def test_gemm_every_tile_geometry(geo):
+    """Round 4: the persistent GEMM picks its tile geometry per launch (qfx_gemm_tune); here each of the five is FORCED in turn on the
+    DiT's own row structure -- a grouped launch of a 2048-row (image) and a 384-row (text) problem with different weights, N = 3072,
+    LoRA K segment with bf16 mid-rounding, every epilogue incl. gate + residual over a joint-buffer row map, a row mask, ragged M --
+    against the fp32 product with the eager graph's rounding points, and bit-identical to the 256x128 result (the K order of an output
+    element does not depend on the tile it lies in)."""
+    import ctypes as C
+    from qflux_amd import _lib as L
+    ops = _ops()
+    lib = L.lib
+
+    def run_all():
+        outs = {}
+        N, K, K2 = 3072, 192, 64
+        # grouped image + text problems, every epilogue
+        for epi in (0, 1, 2, 3):
+            gs, keep, refs = [], [], []
+            for i, Mi in enumerate((2048, 384)):
+                a, b = randn(Mi, K, seed=10 + i).to(BF), randn(N, K, seed=20 + i, scale=0.2).to(BF)
+                a2, b2 = randn(Mi, K2, seed=30 + i).to(BF), randn(N, K2, seed=40 + i, scale=0.1).to(BF)
+                bias = randn(N, seed=50 + i).to(BF)
+                h = rb(rb(a.float() @ b.float().t() + bias.float()) + a2.float() @ b2.float().t())
+                g = L.GemmArgs()
+                t = [x.to(DEV) for x in (a, b, a2, b2, bias)]
+                out = torch.zeros(Mi, N, dtype=BF, device=DEV)
+                g.A1, g.B1, g.lda1, g.ldb1, g.K1 = t[0].data_ptr(), t[1].data_ptr(), K, K, K
+                g.A2, g.B2, g.lda2, g.ldb2, g.K2 = t[2].data_ptr(), t[3].data_ptr(), K2, K2, K2
+                g.M, g.N, g.bias, g.C, g.ldc, g.rows_per_batch, g.epi = Mi, N, t[4].data_ptr(), out.data_ptr(), N, Mi, epi
+                extra = None
+                if epi == 1:
+                    extra = torch.zeros(Mi, N, dtype=BF, device=DEV)
+                    g.C2, g.ldc2 = extra.data_ptr(), N
+                    ref = (h, rb(F.gelu(h, approximate="tanh")))
+                elif epi == 2:
+                    gate, res = randn(1, N, seed=60 + i).to(BF), randn(Mi, N, seed=70 + i).to(BF)
+                    t += [gate.to(DEV), res.to(DEV)]
+                    g.gate, g.gate_bstride, g.aux, g.ldaux = t[-2].data_ptr(), N, t[-1].data_ptr(), N
+                    ref = (rb(res.float() + rb(gate.float() * h)),)
+                elif epi == 3:
+                    hx = randn(Mi, N, seed=80 + i).to(BF)
+                    hh = hx.float().requires_grad_(True)
+                    F.gelu(hh, approximate="tanh").sum().backward()
+                    t.append(hx.to(DEV))
+                    g.aux, g.ldaux = t[-1].data_ptr(), N
+                    ref = (rb(h * hh.grad),)
+                else:
+                    ref = (h,)
+                gs.append(g); keep.append((t, out, extra)); refs.append(ref)
+            arr = (L.GemmArgs * 2)(*gs)
+            L.check(lib.qfx_gemm_grouped(arr, 2, ops.stream_ptr()), "qfx_gemm_grouped")
+            for i in range(2):
+                outs[f"grouped_epi{epi}_{i}"] = (keep[i][1].cpu(), refs[i][0])
+                if epi == 1:
+                    outs[f"grouped_epi1_gelu_{i}"] = (keep[i][2].cpu(), refs[i][1])
+        # gate + residual with two samples, C row map into a joint buffer, row mask, ragged M (1900 = 2 x 950 rows)
+        Bn, rpb, T, K = 2, 950, 24, 128
+        M, S = Bn * rpb, 24 + 950
+        a, b = randn(M, K, seed=1).to(BF), randn(N, K, seed=2, scale=0.2).to(BF)
+        gate, res = randn(Bn, N, seed=7).to(BF), randn(M, N, seed=8).to(BF)
+        y = rb(a.float() @ b.float().t())
+        refg = rb(res.float() + rb(gate.float().repeat_interleave(rpb, 0) * y))
+        mask = torch.ones(M)
+        mask[777:1000] = 0
+        refg[mask == 0] = 0
+        cj = torch.zeros(Bn * S, N, dtype=BF, device=DEV)
+        resj = torch.zeros(Bn, S, N, dtype=BF)
+        resj[:, T:] = res.view(Bn, rpb, N)
+        ops.gemm(a.to(DEV), b.to(DEV), out=cj, epi=2, aux=resj.view(Bn * S, N).to(DEV), gate=gate.to(DEV), rows_per_batch=rpb, c_map=(S, T),
+                 row_mask=mask.to(DEV))
+        outs["gate_res_cmap_mask"] = (cj.view(Bn, S, N)[:, T:].reshape(M, N).cpu(), refg)
+        assert cj.view(Bn, S, N)[:, :T].abs().max().item() == 0.0
+        return outs
+
+    try:
+        assert lib.qfx_gemm_tune(b"256x128", None) == 0
+        base = run_all()
+        assert lib.qfx_gemm_tune(geo.encode(), None) == 0
+        got = run_all()
+    finally:
+        assert lib.qfx_gemm_tune(b"all", None) == 0
+    assert lib.qfx_gemm_tune(b"17x3", None) == -1 and lib.qfx_gemm_tune(None, b"1,2") == -1       # unparsable: refused, policy kept
+    for k, (o, ref) in got.items():
+        check(f"gemm_geo_{geo}_{k}", o, ref, 1.5e-2)
+        assert torch.equal(o, base[k][0]), f"{geo} {k}: differs from the 256x128 tile's result"
+
+
 # ------------------------------------------------------------------------------------------ LoRA pieces
 def _split(x):
     hi = x.to(BF)
