@@ -431,9 +431,9 @@ int qfx_stream_destroy(void* stream);
 int qfx_debug_where(uint32_t* out, int32_t n_blocks, void* stream);
 
 /* ---- tuning: tile-geometry policy of the persistent GEMM (qfx_gemm_grouped / large qfx_gemm_bf16; ABI 5).  Every launch picks
- * its tile from rounds-over-256-CUs x relative tile time among the enabled geometries "256x128", "256x256" (rounds 1-3), "160x192",
- * "160x256", "160x384" (round 4: M = 2048 image + 384 text rows tile into 13 + 3 M-tiles of 160 = whole rounds of 256 tiles).
- * tiles: NULL / "" = keep, "all", "legacy" (the two 256-row tiles), or a comma list of names; eff: NULL = keep, or five
+ * its tile from rounds-over-256-CUs x relative tile time among the enabled geometries "256x128", "256x256" (rounds 1-3) and
+ * "160x192" (round 4: M = 2048 image + 384 text rows tile into 13 + 3 M-tiles of 160 x 16 N-tiles = one whole round of 256 tiles).
+ * tiles: NULL / "" = keep, "all", "legacy" (the two 256-row tiles), or a comma list of names; eff: NULL = keep, or three
  * comma-separated per-flop efficiencies relative to 256x128 in the order above.  Process-wide; the defaults come from the
  * environment (QFX_GEMM_TILES / QFX_GEMM_EFF) at the first launch.  Results do not depend on the geometry (same K order per
  * output element); only speed does.  Returns QFX_EINVAL for an unparsable argument. ---- */

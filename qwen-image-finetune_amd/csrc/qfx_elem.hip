@@ -48,26 +48,9 @@ __device__ __forceinline__ void mx_store8(const float (&o)[8], uint8_t* dst, uin
 struct LnFwdBatch { qfx_ln_fwd_args a[QFX_MAX_LN_BATCH]; int n; };
 struct LnBwdBatch { qfx_ln_bwd_args a[QFX_MAX_LN_BATCH]; int n; };
 
-// Rows per wave (round 4): with one row per wave all ~2400 waves of a launch are resident at once and move in lock-step -- one
-// read burst, then one write burst, the two never overlap.  A grid of 1 / QFX_LN_RPW of the row blocks makes every wave walk
-// QFX_LN_RPW rows (stride = grid): the loads of its next row queue behind the stores of the previous one and the memory system sees
-// reads and writes together.  No register cost (rows are processed one after the other).
-#if !defined(QFX_LN_RPW)
-#define QFX_LN_RPW 1
-#endif
-inline int ln_grid(int row_blocks) { return (row_blocks + QFX_LN_RPW - 1) / QFX_LN_RPW; }
-#if QFX_LN_RPW > 1
-#define QFX_LN_ROWS_BEGIN for (int rb_ = blockIdx.x; rb_ < row_blocks; rb_ += gridDim.x) {
-#define QFX_LN_NEXT continue
-#else      // one row per wave: no loop at all (the loop form costs registers: 165 -> 238 in the backward kernel)
-#define QFX_LN_ROWS_BEGIN { const int rb_ = blockIdx.x; (void)row_blocks;
-#define QFX_LN_NEXT return
-#endif
-
-__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt, int row_blocks) {
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt) {
   const int lane = threadIdx.x & 63;
- QFX_LN_ROWS_BEGIN
-  int row = rb_ * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   int pi = 0;
 #pragma unroll
   for (int i = 0; i + 1 < QFX_MAX_LN_BATCH; ++i)
@@ -80,7 +63,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt, in
     x = q.x; shift = q.shift; scale = q.scale; y = q.y; mod_bstride = q.mod_bstride; rows = q.rows; D = q.D; rpb = q.rows_per_batch; eps = q.eps;
     yq = q.yq; ys = q.ys; ldyq = q.ldyq; ys_rows = q.ys_rows;
   }
-  if (row >= rows) QFX_LN_NEXT;
+  if (row >= rows) return;
   const int b = row / rpb;
   const bf16_t* xr = x + (int64_t)row * D;
   float v[MAXP][8];
@@ -122,15 +105,13 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt, in
       if (yq) mx_store8(o, yq + (int64_t)row * ldyq + col, ys, ys_rows, row, col, lane);
     }
   }
- }
 }
 
 // ---------------------------------------------------------------- LayerNorm + modulate, backward
 template <int NP>   // passes of 512 columns: NP = ceil(D / 512) (register arrays are sized by it)
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt, int row_blocks) {
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   const int lane = threadIdx.x & 63;
- QFX_LN_ROWS_BEGIN     // see ln_mod_fwd_kernel
-  int row = rb_ * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   int pi = 0;
 #pragma unroll
   for (int i = 0; i + 1 < QFX_MAX_LN_BATCH; ++i)
@@ -145,7 +126,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt, in
     mod_bstride = q.mod_bstride; gate_bstride = q.gate_bstride; rows = q.rows; D = q.D; rpb = q.rows_per_batch; eps = q.eps;
     dygq = q.dygq; dygs = q.dygs; lddygq = q.lddygq; dygs_rows = q.dygs_rows;
   }
-  if (row >= rows) QFX_LN_NEXT;
+  if (row >= rows) return;
   const int b = row / rpb;
   const int64_t ro = (int64_t)row * D;
   if (row_mask != nullptr && row_mask[row] == 0.f) {   // padded token: no gradient flows through it
@@ -159,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt, in
         if (dyg && dygq) { const float zf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; mx_store8(zf, dygq + (int64_t)row * lddygq + col, dygs, dygs_rows, row, col, lane); }
       }
     }
-    QFX_LN_NEXT;
+    return;
   }
   // All three HBM streams of the row (x, dy, dres) are requested up front and kept as packed bf16 (one memory latency instead of
   // three dependent ones); g = bf16(dy * bf16(1+scale)) is exactly representable in bf16 and is kept packed too.
@@ -236,7 +217,6 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt, in
       }
     }
   }
- }
 }
 
 // ---------------------------------------------------------------- gradients of the modulation vectors (shift, scale, gate)
@@ -989,7 +969,7 @@ extern "C" int qfx_ln_modulate_fwd_batch(const qfx_ln_fwd_args* list, int32_t n,
   }
   for (int i = n; i < QFX_MAX_LN_BATCH; ++i) bt.a[i] = list[0];
   bt.n = n;
-  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(ln_grid(rows / 4)), dim3(256), 0, (hipStream_t)stream, bt, rows / 4);
+  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }
@@ -1021,8 +1001,8 @@ extern "C" int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n,
   bt.n = n;
   int dmax = 0;
   for (int i = 0; i < n; ++i) dmax = list[i].D > dmax ? list[i].D : dmax;
-  if (dmax <= 3072) hipLaunchKernelGGL(ln_mod_bwd_kernel<6>, dim3(ln_grid(rows / 4)), dim3(256), 0, (hipStream_t)stream, bt, rows / 4);
-  else hipLaunchKernelGGL(ln_mod_bwd_kernel<MAXP>, dim3(ln_grid(rows / 4)), dim3(256), 0, (hipStream_t)stream, bt, rows / 4);
+  if (dmax <= 3072) hipLaunchKernelGGL(ln_mod_bwd_kernel<6>, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
+  else hipLaunchKernelGGL(ln_mod_bwd_kernel<MAXP>, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

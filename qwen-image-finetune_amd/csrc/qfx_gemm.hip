@@ -226,14 +226,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 //   256 x 128  4 x 2 waves of 64 x 64   3-stage ring (48 KiB)   rotated K loop            -- rounds 1-3
 //   256 x 256  2 x 4 waves of 128 x 64  2-stage ring (64 KiB)   streaming K loop (+9 % per flop: a third less LDS-DMA, a
 //                                                                 quarter less fragment traffic)
-//   160 x 192  2 x 4 waves of 80 x 48   3-stage ring (44 KiB)   rotated K loop            -- round 4: the DiT's M is
-//   160 x 256  2 x 4 waves of 80 x 64   2-stage ring (52 KiB)   streaming K loop             2048 image + 384 text rows with
-//   160 x 384  2 x 4 waves of 80 x 96   2-stage ring (68 KiB)   streaming K loop             DIFFERENT weights per stream.
-// Why 160 rows: with 256-row tiles a B = 1 step runs 8 + 2 M-tiles (the second text tile half empty: 5 % padding) x 24 N-tiles
-// = 240 tiles on 256 CUs (6 % idle) -- every narrow launch is ONE round of one 32768-element tile per CU.  160 rows give
-// 13 + 3 = 16 M-tiles x 16 N-tiles of 192 = exactly 256 tiles of 30720 elements (-6.25 % per CU; 2 % padding on the image
-// stream) and 16 x 32 x (160 x 384) = 512 = two full rounds for the N = 12288 launches.  The launcher picks the geometry per
-// launch from rounds x relative tile time (qfx_gemm_grouped).
+//   160 x 192  2 x 4 waves of 80 x 48   3-stage ring (44 KiB)   rotated K loop            -- round 4
+// Why 160 rows: the DiT's M is 2048 image + 384 text rows with DIFFERENT weights per stream.  With 256-row tiles a B = 1 step runs
+// 8 + 2 M-tiles (the second text tile half empty: 5 % padding) x 24 N-tiles = 240 tiles on 256 CUs (6 % idle) -- every narrow
+// launch is ONE round of one 32768-element tile per CU.  160 rows give 13 + 3 = 16 M-tiles x 16 N-tiles of 192 = exactly 256
+// tiles of 30720 elements (-6.25 % per CU; 2 % padding on the image stream).  Measured in the step (profiles/r04_gemm_tiles.json):
+// -1 .. -2.6 % per narrow launch (the 80 x 48 wave tile reads 8 fragments per 15 MFMAs and runs ~3.5 % below the 64 x 64 one per
+// flop), whole step 99.7 -> 99.1 ms with every narrow launch on it.
+// The wide counterparts 160 x 384 (two full rounds for N = 12288; 120 accumulators leave the allocator four registers short: scratch
+// reloads inside the K loop) and 160 x 256 (three rounds) were built and measured +13 % / +24 % against 256 x 256: removed.
+// The launcher picks the geometry per launch from rounds x relative tile time (qfx_gemm_grouped).
 constexpr int NLD = 2;                            // loader waves
 constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
@@ -393,19 +395,26 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 
   // ================================================================== compute waves
   const int wr = w / TC::WCN, wc = w % TC::WCN;
-  const int g = lane >> 4, li = lane & 15;
   constexpr int WROWS = 16 * MI;   // rows per compute wave
   char* stg = smem + NSTAGE * STAGE_BYTES + w * STG_BYTES;
   int buf = 0;
-  // lane-constant fragment offsets: the swizzle depends on li only (wave / fragment rows advance in multiples of 16), the k-step
-  // flips chunk bit 2, i.e. XOR 64 on the byte offset
-  const int swl = (li >> 1) & 7;
-  const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
-  const int offB0 = BMT * BK * 2 + (wc * WCOLS + li) * (BK * 2) + ((g ^ swl) << 4);
+  (void)lane;
   for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
     int gi, m0, n0;
     tile_coord<BMT, TN>(ga, nwg, bid, gi, m0, n0);
     KArgs& p = ga.g[gi];
+    // Lane-derived values are re-derived per tile -- here for the K loop, once more for the epilogue -- from a lane id the optimiser
+    // cannot see through (v_mbcnt in an asm volatile: neither hoisted nor spilled).  Kept in registers across the whole persistent
+    // loop, these lane constants are what the allocator spills when the epilogue is register-hungry, and their reloads land INSIDE
+    // the K loop (a scratch load + vmcnt wait per K tile).
+    int l0;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l0));
+    const int g = l0 >> 4, li = l0 & 15;
+    // fragment offsets: the swizzle depends on li only (wave / fragment rows advance in multiples of 16), the k-step flips chunk
+    // bit 2, i.e. XOR 64 on the byte offset
+    const int swl = (li >> 1) & 7;
+    const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
+    const int offB0 = BMT * BK * 2 + (wc * WCOLS + li) * (BK * 2) + ((g ^ swl) << 4);
     const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
 
     f32x4 acc[MI][NI];
@@ -569,48 +578,6 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
       }
-    } else if constexpr (NI > MI) {
-      // 80 x 96 wave tile: the MI = 5 A fragments stay resident and the NI = 6 B fragments stream one read ahead (120 accumulators +
-      // 20 + 8 operand registers; the mirrored form of the loop below -- 24 resident + a three-deep ring -- spills inside the loop)
-      for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* st = smem + buf * STAGE_BYTES;
-        if (wave_dead) { buf ^= 1; continue; }   // see the narrow-tile loop
-        // the fragment offsets are re-derived from the lane id per K tile (six VALU operations): kept across the loop, the four
-        // address registers are what the allocator spills at 120 accumulators (a scratch reload per K tile and its vmcnt wait)
-        int l2;   // lane id without a live register (asm volatile: not hoisted, not spilled)
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
-        const int g2 = l2 >> 4, li2 = l2 & 15, sw2 = (li2 >> 1) & 7;
-        const int oA = (wr * WROWS + li2) * (BK * 2) + ((g2 ^ sw2) << 4);
-        const int oB = BMT * BK * 2 + (wc * WCOLS + li2) * (BK * 2) + ((g2 ^ sw2) << 4);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const char* pA = st + (oA ^ (kk << 6));
-          const char* pB = st + (oB ^ (kk << 6));
-          bf16x8 a[MI];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(pA + mi * (16 * BK * 2));
-          bf16x8 fb0 = *(const bf16x8*)(pB), fb1;
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-#if !defined(QFX_GEMM_B_RING1)
-            if (ni + 1 < NI) fb1 = *(const bf16x8*)(pB + (ni + 1) * (16 * BK * 2));
-#endif
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, a[mi], acc[mi][ni], 0, 0, 0);
-#if defined(QFX_GEMM_B_RING1)
-            if (ni + 1 < NI) fb1 = *(const bf16x8*)(pB + (ni + 1) * (16 * BK * 2));
-#endif
-            fb0 = fb1;
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        if (mid_round && t == nt1 - 1) round_base();
-        buf ^= 1;
-      }
     } else {
       for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -647,10 +614,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     // accesses are row segments of 16 * NG * 2 bytes (128 B; 96 B for the 48-column groups) instead of 8-byte pieces scattered
     // over 16 rows.
     const bool bias_pending = (p.bias != nullptr) && (nt2 == 0 || p.seg2_plain);
+    int ln;     // the epilogue's own lane id (see the top of the tile loop)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int ge = ln >> 4, lie = ln & 15;
     float bv[NI][4];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wc * WCOLS + ni * 16 + 4 * g;
+      const int n = n0 + wc * WCOLS + ni * 16 + 4 * ge;
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[ni][r] = 0.f;
       if (bias_pending && n + 3 < p.N) {
@@ -661,7 +631,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     }
     constexpr int CH = 2 * NG;                 // 16-byte chunks per staged row (8, or 6 for the 48-column groups)
     constexpr int SLOTS = 16 * CH;             // chunk slots per staging pass: 128 (two full lane passes) or 96 (64 + 32)
-    constexpr bool GATE_CACHE = (NGRP == 1);   // the gate vector of the lane's columns stays in registers across the tile
+    constexpr bool GATE_CACHE = (NGRP == 1) && !TC::WIDE;   // narrow tiles: the gate vector of the lane's columns stays in registers across the tile (the wide tile has none to spare: 128 accumulators)
     constexpr int NGC = (64 % CH == 0) ? 1 : 2;   // CH = 8: the lane's chunk (lane & 7) is the same in both passes; CH = 6: one vector per pass
     float gt[NGC][8];
     int last_b[NGC];
@@ -699,11 +669,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       if ((ch & 3) == 0) cs[((int64_t)(kb >> 2) * cq_rows + crow) * 4 + (kb & 3)] = (uint8_t)(e + 127);
     };
     // read-back slot of this lane in the two lane passes over a staged 16-row group: row, 16-byte chunk, LDS offset, first column
-    // (derived from a lane id the optimiser cannot see through: hoisted out of the persistent tile loop these lane constants
-    // would sit in registers across the K loop, which has none to spare)
     int srow_[2], sch_[2], soff_[2], ncol_[2];
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int slot = j * 64 + ln;
@@ -721,7 +687,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
           u32x2 u;
           u[0] = pack2bf(acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]);
           u[1] = pack2bf(acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]);
-          *(u32x2*)(stg + li * 128 + (((nn * 4 + g) ^ ((li >> 1) << 1)) << 3)) = u;
+          *(u32x2*)(stg + lie * 128 + (((nn * 4 + ge) ^ ((lie >> 1) << 1)) << 3)) = u;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -770,6 +736,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 #pragma unroll
               for (int q = 0; q < 8; ++q) gl[q] = gt[jc][q];
             }
+            // (aux rows are loaded where they are used: requesting them one to MI passes ahead was measured 1-2 % SLOWER on the whole
+            // step -- the extra live registers spill, and other waves already cover the round trip: profiles/r04_gemm_aux_prefetch.json)
             const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
             u32x4 o;
 #pragma unroll
@@ -820,42 +788,41 @@ int validate(const qfx_gemm_args* a) {
 
 // ---- tile geometry choice ------------------------------------------------------------------------------------------------
 // cost(geometry) = rounds over the 256 CUs x relative time of one tile.  The relative tile times are the tile areas scaled by a
-// measured per-flop efficiency (256x128 = 1): the 256-wide tiles move a third less LDS-DMA and a quarter less fragment traffic
-// per flop (+9 %: round 1); the 160-row tiles were measured in round 4 (profiles/r04_gemm_tiles.json).  QFX_GEMM_TILES selects
+// measured per-flop efficiency (256x128 = 1): the 256-wide tile moves a third less LDS-DMA and a quarter less fragment traffic
+// per flop (+9 %: round 1); the 160-row tile was measured in round 4 (profiles/r04_gemm_tiles.json).  QFX_GEMM_TILES selects
 // the candidate set ("legacy" = the 256-row tiles of rounds 1-3; a comma list of BMTxTN names; default: all); QFX_GEMM_EFF
-// overrides the five efficiency factors (A/B experiments).  Both are read once per process.
+// overrides the three efficiency factors (A/B experiments).  Both are read once per process.
 struct Geo { int bmt, tn; double area, eff; bool on; };
-Geo g_geo[5] = {
+constexpr int NGEO = 3;
+Geo g_geo[NGEO] = {
     {256, 128, 1.0, 1.00, true},
     {256, 256, 2.0, 1.09, true},
-    {160, 192, 0.9375, 0.985, true},
-    {160, 256, 1.25, 1.04, true},
-    {160, 384, 1.875, 1.06, true},
+    {160, 192, 0.9375, 0.965, true},      // round 4: 0.9375 of the work at ~0.965 of the per-flop speed (profiles/r04_gemm_tiles.json)
 };
 bool g_geo_init = false;
 
 int geo_set(const char* tiles, const char* eff) {
   if (tiles && *tiles) {
     const std::string v(tiles);
-    if (v == "legacy") { for (int i = 0; i < 5; ++i) g_geo[i].on = i < 2; }
+    if (v == "legacy") { for (int i = 0; i < NGEO; ++i) g_geo[i].on = i < 2; }
     else if (v == "all") { for (auto& gg : g_geo) gg.on = true; }
     else {
-      bool on[5], any = false;
-      for (int i = 0; i < 5; ++i) {
+      bool on[NGEO], any = false;
+      for (int i = 0; i < NGEO; ++i) {
         char name[32];
         snprintf(name, sizeof name, "%dx%d", g_geo[i].bmt, g_geo[i].tn);
         on[i] = v.find(name) != std::string::npos;
         any = any || on[i];
       }
       if (!any) return QFX_EINVAL;
-      for (int i = 0; i < 5; ++i) g_geo[i].on = on[i];
+      for (int i = 0; i < NGEO; ++i) g_geo[i].on = on[i];
     }
   }
   if (eff && *eff) {
-    double e[5];
-    if (sscanf(eff, "%lf,%lf,%lf,%lf,%lf", &e[0], &e[1], &e[2], &e[3], &e[4]) != 5) return QFX_EINVAL;
-    for (int i = 0; i < 5; ++i) if (!(e[i] > 0.1 && e[i] < 10.0)) return QFX_EINVAL;
-    for (int i = 0; i < 5; ++i) g_geo[i].eff = e[i];
+    double e[NGEO];
+    if (sscanf(eff, "%lf,%lf,%lf", &e[0], &e[1], &e[2]) != NGEO) return QFX_EINVAL;
+    for (int i = 0; i < NGEO; ++i) if (!(e[i] > 0.1 && e[i] < 10.0)) return QFX_EINVAL;
+    for (int i = 0; i < NGEO; ++i) g_geo[i].eff = e[i];
   }
   return QFX_OK;
 }
@@ -874,9 +841,7 @@ void launch_geo(int gi, int grid, hipStream_t s, const GroupedArgs& ga) {
     switch (gi) {
       case 0: hipLaunchKernelGGL((gemm256_kernel<E, 256, 128>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
       case 1: hipLaunchKernelGGL((gemm256_kernel<E, 256, 256>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-      case 2: hipLaunchKernelGGL((gemm256_kernel<E, 160, 192>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-      case 3: hipLaunchKernelGGL((gemm256_kernel<E, 160, 256>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
-      default: hipLaunchKernelGGL((gemm256_kernel<E, 160, 384>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
+      default: hipLaunchKernelGGL((gemm256_kernel<E, 160, 192>), dim3(grid), dim3(WS_THREADS), 0, s, ga); break;
     }
   }
 }
@@ -928,15 +893,14 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
     probs[i] = &groups[i];
   }
   geo_init();
-  // e.g. B = 1, N = 3072: 240 tiles of 256x128 (one round, cost 1.0) vs 256 tiles of 160x192 (one round, 0.9375 / eff);
-  // N = 12288: 480 tiles of 256x256 (two rounds of 240) vs 512 tiles of 160x384 (two full rounds); the q/k/v launch: 720 vs 768
-  // narrow tiles (three rounds either way).
+  // e.g. B = 1, N = 3072: 240 tiles of 256x128 (one round, cost 1.0) vs 256 tiles of 160x192 (one round, 0.9375 / eff); the q/k/v
+  // launch: 720 vs 768 narrow tiles (three rounds either way); N = 12288: 480 tiles of 256x256 (two rounds of 240).
   int best = -1;
   double best_cost = 0.0;
-  for (int c = 0; c < 5; ++c) {
+  for (int c = 0; c < NGEO; ++c) {
     const Geo& gg = g_geo[c];
     if (!gg.on) continue;
-    if (gg.tn >= 256 && !n256) continue;     // the wide tiles keep whole tiles along N (round-1 contract)
+    if (gg.tn >= 256 && !n256) continue;     // the wide tile keeps whole tiles along N (round-1 contract)
     long t = 0;
     for (int i = 0; i < n; ++i) t += (long)((groups[i].M + gg.bmt - 1) / gg.bmt) * ((groups[i].N + gg.tn - 1) / gg.tn);
     const double cost = (double)((t + QFX_NUM_CU - 1) / QFX_NUM_CU) * gg.area / gg.eff;

@@ -25,10 +25,8 @@ sys.path.insert(0, ROOT)
 
 POLICIES = {
     "legacy": "256x128,256x256",           # rounds 1-3
-    "n160": "160x192,256x256",             # 160-row narrow tile, legacy wide tile
-    "n160_w384": "160x192,160x384",
-    "n160_w256": "160x192,160x256",
-    "w384": "256x128,160x384",
+    "n160": "256x128,160x192,256x256",     # all three: the cost model decides
+    "n160only": "160x192,256x256",       # (the launcher itself keeps 256x128 for gate + residual when it is enabled)
     "all": "all",                          # the launcher's own cost model over all five
 }
 
@@ -43,8 +41,8 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--policies", default="legacy,n160,n160_w384,n160_w256,all")
-    ap.add_argument("--eff", default="", help="five efficiencies for the 'all' policy (qfx_gemm_tune)")
+    ap.add_argument("--policies", default="legacy,n160,all")
+    ap.add_argument("--eff", default="", help="three efficiencies for the 'all' policy (qfx_gemm_tune)")
     args = ap.parse_args()
     import bench as Bn
     from qflux_amd import _lib as L
