@@ -12,6 +12,33 @@ for p in (ROOT, os.path.join(ROOT, "qwen-image-finetune_amd"), os.path.join(ROOT
         sys.path.insert(0, p)
 
 BF = torch.bfloat16
+# Step-parity bars of the tiny-model drivers (HIP path vs the bf16 oracle), ~2x the maxima observed over the whole -m gpu suite
+# (gpurun_out/parity_observed.json of the round-4 run is quoted in DESIGN.md section 4).
+LOSS_BAR, PRED_BAR, GRAD_BAR = 2e-2, 2e-2, 4e-2
+
+
+_OBSERVED = {}
+
+
+def _observe(kind, res):
+    """Running maxima of what the step-parity drivers measured in this process (gpurun_out/parity_observed.json): the bars below are
+    ratcheted to ~2x these (VERDICT r3 weak #3)."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    path = os.path.join(d, "parity_observed.json")
+    if not _OBSERVED and os.path.exists(path):      # several processes (pytest, smoke) add to one file
+        try:
+            _OBSERVED.update(json.load(open(path)))
+        except Exception:  # noqa: BLE001
+            pass
+    o = _OBSERVED.setdefault(kind, dict(n=0, loss_rel=0.0, pred_rel=0.0, grad_rel_worst=0.0))
+    o["n"] += 1
+    for k in ("loss_rel", "pred_rel", "grad_rel_worst"):
+        if k in res and res[k] is not None:
+            o[k] = max(o[k], float(res[k]))
+    if os.path.isdir(d):
+        with open(path, "w") as f:
+            json.dump(_OBSERVED, f, indent=1)
 
 
 def relmax(a, b):
@@ -104,7 +131,8 @@ def run_tiny_step_parity(device="cuda:0", verbose=False, cfg=None, shapes=((1, 4
             if e > worst:
                 worst, worst_name = e, n
     res["grad_rel_worst"], res["grad_worst_name"], res["grads_nonzero"] = worst, worst_name, nz
-    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 2e-2 and worst < 4e-2 and nz == len(og) - dead)
+    _observe("qwen_tiny_step", res)
+    res["ok"] = bool(res["loss_rel"] < LOSS_BAR and res.get("pred_rel", 0.0) < PRED_BAR and worst < GRAD_BAR and nz == len(og) - dead)
     if verbose:
         print(res)
     return res
@@ -176,7 +204,8 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
             if e > worst:
                 worst, worst_name = e, n
     res["grad_rel_worst"], res["grad_worst_name"], res["n_lora"] = worst, worst_name, len(og)
-    res["ok"] = bool(res["loss_rel"] < 2e-2 and res.get("pred_rel", 0.0) < 2e-2 and worst < 4e-2 and bad == 0)
+    _observe("flux_tiny_step", res)
+    res["ok"] = bool(res["loss_rel"] < LOSS_BAR and res.get("pred_rel", 0.0) < PRED_BAR and worst < GRAD_BAR and bad == 0)
     if verbose:
         print(res)
     return res
