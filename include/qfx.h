@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QFX_ABI_VERSION 5
+#define QFX_ABI_VERSION 6
 
 #define QFX_OK 0
 #define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
@@ -134,6 +134,20 @@ typedef struct qfx_lora_down_args {
 } qfx_lora_down_args;
 
 int qfx_lora_down(const qfx_lora_down_args* args, void* stream);
+
+/* ABI 6: second half of a down projection fused into an attention epilogue (qfx_head_lora): U[m, j] = sum_h part[h][row(m)][j] in
+ * head order (deterministic), then exactly qfx_lora_down's outputs -- EXT[m, ...] = [U_hi | U_lo | U_hi] per group and the transposed
+ * split image Ut -- for the M compact rows of one stream (row(m) = the joint row, X-remap fields as in qfx_lora_down).  R = total
+ * columns (e.g. 3 * Rp for q | k | v with group_R = Rp).  Up to 2 problems (image + text stream) per launch. */
+typedef struct qfx_lora_head_reduce_args {
+  const float* part; int64_t part_hstride; int32_t ld_part; int32_t H;
+  int32_t M; int32_t R;
+  uint16_t* ext; int64_t ld_ext;
+  uint16_t* Ut_hi; uint16_t* Ut_lo; int64_t ld_ut;
+  int32_t group_R; int32_t group_stride;
+  int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off; int32_t reserved;
+} qfx_lora_head_reduce_args;
+int qfx_lora_head_reduce(const qfx_lora_head_reduce_args* list, int32_t n, void* stream);
 /* n <= QFX_MAX_BATCH independent problems of the same R in ONE launch (e.g. the q, k and v down projections of a block's
  * backward): every separate launch of these one-round-trip kernels costs a dispatch gap plus its own latency floor. */
 #define QFX_MAX_BATCH 8
@@ -170,6 +184,11 @@ typedef struct qfx_lora_pack_args {
   uint16_t* We; int64_t ld_we;                       /* [N,Kext] */
   uint16_t* WeT; int64_t ld_wet;                     /* [K,Kext] */
   int32_t Rp; int32_t Kext;
+  /* ABI 6 (optional, NULL = off): head-fragment images for qfx_head_lora.  A_hl: (A_hi, A_lo) of an adapter whose INPUT is a
+   * [*, H*hl_dh] attention output; Bt_hl: (Bt_hi, Bt_lo) of an adapter whose OUTPUT is a q / k / v row.  Element (row j, column
+   * h*hl_dh + 32 ks + 16 db + 4 g + r) of the hi (sel = 0) / lo (sel = 1) split sits at
+   *   ((((h * Rp/16 + j/16) * hl_dh/32 + ks) * 2 + sel) * 64 + 16 g + j%16) * 8 + 4 db + r        (bf16 elements). */
+  uint16_t* A_hl; uint16_t* Bt_hl; int32_t hl_dh; int32_t reserved;
 } qfx_lora_pack_args;
 
 /* descs: DEVICE array of n descriptors (one per LoRA target); one launch packs them all. */
@@ -338,6 +357,21 @@ int qfx_transpose_heads(const uint16_t* in, int64_t ld_in, uint16_t* out, int32_
  * copy is read any more; the fields keep the struct layout stable and may be NULL.
  * O [B,S,H*dh] (row stride ldo). lse2 [B,H,S_pad] fp32 = log2-domain logsumexp. key_mask [B,S] fp32 additive or NULL.
  */
+/* ABI 6: a rank-r LoRA down projection fused into an attention epilogue (north_star: "LoRA side branches ... inside the kernels").
+ * The kernel that holds a row of X = O / d(pre-norm q) / d(pre-norm k) / dV in registers also emits, per head h,
+ *     part[h * part_hstride + row * ld_part + c0 + j] = sum_{n < dh} X[row, h*dh + n] * (W_hi + W_lo)[j, h*dh + n]      (j < R, fp32)
+ * with row = the JOINT row b*S + s; qfx_lora_head_reduce adds the H slabs in a fixed order and writes the bf16 images
+ * qfx_lora_down would have written (peft: lora_A(x) in the forward, dY * B in the backward; base_trainer.py:929-941).
+ * w_pk = the adapter weight in HEAD-FRAGMENT order (qfx_lora_pack's A_hl / Bt_hl images: the MFMA operand of lane l for head h, 16-row
+ * group nf, 32-column step ks is 16 contiguous bytes, hi and lo split interleaved per step -- fully coalesced 1 KiB wave loads; the
+ * row-major split images cost 7 us per launch in 8-byte pieces at row stride); index [0] applies to rows s >= T (image stream), [1]
+ * to rows s < T (text stream); NULL = that stream has no adapter on this linear.  Needs T % 16 == 0, R in {16, 32}, part 16-byte
+ * aligned with ld_part % 4 == 0 and c0 % 4 == 0.  part == NULL: off. */
+typedef struct qfx_head_lora {
+  const uint16_t* w_pk[2];
+  float* part; int64_t part_hstride; int32_t ld_part; int32_t c0; int32_t R; int32_t reserved;
+} qfx_head_lora;
+
 typedef struct qfx_attn_args {
   const uint16_t* Q; const uint16_t* K; const uint16_t* V; int64_t ldq; int64_t ldk; int64_t ldv;
   const uint16_t* Qt; const uint16_t* Kt; const uint16_t* Vt;   /* reserved (unused), may be NULL */
@@ -355,6 +389,9 @@ typedef struct qfx_attn_args {
   const uint16_t* qk_saved; int64_t ld_saved; const float* rope; int64_t rope_bstride;
   const uint16_t* wq_txt; const uint16_t* wk_txt; const uint16_t* wq_img; const uint16_t* wk_img;
   int32_t T; int32_t norm_flags; float norm_eps;
+  /* ABI 6 (zero = off): hl[0] X = O in qfx_attn_fwd; hl[1] X = d(pre-norm q) in qfx_attn_bwd_dq; hl[2] X = d(pre-norm k), hl[3] X = dV
+   * in qfx_attn_bwd_dkv (the backward slots need qk_saved != NULL). */
+  qfx_head_lora hl[4];
 } qfx_attn_args;
 
 int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,V -> O,lse2 */

@@ -94,6 +94,39 @@ __device__ __forceinline__ void attn_block_coord(int nx, int H, int& xb, int& h,
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Rank-r down projection of ONE 16-row fragment held in the accumulator layout (ABI 6, qfx_head_lora): lane (g, li) owns row li,
+// x[d] = the packed bf16 pairs of columns 16 d + 4 g + {0,1 | 2,3} of this head's dh columns -- exactly what the epilogues store.
+//   part[h][row][c0 + j] = sum_n x[row][n] * (W_hi + W_lo)[j][h*dh + n]
+// as D[i = j][col = row] = W_frag[i][k] X_frag[k][col] on the MFMA: the k-slots of a 32-deep step are the lane's own eight values
+// of two adjacent d blocks (k = 8 g + r -> column 16 (2 ks) + 4 g + r, k = 8 g + 4 + r -> 16 (2 ks + 1) + 4 g + r); the weight
+// operand comes from qfx_lora_pack's head-fragment image in exactly that order: one 16-byte load per lane, 1 KiB per wave.
+// `frow` = the fragment's first row within its sample (a multiple of 16; with T % 16 == 0 a fragment is all text or all image).
+template <int DH>
+__device__ __forceinline__ void head_lora_frag(const qfx_head_lora& hl, int h, int T, int frow, int64_t jrow, bool row_ok,
+                                               const u32x2 (&x)[DH / 16], int g, int li) {
+  if (hl.part == nullptr) return;                                  // block-uniform
+  const bf16_t* wp = hl.w_pk[frow >= T ? 0 : 1];                   // wave-uniform
+  if (wp == nullptr) return;
+  constexpr int KS = DH / 32;
+  const int nfs = hl.R >> 4;
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+    if (nf >= nfs) break;
+    const bf16_t* wf = wp + ((int64_t)(h * nfs + nf) * KS * 2 * 64 + 16 * g + li) * 8;
+    u32x4 ah[KS], al[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { ah[ks] = *(const u32x4*)(wf + (ks * 2) * 512); al[ks] = *(const u32x4*)(wf + (ks * 2 + 1) * 512); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 bx = {x[2 * ks][0], x[2 * ks][1], x[2 * ks + 1][0], x[2 * ks + 1][1]};
+      acc = MFMA(__builtin_bit_cast(bf16x8, ah[ks]), __builtin_bit_cast(bf16x8, bx), acc);
+      acc = MFMA(__builtin_bit_cast(bf16x8, al[ks]), __builtin_bit_cast(bf16x8, bx), acc);
+    }
+    if (row_ok) *(f32x4*)(hl.part + (int64_t)h * hl.part_hstride + jrow * hl.ld_part + hl.c0 + nf * 16 + 4 * g) = acc;
+  }
+}
+
 // =============================================================================================
 // forward: block = 128 queries (4 waves x 32), loop over 64-key tiles, K/V^T double-buffered in LDS
 // NW = waves per block (32 queries each).  8 waves / 256 queries, one block per CU, is used when it quantises better onto the
@@ -279,18 +312,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const int q = q0 + f * 16 + li;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    u32x2 u[DF];
+#pragma unroll
+    for (int d = 0; d < DF; ++d) {
+      u[d][0] = pack2bf(oacc[d][f][0] * inv, oacc[d][f][1] * inv);
+      u[d][1] = pack2bf(oacc[d][f][2] * inv, oacc[d][f][3] * inv);
+    }
     if (q < S) {
-      const float inv = l > 0.f ? 1.0f / l : 0.f;
       bf16_t* op = a.O + ((int64_t)b * S + q) * a.ldo + h * DH + 4 * g;
 #pragma unroll
-      for (int d = 0; d < DF; ++d) {
-        u32x2 u;
-        u[0] = pack2bf(oacc[d][f][0] * inv, oacc[d][f][1] * inv);
-        u[1] = pack2bf(oacc[d][f][2] * inv, oacc[d][f][3] * inv);
-        *(u32x2*)(op + d * 16) = u;
-      }
+      for (int d = 0; d < DF; ++d) *(u32x2*)(op + d * 16) = u[d];
       if (g == 0) a.lse2[((int64_t)b * a.H + h) * a.S_pad + q] = mrow[f] + log2f(l);
     }
+    // rank-r down projection of the out-projection adapter on the rows just produced (ABI 6)
+    if (q0 + f * 16 < S) head_lora_frag<DH>(a.hl[0], h, a.T, q0 + f * 16, (int64_t)b * S + (q < S ? q : S - 1), q < S, u, g, li);
   }
 }
 
@@ -521,6 +557,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_kernel(c
 #pragma unroll
         for (int d = 0; d < DF; ++d) *(u32x2*)(op + d * 16) = u[d];
       }
+      if (q0 + f * 16 < S) head_lora_frag<DH>(a.hl[1], h, a.T, q0 + f * 16, (int64_t)b * S + qc, q < S, u, g, li);   // v_q = d(pre-norm q) (s B_q)^T
     } else if (q < S) {
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
@@ -736,6 +773,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
 #pragma unroll
         for (int d = 0; d < DF; ++d) *(u32x2*)(kp + d * 16) = u[d];
       }
+      if (key0 + f * 16 < S) {      // fragment-uniform: v_k = d(pre-norm k) (s B_k)^T, v_v = dV (s B_v)^T (ABI 6)
+        head_lora_frag<DH>(a.hl[2], h, a.T, key0 + f * 16, (int64_t)b * S + mykey[f], keyok[f], u, g, li);
+        if (a.hl[3].part != nullptr) {
+#pragma unroll
+          for (int d = 0; d < DF; ++d) { u[d][0] = pack2bf(dv[d][f][0], dv[d][f][1]); u[d][1] = pack2bf(dv[d][f][2], dv[d][f][3]); }
+          head_lora_frag<DH>(a.hl[3], h, a.T, key0 + f * 16, (int64_t)b * S + mykey[f], keyok[f], u, g, li);
+        }
+      }
     }
     if (!keyok[f]) continue;
 #pragma unroll
@@ -770,12 +815,29 @@ int check_common(const qfx_attn_args* a) {
   return QFX_OK;
 }
 
+// ABI 6: fused rank-r down projections of the slots [first, last] (see qfx_head_lora)
+int check_head_lora(const qfx_attn_args* a, int first, int last) {
+  for (int i = first; i <= last; ++i) {
+    const qfx_head_lora& hl = a->hl[i];
+    if (!hl.part) continue;
+    if (hl.R != 16 && hl.R != 32) return QFX_EUNSUPPORTED;
+    if ((a->T % 16) || a->T < 0 || (hl.ld_part % 4) || (hl.c0 % 4) || hl.c0 < 0 || hl.c0 + hl.R > hl.ld_part ||
+        ((uintptr_t)hl.part % 16) || hl.part_hstride < (int64_t)a->B * a->S * hl.ld_part)
+      return QFX_EINVAL;
+    if (i > 0 && !a->qk_saved) return QFX_EINVAL;        // the backward slots project d(PRE-norm q / k)
+    for (int s = 0; s < 2; ++s)
+      if ((uintptr_t)hl.w_pk[s] % 16) return QFX_EINVAL;
+  }
+  return QFX_OK;
+}
+
 }  // namespace
 
 extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   int rc = check_common(a);
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return QFX_EINVAL;
+  if ((rc = check_head_lora(a, 0, 0))) return rc;
   const int nw = pick_waves(a);
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
   if (a->dh == 128) {
@@ -808,6 +870,7 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   if (a->qk_saved && (!a->rope || !a->wq_txt || !a->wq_img || (a->ld_saved % 4) || a->T < 0)) return QFX_EINVAL;
   if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
+  if ((rc = check_head_lora(a, 1, 1))) return rc;
   const int nw = 4;   /* see pick_waves */
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
   if (a->dh == 128) {
@@ -827,6 +890,7 @@ extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
   if (a->qk_saved && (!a->rope || !a->wk_txt || !a->wk_img || (a->ld_saved % 4) || a->T < 0)) return QFX_EINVAL;
   if (!a->Q || !a->K || !a->V || !a->dO || !a->lse2 || !a->dsum || !a->dK || !a->dV) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->lddo % 8) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
+  if ((rc = check_head_lora(a, 2, 3))) return rc;
   dim3 grid(((a->S + 255) / 256) * a->H * a->B);
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(512), 0, (hipStream_t)stream, *a);

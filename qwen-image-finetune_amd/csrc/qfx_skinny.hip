@@ -436,6 +436,47 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second half of a down projection fused into an attention epilogue (ABI 6, qfx_head_lora): U[m, j] = sum over the H per-head slabs
+// in head order (fixed order: deterministic), then qfx_lora_down's outputs -- the K-extension image [U_hi | U_lo | U_hi] per group
+// and the transposed hi / lo split.  One thread per (row, column); a block covers 256 / R rows.
+struct HeadReduceBatch { qfx_lora_head_reduce_args a[2]; int start[3]; int n; };
+
+__global__ __launch_bounds__(256) void lora_head_reduce_kernel(const HeadReduceBatch kb) {
+  const int pi = (kb.n > 1 && (int)blockIdx.x >= kb.start[1]) ? 1 : 0;
+  const qfx_lora_head_reduce_args& p = pi ? kb.a[1] : kb.a[0];
+  const int R = p.R;
+  const int rpb_ = 256 / R;                           // rows per block (R in {16, 32, 48, 64, 96}: 16 .. 2 rows)
+  const int tid = threadIdx.x;
+  if (tid >= rpb_ * R) return;
+  const int m = ((int)blockIdx.x - kb.start[pi]) * rpb_ + tid / R, j = tid % R;
+  if (m >= p.M) return;
+  const int64_t jrow = remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off);
+  const float* src = p.part + jrow * p.ld_part + j;
+  // eight slabs requested at a time (independent loads), added in head order: a one-load-per-iteration loop is H dependent L2
+  // round trips (24 us per launch at H = 24 -- more than the qfx_lora_down launch this replaces)
+  float v = 0.f;
+  for (int h0 = 0; h0 < p.H; h0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = h0 + i < p.H ? src[(int64_t)(h0 + i) * p.part_hstride] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v += t[i];
+  }
+  const bf16_t hi = f2bf(v);
+  const bf16_t lo = f2bf(v - bf2f(hi));
+  if (p.ext) {
+    bf16_t* e0 = p.ext + (int64_t)m * p.ld_ext + (j / p.group_R) * p.group_stride + (j % p.group_R);
+    e0[0] = hi;
+    e0[p.group_R] = lo;
+    e0[2 * p.group_R] = hi;
+  }
+  if (p.Ut_hi) {
+    p.Ut_hi[(int64_t)j * p.ld_ut + m] = hi;
+    p.Ut_lo[(int64_t)j * p.ld_ut + m] = lo;
+  }
+}
+
 // debug: dump the lane mapping of ds_read_b64_tr_b16 (lane l supplies elements 4l..4l+3 of `in`)
 __global__ void tr_probe_kernel(const bf16_t* in, bf16_t* out) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[256];
@@ -456,6 +497,11 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const qfx_lora_pack_args
   const int stride = gridDim.x * blockDim.x;
   const int t0 = blockIdx.x * blockDim.x + threadIdx.x;
   const int Rp = d.Rp, Kext = d.Kext;
+  // head-fragment images (ABI 6): position of column c's element of row j -- see qfx_lora_pack_args
+  auto hl_off = [&](int c, int j, int sel) {
+    const int h = c / d.hl_dh, dd = c - h * d.hl_dh, ks = dd >> 5, db = (dd >> 4) & 1, g = (dd >> 2) & 3, r = dd & 3;
+    return ((((int64_t)(h * (Rp >> 4) + (j >> 4)) * (d.hl_dh >> 5) + ks) * 2 + sel) * 64 + 16 * g + (j & 15)) * 8 + 4 * db + r;
+  };
   for (int k = t0; k < d.K; k += stride) {
     bf16_t* wt = d.WeT + (int64_t)k * d.ld_wet;
     for (int j0 = 0; j0 < Rp; j0 += 8) {
@@ -470,6 +516,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const qfx_lora_pack_args
           const bf16_t hi = f2bf(a), lo = f2bf(a - bf2f(hi));
           d.A_hi[(int64_t)j * d.ld_a + k] = hi;
           d.A_lo[(int64_t)j * d.ld_a + k] = lo;
+          if (d.A_hl) { d.A_hl[hl_off(k, j, 0)] = hi; d.A_hl[hl_off(k, j, 1)] = lo; }
           ph |= (uint32_t)hi << (16 * e); pl |= (uint32_t)lo << (16 * e);
         }
         vh[q] = ph; vl[q] = pl;
@@ -493,6 +540,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const qfx_lora_pack_args
           const bf16_t hi = f2bf(b), lo = f2bf(b - bf2f(hi));
           d.Bt_hi[(int64_t)j * d.ld_bt + n] = hi;
           d.Bt_lo[(int64_t)j * d.ld_bt + n] = lo;
+          if (d.Bt_hl) { d.Bt_hl[hl_off(n, j, 0)] = hi; d.Bt_hl[hl_off(n, j, 1)] = lo; }
           ph |= (uint32_t)hi << (16 * e); pl |= (uint32_t)lo << (16 * e);
         }
         vh[q] = ph; vl[q] = pl;
@@ -592,6 +640,28 @@ extern "C" int qfx_ln_down_fwd(const qfx_ln_down_args* list, int32_t n, void* st
     case 2: hipLaunchKernelGGL(ln_down_kernel<2>, dim3(blocks), dim3(512), 0, s, b); break;
     default: hipLaunchKernelGGL(ln_down_kernel<3>, dim3(blocks), dim3(512), 0, s, b); break;
   }
+  QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_lora_head_reduce(const qfx_lora_head_reduce_args* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 2) return QFX_EINVAL;
+  HeadReduceBatch b;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const qfx_lora_head_reduce_args& a = list[i];
+    if (!a.part || a.H <= 0 || a.M <= 0 || a.R <= 0 || a.R > 256 || (a.R % 16) || a.ld_part < a.R || a.group_R <= 0 || (a.R % a.group_R) ||
+        a.rows_per_batch <= 0 || (!a.ext && !a.Ut_hi) || ((a.Ut_hi == nullptr) != (a.Ut_lo == nullptr)))
+      return QFX_EINVAL;
+    b.a[i] = a;
+    b.start[i] = blocks;
+    const int rpb_ = 256 / a.R;
+    blocks += (a.M + rpb_ - 1) / rpb_;
+  }
+  for (int i = n; i <= 2; ++i) b.start[i] = blocks;
+  if (n == 1) b.a[1] = list[0];
+  b.n = n;
+  hipLaunchKernelGGL(lora_head_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
   QFX_CHECK_LAUNCH();
   return QFX_OK;
 }

@@ -97,6 +97,7 @@ class LoraPackArgs(C.Structure):
         ("We", C.c_void_p), ("ld_we", C.c_int64),
         ("WeT", C.c_void_p), ("ld_wet", C.c_int64),
         ("Rp", C.c_int32), ("Kext", C.c_int32),
+        ("A_hl", C.c_void_p), ("Bt_hl", C.c_void_p), ("hl_dh", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -119,6 +120,21 @@ class ProdigyArgs(C.Structure):
 PRODIGY_STATE = 12
 
 
+class HeadLora(C.Structure):
+    _fields_ = [("w_pk", C.c_void_p * 2),
+                ("part", C.c_void_p), ("part_hstride", C.c_int64), ("ld_part", C.c_int32), ("c0", C.c_int32), ("R", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class LoraHeadReduceArgs(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("part_hstride", C.c_int64), ("ld_part", C.c_int32), ("H", C.c_int32),
+                ("M", C.c_int32), ("R", C.c_int32),
+                ("ext", C.c_void_p), ("ld_ext", C.c_int64),
+                ("Ut_hi", C.c_void_p), ("Ut_lo", C.c_void_p), ("ld_ut", C.c_int64),
+                ("group_R", C.c_int32), ("group_stride", C.c_int32),
+                ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32), ("reserved", C.c_int32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64),
@@ -132,10 +148,11 @@ class AttnArgs(C.Structure):
         ("qk_saved", C.c_void_p), ("ld_saved", C.c_int64), ("rope", C.c_void_p), ("rope_bstride", C.c_int64),
         ("wq_txt", C.c_void_p), ("wk_txt", C.c_void_p), ("wq_img", C.c_void_p), ("wk_img", C.c_void_p),
         ("T", C.c_int32), ("norm_flags", C.c_int32), ("norm_eps", C.c_float),
+        ("hl", HeadLora * 4),
     ]
 
 
-ABI_VERSION = 5        # QFX_ABI_VERSION
+ABI_VERSION = 6        # QFX_ABI_VERSION
 MAX_BATCH = 8          # QFX_MAX_BATCH
 MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
@@ -189,6 +206,7 @@ SYMBOLS = {
     "qfx_stream_destroy": (C.c_int, [_vp]),
     "qfx_debug_where": (C.c_int, [_vp, _i32, _vp]),
     "qfx_gemm_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "qfx_lora_head_reduce": (C.c_int, [C.POINTER(LoraHeadReduceArgs), _i32, _vp]),
     "qfx_debug_tr_read": (C.c_int, [_vp, _vp, _vp]),
     "qfx_abi_version": (C.c_int, []),
     "qfx_build_arch": (C.c_char_p, []),
@@ -220,3 +238,22 @@ class QfxError(RuntimeError):
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise QfxError(f"{what} failed with code {rc}" + (" (HIP error %d)" % (-rc - 1000) if rc <= -1000 else ""))
+
+
+def head_fragment_image(hi, lo, dh):
+    """The head-fragment order of a [Rp, H*dh] bf16 hi/lo split (include/qfx.h, qfx_lora_pack_args.A_hl / Bt_hl): what
+    qfx_lora_pack writes for the attention epilogues (qfx_head_lora.w_pk).  Layout statement for tests and tools -- the training
+    path's images come from qfx_lora_pack."""
+    import torch
+    Rp, C_ = hi.shape
+    assert Rp % 16 == 0 and dh % 32 == 0 and C_ % dh == 0
+    j = torch.arange(Rp, device=hi.device).view(Rp, 1)
+    c = torch.arange(C_, device=hi.device).view(1, C_)
+    h, dd = c // dh, c % dh
+    ks, db, g, r = dd // 32, (dd // 16) % 2, (dd // 4) % 4, dd % 4
+    base = ((h * (Rp // 16) + j // 16) * (dh // 32) + ks) * 2
+    img = torch.zeros(2 * Rp * C_, dtype=hi.dtype, device=hi.device)
+    for sel, t in ((0, hi), (1, lo)):
+        off = ((base + sel) * 64 + 16 * g + j % 16) * 8 + 4 * db + r
+        img[off.reshape(-1)] = t.reshape(-1)
+    return img

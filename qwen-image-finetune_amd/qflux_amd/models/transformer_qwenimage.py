@@ -98,7 +98,7 @@ class _Cfg:
 # prepared device-side weights
 # ----------------------------------------------------------------------------------------------
 class _LoraW:
-    __slots__ = ("mod", "r", "Rp", "Kext", "scale", "A_hi", "A_lo", "Bt_hi", "Bt_lo", "We", "WeT", "gA", "gB")
+    __slots__ = ("mod", "r", "Rp", "Kext", "scale", "A_hi", "A_lo", "Bt_hi", "Bt_lo", "We", "WeT", "gA", "gB", "A_hl", "Bt_hl", "hl_dh")
 
 
 class _LinW:
@@ -509,7 +509,7 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
     def _prep_head_lora(self, P, descs):
         return max(self._prep_site_lora(P[key], descs) for key in self._HEAD_SITES.values())
 
-    def _prep_qkv_lora(self, w, prefix, mods, descs, WeT=None):
+    def _prep_qkv_lora(self, w, prefix, mods, descs, WeT=None, hl=None):
         """LoRA operand buffers of a q/k/v projection group sharing one input: concatenated A_hi/A_lo [3Rp,D] (one fused
         down-projection) and WeT [D, 3*Kext] (one K-extension of the dX GEMM).  WeT may be a column slice of a bigger B2."""
         dev, D = self.device, self.inner_dim
@@ -531,7 +531,7 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
             if not isinstance(m, QfxLoraLinear):
                 continue
             lo = self._make_lora(m, Rp, Kext, A_hi[sec * Rp:(sec + 1) * Rp], A_lo[sec * Rp:(sec + 1) * Rp],
-                                 WeT[:, sec * Kext:(sec + 1) * Kext], dev)
+                                 WeT[:, sec * Kext:(sec + 1) * Kext], dev, hl=hl)
             lw.lora = lo
             descs.append(self._pack_desc(lo))
             md = max(md, lw.N, lw.K)
@@ -540,8 +540,10 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
     def _prep_double_lora(self, w, a, descs):
         dev = self.device
         md = 1
+        # head-fragment weight images for the attention epilogues' rank-r projections (qfx_head_lora, ABI 6)
+        hl = os.environ.get("QFX_FUSE_HEAD_LORA", "1") != "0" and self.config.attention_head_dim % 32 == 0
         for s, names in (("img", ("to_q", "to_k", "to_v")), ("txt", ("add_q_proj", "add_k_proj", "add_v_proj"))):
-            md = max(md, self._prep_qkv_lora(w, s + ".", [getattr(a, n) for n in names], descs))
+            md = max(md, self._prep_qkv_lora(w, s + ".", [getattr(a, n) for n in names], descs, hl="Bt" if hl else None))
         for key in ("img.o", "txt.o", "img.fc1", "img.fc2", "txt.fc1", "txt.fc2"):
             m = w[key].mod
             if isinstance(m, QfxLoraLinear):
@@ -550,13 +552,13 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
                 lw = w[key]
                 lo = self._make_lora(m, Rp, Kext, torch.zeros(Rp, lw.K, dtype=BF, device=dev),
                                      torch.zeros(Rp, lw.K, dtype=BF, device=dev),
-                                     torch.zeros(lw.K, Kext, dtype=BF, device=dev), dev)
+                                     torch.zeros(lw.K, Kext, dtype=BF, device=dev), dev, hl="A" if (hl and key.endswith(".o")) else None)
                 lw.lora = lo
                 descs.append(self._pack_desc(lo))
                 md = max(md, lw.N, lw.K)
         return md
 
-    def _make_lora(self, m: QfxLoraLinear, Rp, Kext, A_hi, A_lo, WeT, dev):
+    def _make_lora(self, m: QfxLoraLinear, Rp, Kext, A_hi, A_lo, WeT, dev, hl=None):
         lo = _LoraW()
         name = m.active_adapter
         lo.mod, lo.r, lo.Rp, lo.Kext, lo.scale = m, m.r[name], Rp, Kext, m.scaling[name]
@@ -565,6 +567,9 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         lo.Bt_hi = torch.zeros(Rp, N, dtype=BF, device=dev)
         lo.Bt_lo = torch.zeros(Rp, N, dtype=BF, device=dev)
         lo.We = torch.zeros(N, Kext, dtype=BF, device=dev)
+        lo.A_hl = torch.zeros(2 * Rp * K, dtype=BF, device=dev) if hl == "A" else None
+        lo.Bt_hl = torch.zeros(2 * Rp * N, dtype=BF, device=dev) if hl == "Bt" else None
+        lo.hl_dh = self.config.attention_head_dim
         st = self._lora
         oa, ob = st.offset_of(m.A), st.offset_of(m.B)
         lo.gA = st.gflat[oa:oa + m.A.numel()]
@@ -582,6 +587,9 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         d.We, d.ld_we = lo.We.data_ptr(), lo.We.stride(0)
         d.WeT, d.ld_wet = lo.WeT.data_ptr(), lo.WeT.stride(0)
         d.Rp, d.Kext = lo.Rp, lo.Kext
+        d.A_hl = lo.A_hl.data_ptr() if lo.A_hl is not None else None
+        d.Bt_hl = lo.Bt_hl.data_ptr() if lo.Bt_hl is not None else None
+        d.hl_dh = lo.hl_dh
         return d
 
     def refresh_lora_operands(self):
@@ -756,6 +764,62 @@ class _QwenPlan:
         a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = _ptr(nq_t), _ptr(nk_t), _ptr(nq_i), _ptr(nk_i)
         a.T, a.norm_flags, a.norm_eps = self.T, norm_flags & 1, eps
 
+    def _head_lora_slots(self, a, w, live):
+        """Fill the qfx_head_lora slots of a block's attention arguments (forward slot 0: out-projection adapter; backward slots
+        1-3: q / k / v adapters, which need the fused QK-norm backward).  Returns {stream: H} for the streams whose out-projection
+        down projection now rides in qfx_attn_fwd; the backward streams are recorded in a._hl_qkv."""
+        a._hl_qkv = {}
+        if not getattr(self, "head_lora", False):
+            return {}
+        A, B, S, H = self.A, self.B, self.S, self.H
+        out = {}
+        los = {s: w[s + ".o"].lora for s in live}
+        rps = {lo.Rp for lo in los.values() if lo is not None}
+        if len(rps) == 1:
+            Rp = rps.pop()
+            hl = a.hl[0]
+            hl.part, hl.part_hstride, hl.ld_part, hl.c0, hl.R = _ptr(A["hl_o"]), B * S * A["hl_o"].shape[2], A["hl_o"].shape[2], 0, Rp
+            for si, s in enumerate(("img", "txt")):
+                lo = los.get(s)
+                if lo is not None and lo.A_hl is not None:
+                    hl.w_pk[si] = _ptr(lo.A_hl)
+                    out[s] = H
+        if a.qk_saved:
+            grp = {s: w[s + ".qkv_lora"] for s in ("img", "txt")}
+            full = {s: g for s, g in grp.items() if g is not None and all(
+                w[s + ".qkv"][sec].lora is not None and w[s + ".qkv"][sec].lora.Bt_hl is not None for sec in range(3))}
+            rps = {g["Rp"] for g in full.values()}
+            if len(rps) == 1:
+                Rp = rps.pop()
+                ld = A["hl_qkv"].shape[2]
+                for sec in range(3):
+                    hl = a.hl[1 + sec]
+                    hl.part, hl.part_hstride, hl.ld_part, hl.c0, hl.R = _ptr(A["hl_qkv"]), B * S * ld, ld, sec * Rp, Rp
+                    for si, s in enumerate(("img", "txt")):
+                        if s in full:
+                            lo = w[s + ".qkv"][sec].lora
+                            hl.w_pk[si] = _ptr(lo.Bt_hl)
+                a._hl_qkv = {s: Rp for s in full}
+        return out
+
+    def _head_reduce_args(self, part, H, R, M, rpb, off, ext, Ut, group_R, group_stride):
+        r = L.LoraHeadReduceArgs()
+        r.part, r.part_hstride, r.ld_part, r.H = _ptr(part), part.shape[1] * part.shape[2], part.shape[2], H
+        r.M, r.R = M, R
+        r.ext, r.ld_ext = _ptr(ext), ext.stride(0)
+        r.Ut_hi, r.Ut_lo, r.ld_ut = _ptr(Ut[0]), _ptr(Ut[1]), Ut[0].stride(0)
+        r.group_R, r.group_stride = group_R, group_stride
+        r.rows_per_batch, r.x_batch_rows, r.x_row_off = rpb, self.S, off
+        return r
+
+    @staticmethod
+    def _flush_head_reduce(prog, pending):
+        if pending:
+            arr = (L.LoraHeadReduceArgs * len(pending))(*pending)
+            prog.keep.append(arr)
+            prog.c(lib.qfx_lora_head_reduce, arr, len(pending))
+            pending.clear()
+
     def _sb(self, name, par):
         """Scratch buffer `name` of block parity `par` (second copies exist only with side-stream gradient launches)."""
         return self.A[name + "#1"] if (par and self.side_grads) else self.A.get(name)   # v^T scratch exists only with adapters
@@ -845,6 +909,16 @@ class _QwenPlan:
                            for s in ("img", "txt")}
             A["Vt"] = {s: (buf(3 * rp_max, _ceil(rows[s], 128), zero=True), buf(3 * rp_max, _ceil(rows[s], 128), zero=True))
                        for s in ("img", "txt")}   # v^T hi/lo scratch (pad columns stay zero)
+        # Round 4 (ABI 6): the rank-r down projections whose input an attention kernel holds in registers -- u = ao A_o^T in the
+        # forward, v = d(pre-norm q | k) , dV times (sB)^T in the backward -- ride in that kernel's epilogue as per-head partial sums
+        # (qfx_head_lora) and a small reduce launch writes what qfx_lora_down wrote: 2 of the 3 qfx_lora_down launches per block go.
+        # Needs T % 16 == 0 (a 16-row fragment is all text or all image), rank <= 32, the bf16 trunk (the MX-FP8 trunk's down
+        # projections also quantise their input), and -- backward -- the QK-norm backward fused into the same epilogues.
+        self.head_lora = (self.has_lora and os.environ.get("QFX_FUSE_HEAD_LORA", "1") != "0" and self.T % 16 == 0 and 0 < rp_max <= 32
+                          and getattr(self.model, "_quant", None) is None)
+        if self.head_lora:
+            A["hl_o"] = buf(H, B * S, rp_max, dtype=F32, zero=True)
+            A["hl_qkv"] = buf(H, B * S, 3 * rp_max, dtype=F32, zero=True)
         A["dX"] = {s: [buf(rows[s], D), buf(rows[s], D)] for s in ("img", "txt")}
         A["dyg2"] = {s: buf(rows[s], D) for s in ("img", "txt")}
         A["dyg1"] = {s: buf(rows[s], D) for s in ("img", "txt")}
@@ -1321,16 +1395,23 @@ class _QwenPlan:
             a.dQ, a.dK, a.dV = _ptr(dq2[:, 0:]), _ptr(dq2[:, D:]), _ptr(dq2[:, 2 * D:])
             a.lddq = a.lddk = a.lddv = 3 * D
             self._fuse_qk_bwd(a, bb["sqk"], (nq_t, nk_t, nq_i, nk_i), norm_flags, eps)
-            self.attn_args.append(a)
-            p.c(lib.qfx_attn_fwd, C.byref(a))
             # the text stream of the last block never reaches the output (:661-663): dead compute, skipped
             live = [(s, sidx) for s, sidx in STREAMS if not (last and s == "txt")]
+            hl_o = self._head_lora_slots(a, w, [s for s, _ in live])
+            self.attn_args.append(a)
+            p.c(lib.qfx_attn_fwd, C.byref(a))
             groups = []
             dfo = []
+            dho = []
             for s, sidx in live:
                 lw = w[s + ".o"]
                 kw = {}
-                if lw.lora is not None:
+                if lw.lora is not None and s in hl_o:
+                    # u = ao A_o^T left the attention epilogue as per-head partial sums: reduce + pack (what qfx_lora_down wrote)
+                    dho.append(self._head_reduce_args(A["hl_o"], hl_o[s], lw.lora.Rp, rows[s], rpb[s], off[s], A["ext1"][s], bb["Uo." + s],
+                                                      lw.lora.Rp, 0))
+                    kw = dict(A2=A["ext1"][s], lda2=A["ext1"][s].stride(0), B2=lw.lora.We, ldb2=lw.lora.We.stride(0), K2=lw.lora.Kext)
+                elif lw.lora is not None:
                     # MX-FP8 trunk: the down projection reads every attention-output row of this stream anyway and leaves its
                     # MX-FP8 image for the out-projection GEMM
                     pq_ = self._preq_out(p, ao2, D, rows[s], D, "ao." + s, a_map=(S, off[s]))
@@ -1345,6 +1426,7 @@ class _QwenPlan:
                                           epi=L.EPI_GATE_RES, aux=x_in[s], ldaux=D, gate=mods[s][:, 2 * D:3 * D], gate_bs=6 * D,
                                           rpb=rpb[s], a_map=(S, off[s]), **kw))
             self._flush_batch(p, dfo, L.LoraDownArgs, lib.qfx_lora_down_batch)
+            self._flush_head_reduce(p, dho)
             self._gemm_group(p, groups)
             groups = []
             # feed-forward (+ LoRA on net.0.proj / net.2: the adapter's input is then kept per block instead of in scratch)
@@ -1544,6 +1626,7 @@ class _QwenPlan:
             # ---- q/k/v projection backward (+ LoRA), both streams in one launch
             groups = []
             dl = []   # the q/k/v down projections of both streams: one batched launch
+            dhq = []  # ... or, fused into the attention epilogues, their reduce + pack halves
             for s, sidx in STREAMS:
                 grp = w[s + ".qkv_lora"]
                 kw = {}
@@ -1557,16 +1640,21 @@ class _QwenPlan:
                     pq_ = None
                     if i > 0 and all(w[s + ".qkv"][sec].lora is not None for sec in range(3)):
                         pq_ = self._preq_out(p, dq2, 3 * D, rows[s], 3 * D, "dqkv." + s, a_map=(S, off[s]))
+                    hl_fused = s in getattr(a, "_hl_qkv", {})
+                    if hl_fused:     # v = d(pre-norm q | k), dV times (sB)^T left the attention epilogues as per-head partial sums
+                        dhq.append(self._head_reduce_args(A["hl_qkv"], H, 3 * Rp, rows[s], rpb[s], off[s], e3, (Vth[:3 * Rp], Vtl[:3 * Rp]),
+                                                          Rp, Kext))
                     for sec in range(3):
                         lw = w[s + ".qkv"][sec]
                         if lw.lora is None:
                             continue
                         lo = lw.lora
                         sl = slice(sec * Rp, (sec + 1) * Rp)
-                        self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=rows[s], K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo,
-                                   ldw=lo.Bt_hi.stride(0), R=Rp, Ut=(Vth[sl], Vtl[sl]), ext=e3[:, sec * Kext:],
-                                   ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]), defer=dl,
-                                   xq=None if pq_ is None else (_ptr(pq_[0]) + sec * D, _ptr(pq_[1]), 3 * D, rows[s], sec * D // 32))
+                        if not hl_fused:
+                            self._down(p, X=dq2[:, sec * D:], ldx=3 * D, M=rows[s], K=D, W_hi=lo.Bt_hi, W_lo=lo.Bt_lo,
+                                       ldw=lo.Bt_hi.stride(0), R=Rp, Ut=(Vth[sl], Vtl[sl]), ext=e3[:, sec * Kext:],
+                                       ld_ext=e3.stride(0), rpb=rpb[s], x_map=(S, off[s]), defer=dl,
+                                       xq=None if pq_ is None else (_ptr(pq_[0]) + sec * D, _ptr(pq_[1]), 3 * D, rows[s], sec * D // 32))
                         self._grad(p, Vt=(Uth[sl], Utl[sl]), R=Rp, r_valid=lo.r, X=dq2[:, sec * D:], ldx=3 * D,
                                    M=rows[s], K=D, G=lo.gB, g_sr=1, g_sc=lo.r, rpb=rpb[s], x_map=(S, off[s]), out_scale=lo.scale,
                                    defer=gl)
@@ -1585,6 +1673,7 @@ class _QwenPlan:
                     groups.append(self._gargs(A1=dq2, lda1=3 * D, B1=w[s + ".qkvT"], K1=3 * D, M=rows[s], N=D, C_=A["dxm"][s], ldc=D,
                                               rpb=rpb[s], a_map=(S, off[s]), **kw))
             self._flush_batch(p, dl, L.LoraDownArgs, lib.qfx_lora_down_batch)
+            self._flush_head_reduce(p, dhq)
             if i > 0:
                 self._gemm_group(p, groups)
                 if dmods is not None:   # d(shift1, scale1, gate1): dy = d(xm1) (q/k/v dX output), LN input x_in, gate side dx1 * y1

@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.qfx_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib.qfx_abi_version() == _lib.ABI_VERSION == 6
     assert _lib.lib.qfx_build_arch() == b"gfx950"
 
 
@@ -103,7 +103,8 @@ def test_ctypes_structs_match_the_c_header_layout(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = {"qfx_gemm_args": L.GemmArgs, "qfx_lora_down_args": L.LoraDownArgs, "qfx_lora_grad_args": L.LoraGradArgs,
              "qfx_lora_pack_args": L.LoraPackArgs, "qfx_attn_args": L.AttnArgs, "qfx_ln_fwd_args": L.LnFwdArgs, "qfx_ln_bwd_args": L.LnBwdArgs,
-             "qfx_prodigy_args": L.ProdigyArgs, "qfx_cond_lora_args": L.CondLoraArgs}
+             "qfx_prodigy_args": L.ProdigyArgs, "qfx_cond_lora_args": L.CondLoraArgs, "qfx_head_lora": L.HeadLora,
+             "qfx_lora_head_reduce_args": L.LoraHeadReduceArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "qfx.h"', "int main(void) {"]
     for cname, ct in pairs.items():
         lines.append(f'  printf("{cname} %zu", sizeof({cname}));')

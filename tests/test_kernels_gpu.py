@@ -338,6 +338,64 @@ def test_lora_down_grouped_ext():
     assert e[:, :, 3 * Rp:].abs().max() == 0
 
 
+@pytest.mark.parametrize("dh,S,T,R,Bn", [(128, 2432, 384, 16, 1), (64, 200, 16, 32, 2), (128, 333, 48, 16, 1)])
+def test_attention_forward_emits_the_out_projection_down_projection(dh, S, T, R, Bn):
+    """ABI 6, qfx_head_lora slot 0 + qfx_lora_head_reduce: u = O A^T leaves the attention forward as per-head partial sums and the
+    reduce launch writes qfx_lora_down's outputs -- compared with qfx_lora_down on the O the kernel wrote (image rows s >= T with
+    one adapter, text rows s < T with another; ragged S, two samples, both head dims, rank 16 / 32)."""
+    import ctypes as C
+    from qflux_amd import _lib as L
+    ops = _ops()
+    H = 3
+    D = H * dh
+    S_pad = (S + 63) // 64 * 64
+    qkv = randn(Bn, S, 3 * D, seed=4).to(BF).to(DEV)
+    O = torch.zeros(Bn, S, D, dtype=BF, device=DEV)
+    lse2 = torch.zeros(Bn, H, S_pad, device=DEV)
+    w = {s: _split(randn(R, D, seed=10 + i, scale=0.1)) for i, s in enumerate(("img", "txt"))}
+    wd = {s: (w[s][0].to(DEV), w[s][1].to(DEV)) for s in w}
+    part = torch.full((H, Bn * S, R + 4), float("nan"), device=DEV)       # ld_part > R, c0 = 4: neighbours must stay untouched
+    a = ops.attn_args(Bn, S, S_pad, H, dh, 1 / math.sqrt(dh), Q=qkv[:, :, :D], K=qkv[:, :, D:2 * D], V=qkv[:, :, 2 * D:], ldq=3 * D, ldk=3 * D,
+                      ldv=3 * D, O=O, ldo=D, lse2=lse2)
+    a.T = T
+    hl = a.hl[0]
+    hl.part, hl.part_hstride, hl.ld_part, hl.c0, hl.R = part.data_ptr(), Bn * S * (R + 4), R + 4, 4, R
+    imgs = {s: L.head_fragment_image(wd[s][0], wd[s][1], dh) for s in wd}
+    for si, s in enumerate(("img", "txt")):
+        hl.w_pk[si] = imgs[s].data_ptr()
+    ops.attn_call("qfx_attn_fwd", a)
+    assert torch.isnan(part[:, :, :4]).all() and not torch.isnan(part[:, :, 4:]).any()
+    Kext = ((3 * R + 63) // 64) * 64
+    for s, (lo_, hi_) in (("txt", (0, T)), ("img", (T, S))):
+        M = Bn * (hi_ - lo_)
+        mp = (M + 127) // 128 * 128
+        ext = torch.zeros(M, Kext, dtype=BF, device=DEV)
+        Ut = (torch.zeros(R, mp, dtype=BF, device=DEV), torch.zeros(R, mp, dtype=BF, device=DEV))
+        r = L.LoraHeadReduceArgs()
+        pv = part[:, :, 4:]
+        r.part, r.part_hstride, r.ld_part, r.H = pv.data_ptr(), Bn * S * (R + 4), R + 4, H
+        r.M, r.R, r.ext, r.ld_ext = M, R, ext.data_ptr(), Kext
+        r.Ut_hi, r.Ut_lo, r.ld_ut, r.group_R, r.group_stride = Ut[0].data_ptr(), Ut[1].data_ptr(), mp, R, 0
+        r.rows_per_batch, r.x_batch_rows, r.x_row_off = hi_ - lo_, S, lo_
+        L.check(L.lib.qfx_lora_head_reduce(C.byref(r), 1, ops.stream_ptr()), "qfx_lora_head_reduce")
+        # reference: the stand-alone down projection of the same rows of O
+        ext_r = torch.zeros_like(ext)
+        Ut_r = (torch.zeros_like(Ut[0]), torch.zeros_like(Ut[1]))
+        U_r = torch.empty(M, R, dtype=torch.float32, device=DEV)
+        ops.lora_down(O.view(Bn * S, D), wd[s][0], wd[s][1], U=U_r, ext=ext_r, Ut=Ut_r, M=M, rows_per_batch=hi_ - lo_, x_map=(S, lo_))
+        e, er = ext.float().cpu(), ext_r.float().cpu()
+        check(f"head_lora_fwd_{dh}_{S}_{s}", e[:, :R] + e[:, R:2 * R], U_r, 2e-5)       # fp32 sums in a different order
+        assert torch.equal(e[:, :R], e[:, 2 * R:3 * R]) and e[:, 3 * R:].abs().max() == 0
+        check(f"head_lora_fwd_ut_{dh}_{S}_{s}", (Ut[0].float() + Ut[1].float())[:, :M].t(), U_r, 2e-5)
+        assert Ut[0][:, M:].abs().sum() == 0 and (er[:, :R] - e[:, :R]).abs().max() <= 2.0 ** -7 * er[:, :R].abs().max()
+    # bad arguments are refused before any launch
+    hl.R = 24
+    assert L.lib.qfx_attn_fwd(C.byref(a), ops.stream_ptr()) == -2
+    hl.R = R
+    a.T = T + 3
+    assert L.lib.qfx_attn_fwd(C.byref(a), ops.stream_ptr()) == -1
+
+
 def test_tr_read_lane_mapping():
     """gfx950 ds_read_b64_tr_b16: result[lane i][j] = data[lane 16*(i>>4) + 4j + ((i&15)>>2)][i&3] (documents the HW)."""
     from qflux_amd import _lib as L
@@ -418,9 +476,13 @@ def test_lora_pack():
     d.A_hi, d.A_lo, d.ld_a = A_hi.data_ptr(), A_lo.data_ptr(), K
     d.Bt_hi, d.Bt_lo, d.ld_bt = Bt_hi.data_ptr(), Bt_lo.data_ptr(), N
     d.We, d.ld_we, d.WeT, d.ld_wet, d.Rp, d.Kext = We.data_ptr(), Kext, WeT.data_ptr(), Kext, Rp, Kext
+    # ABI 6: the head-fragment images of both operands (head dim 64: K = 2 heads, N = 3 heads)
+    A_hl = torch.full((2 * Rp * K,), 7.0, dtype=BF, device=DEV); Bt_hl = torch.full((2 * Rp * N,), 7.0, dtype=BF, device=DEV)
+    d.A_hl, d.Bt_hl, d.hl_dh = A_hl.data_ptr(), Bt_hl.data_ptr(), 64
     t = ops.pack_descs_tensor([d], DEV)
     ops.lora_pack(t, 1, max(K, N))
     torch.cuda.synchronize()
+    assert torch.equal(A_hl, L.head_fragment_image(A_hi, A_lo, 64)) and torch.equal(Bt_hl, L.head_fragment_image(Bt_hi, Bt_lo, 64))
     Ap = torch.zeros(Rp, K); Ap[:r] = A.cpu()
     Bp = torch.zeros(Rp, N); Bp[:r] = s * Bm.cpu().t()
     check("pack_A", A_hi.float() + A_lo.float(), Ap, 1e-4)

@@ -351,6 +351,48 @@ def test_merge_adapter_matches_oracle_with_folded_weights():
     assert relmax(fwd_hip(), out_u) < 1e-2
 
 
+@pytest.mark.parametrize("both_streams", [False, True], ids=["image-adapters", "image+text-adapters"])
+def test_head_lora_fusion_matches_separate_down_projections(both_streams, monkeypatch):
+    """ABI 6 (round 4): with T % 16 == 0 the rank-r down projections of the out-projection adapter (forward) and of the q / k / v
+    adapters (backward) ride in the attention epilogues (qfx_head_lora + qfx_lora_head_reduce).  The same step with the fusion switched
+    off (QFX_FUSE_HEAD_LORA=0: three qfx_lora_down launches per block, rounds 1-3) must give the same prediction, loss and LoRA
+    gradients up to the fp32 summation order, both against the bf16 oracle; and two of the three launches are really gone."""
+    from common import TINY
+    from oracle import qwen_dit as O
+    from qflux_amd.trainer import QwenLoraTrainStep
+    targets = ("to_k", "to_q", "to_v", "to_out.0") + (("add_q_proj", "add_k_proj", "add_v_proj", "to_add_out") if both_streams else ())
+    oracle, hip = build_pair(dict(TINY), device=DEV, targets=targets)
+    emb, noise, u = tiny_embeddings(B=2, shapes=((1, 4, 8), (1, 4, 8)), T=16, Jd=TINY["joint_attention_dim"])
+    with torch.no_grad():
+        for (n, p), (_, po) in zip(sorted(hip.named_parameters()), sorted(oracle.named_parameters())):
+            if "lora_B" in n:
+                v = torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))) * 1e-2
+                p.copy_(v.to(p.device)); po.copy_(v)
+    loss_o, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+    loss_o.backward()
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QFX_FUSE_HEAD_LORA", mode)
+        hip._invalidate()
+        step = QwenLoraTrainStep(hip)
+        step.zero_grad()
+        loss = step.forward_backward(emb, noise=noise, u=u).item()
+        plan = list(hip._plans.values())[0]
+        names = [c[0].__name__ for prog in (plan.fwd, plan.bwd) for c in prog.calls if c[0] is not None]
+        res[mode] = dict(loss=loss, pred=plan.A["out"].float().cpu().clone(), grads={n: p.grad.float().cpu().clone() for n, p in hip.named_parameters() if "lora" in n},
+                         down=sum(n.startswith("qfx_lora_down") for n in names), red=names.count("qfx_lora_head_reduce"), fused=plan.head_lora)
+    f, s_ = res["1"], res["0"]
+    L_ = TINY["num_layers"]
+    assert f["fused"] and not s_["fused"] and f["red"] == 2 * L_ and s_["red"] == 0
+    assert f["down"] == s_["down"] - 2 * L_, (f["down"], s_["down"])       # per block: ao down (forward) and the q/k/v batch (backward) are gone
+    assert abs(f["loss"] - s_["loss"]) < 1e-5 * abs(s_["loss"]) and relmax(f["pred"], s_["pred"]) < 4e-3
+    worst = max(relmax(f["grads"][n], s_["grads"][n]) for n in f["grads"])
+    worst_o = max(relmax(f["grads"][n], og[n]) for n in f["grads"] if og[n] is not None)
+    print("head-lora fusion: loss", f["loss"], s_["loss"], loss_o.item(), "grad fused~separate", worst, "fused~oracle", worst_o)
+    assert worst < 5e-3 and worst_o < 4e-2 and abs(f["loss"] - loss_o.item()) / abs(loss_o.item()) < 5e-3
+
+
 def test_loss_curve_matches_oracle_training_run():
     """BASELINE north_star: "loss-curve match to the reference within 1e-3 MSE".  60 optimisation steps on a rotating pool of
     batches with fresh (injected) noise / timestep draws: the fused HIP step (forward, backward, clip, AdamW) vs the oracle DiT trained

@@ -6,11 +6,12 @@ import argparse, ctypes as C, json, math, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from step_ab import load_variant
-from qflux_amd import ops
+from qflux_amd import ops, _lib as L
 ap = argparse.ArgumentParser(); ap.add_argument("variants"); ap.add_argument("--entry", default="fwd,dq,dkv"); ap.add_argument("--S", default="2432,8576")
+ap.add_argument("--hl", type=int, default=0, help="rank of a fused out-projection down projection (qfx_head_lora slot 0, forward only); names ending in '-' run without it")
 args = ap.parse_args()
 names = args.variants.split(",")
-libs = {n: load_variant(n) for n in names}
+libs = {n: load_variant(n.rstrip("-")) for n in names}
 BF, DEV = torch.bfloat16, "cuda:0"
 out = {}
 for S in [int(x) for x in args.S.split(",")]:
@@ -27,6 +28,16 @@ for S in [int(x) for x in args.S.split(",")]:
         a = ops.attn_args(Bn, S, S_pad, H, dh, 1 / math.sqrt(dh), Q=qkv[:, :, :D], K=qkv[:, :, D:2 * D], V=qkv[:, :, 2 * D:], ldq=ld, ldk=ld, ldv=ld,
                           O=O, ldo=D, lse2=lse2, dsum=dsum, dO=dO, lddo=D, dQ=dqkv[:, :, :D], dK=dqkv[:, :, D:2 * D], dV=dqkv[:, :, 2 * D:],
                           lddq=ld, lddk=ld, lddv=ld)
+        if args.hl and not n.endswith("-"):
+            R = args.hl
+            wts = [(torch.randn(R, D, device=DEV) * 0.1).to(BF) for _ in range(4)]
+            part = torch.zeros(H, Bn * S, R, device=DEV)
+            a.T = 384
+            hl = a.hl[0]
+            hl.part, hl.part_hstride, hl.ld_part, hl.c0, hl.R = part.data_ptr(), Bn * S * R, R, 0, R
+            wts = [L.head_fragment_image(wts[0], wts[1], dh), L.head_fragment_image(wts[2], wts[3], dh)]
+            hl.w_pk[0], hl.w_pk[1] = (t.data_ptr() for t in wts)
+            a._keep = (wts, part)
         bufs[n] = (a, O, lse2, dsum, dqkv)
     st = torch.cuda.current_stream().cuda_stream
     for ent in args.entry.split(","):
