@@ -127,11 +127,43 @@ __device__ __forceinline__ void head_lora_frag(const qfx_head_lora& hl, int h, i
   }
 }
 
+// Store one 16-row fragment held as packed bf16 pairs in the accumulator layout (lane (g, li): row li, u[d] = columns 16 d + 4 g .. + 3)
+// as whole 16-byte pieces: v_permlane16_swap hands the two lanes of a (g, g ^ 1) pair each other's half of a 32-column block, so a lane
+// stores 8 adjacent columns -- DH / 32 dwordx4 per lane instead of DH / 16 dwordx2 (the store tail of these kernels is store-ISSUE
+// bound, microarch guide: per-lane dwordx2 at a row stride; half the instructions, same bytes).  `rowp` = the row's first column of
+// this head; every lane of the wave must call (the exchange is cross-lane), `ok` masks the store.  wide == false (a base or row
+// stride that is not 16-byte aligned): the 8-byte form.
+template <int DH>
+__device__ __forceinline__ void store_frag(bf16_t* rowp, const u32x2 (&u)[DH / 16], int g, bool ok, bool wide) {
+  if (wide) {
+    const int c0 = 16 * (g & 1) + 4 * (g & 2);
+#pragma unroll
+    for (int p = 0; p < DH / 32; ++p) {
+      const auto s0 = __builtin_amdgcn_permlane16_swap(u[2 * p][0], u[2 * p + 1][0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(u[2 * p][1], u[2 * p + 1][1], false, false);
+      if (ok) *(u32x4*)(rowp + 32 * p + c0) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+    }
+  } else if (ok) {
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d) *(u32x2*)(rowp + d * 16 + 4 * g) = u[d];
+  }
+}
+__device__ __forceinline__ bool rows_16b(const void* base, int64_t ld_elems) {
+#if defined(QFX_ATTN_NARROW_STORE)      // A/B lever (tools/build_variants.py): the 8-byte store tail of rounds 1-3
+  return false;
+#else
+  return (((uintptr_t)base | (uintptr_t)(ld_elems * 2)) & 15) == 0;
+#endif
+}
+
 // =============================================================================================
 // forward: block = 128 queries (4 waves x 32), loop over 64-key tiles, K/V^T double-buffered in LDS
 // NW = waves per block (32 queries each).  8 waves / 256 queries, one block per CU, is used when it quantises better onto the
 // 256 CUs (S = 2432: 10 x 24 = 240 blocks, 94 % of the CUs, against 456 blocks on 512 half-CU slots = 89 %) and halves the K/V
 // LDS-DMA traffic per query; 4 waves / 128 queries, two blocks per CU, otherwise.
+#ifndef ATTN_DEFER_MAX
+#define ATTN_DEFER_MAX 8.0f     // log2 units; -DATTN_DEFER_MAX=0.0f = the eager running maximum of rounds 1-3
+#endif
 template <int DH, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(const qfx_attn_args a) {
   constexpr int KC = DH / 32, DF = DH / 16;
@@ -218,23 +250,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     }
     const float cs = need_mask ? 1.0f : c2;   // scores are already scaled (and masked) on the masked path
     bf16x8 pb[2][2];
-    float alpha[2];
+    // Lazy reference maximum: the exponent reference mrow (and with it O and l) moves only when some score of this wave's tile exceeds
+    // it by more than 2^8 -- P = exp2(s - mrow) <= 256 otherwise, exact in the bf16 / fp32 ranges involved, and O / l = softmax(s) V
+    // whatever reference is used (lse2 = mrow + log2 l likewise).  The test is lane-local (each lane's own 16 scores of a query row
+    // against that row's reference, one wave vote); the cross-lane row maximum is only formed when the reference has to move.  On
+    // typical data the reference settles within the first tiles and both the reduction and the 64-register rescale of O leave the
+    // loop.  (-inf - -inf = NaN compares false: the first tile and fully masked rows take the update path.)
+    if (!__all(mx[0] * cs - mrow[0] <= ATTN_DEFER_MAX && mx[1] * cs - mrow[1] <= ATTN_DEFER_MAX)) {
+      float alpha[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float m = mx[f];
+        {   // cross-lane maximum over the four 16-lane groups on the VALU (v_permlane16_swap / v_permlane32_swap): no LDS crossbar trip
+          const uint32_t u0 = __float_as_uint(m);
+          const auto r0 = __builtin_amdgcn_permlane16_swap(u0, u0, false, false);
+          m = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
+          const uint32_t u1 = __float_as_uint(m);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+          m = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+        }
+        const float mnew = fmaxf(mrow[f], m * cs);
+        alpha[f] = fexp2(mrow[f] - ((mnew == -INFINITY) ? 0.f : mnew));
+        mrow[f] = mnew;
+        lrow[f] *= alpha[f];
+      }
+#pragma unroll
+      for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { oacc[d][0][r] *= alpha[0]; oacc[d][1][r] *= alpha[1]; }
+    }
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-      float m = mx[f];
-      {   // cross-lane maximum over the four 16-lane groups on the VALU (v_permlane16_swap / v_permlane32_swap): no LDS crossbar trip
-        const uint32_t u0 = __float_as_uint(m);
-        const auto r0 = __builtin_amdgcn_permlane16_swap(u0, u0, false, false);
-        m = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
-        const uint32_t u1 = __float_as_uint(m);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
-        m = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
-      }
-      m *= cs;
-      const float mnew = fmaxf(mrow[f], m);
-      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      alpha[f] = fexp2(mrow[f] - msafe);
-      mrow[f] = mnew;
+      const float msafe = (mrow[f] == -INFINITY) ? 0.f : mrow[f];
       float ps = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
@@ -244,16 +291,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
           sacc[kf][f][r] = p;
           ps += p;
         }
-      lrow[f] = lrow[f] * alpha[f] + ps;
+      lrow[f] += ps;
       pb[f][0] = pack8(sacc[0][f], sacc[1][f]);
       pb[f][1] = pack8(sacc[2][f], sacc[3][f]);
-    }
-    // rescale O only when some running max of this wave moved (exact: alpha == 1 otherwise)
-    if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
-#pragma unroll
-      for (int d = 0; d < DF; ++d)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { oacc[d][0][r] *= alpha[0]; oacc[d][1][r] *= alpha[1]; }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -319,12 +359,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
       u[d][0] = pack2bf(oacc[d][f][0] * inv, oacc[d][f][1] * inv);
       u[d][1] = pack2bf(oacc[d][f][2] * inv, oacc[d][f][3] * inv);
     }
-    if (q < S) {
-      bf16_t* op = a.O + ((int64_t)b * S + q) * a.ldo + h * DH + 4 * g;
-#pragma unroll
-      for (int d = 0; d < DF; ++d) *(u32x2*)(op + d * 16) = u[d];
-      if (g == 0) a.lse2[((int64_t)b * a.H + h) * a.S_pad + q] = mrow[f] + log2f(l);
-    }
+    store_frag<DH>(a.O + ((int64_t)b * S + (q < S ? q : S - 1)) * a.ldo + h * DH, u, g, q < S, rows_16b(a.O, a.ldo));
+    if (q < S && g == 0) a.lse2[((int64_t)b * a.H + h) * a.S_pad + q] = mrow[f] + log2f(l);
     // rank-r down projection of the out-projection adapter on the rows just produced (ABI 6)
     if (q0 + f * 16 < S) head_lora_frag<DH>(a.hl[0], h, a.T, q0 + f * 16, (int64_t)b * S + (q < S ? q : S - 1), q < S, u, g, li);
   }
@@ -547,25 +583,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_kernel(c
   for (int f = 0; f < 2; ++f) {
     const int q = q0 + f * 16 + li;
     const int qc = q < S ? q : S - 1;       // rows past S compute on row S-1 (the shuffles below need every lane) and are not stored
-    bf16_t* op = a.dQ + ((int64_t)b * S + qc) * a.lddq + h * DH + 4 * g;
+    bf16_t* op = a.dQ + ((int64_t)b * S + qc) * a.lddq + h * DH;
+    const bool wide = rows_16b(a.dQ, a.lddq);
     if (a.qk_saved) {       // block-uniform: d(pre-norm q) straight from the accumulators (QK RMSNorm + RoPE backward fused here)
       u32x2 u[DF];
       norm_rope_bwd_row<DH>(dq, f, a.scale, a.qk_saved + ((int64_t)b * S + qc) * a.ld_saved + h * DH + 4 * g,
                             a.rope + (int64_t)b * a.rope_bstride + ((int64_t)qc * (DH / 2) + 2 * g) * 2,
                             (qc < a.T ? a.wq_txt : a.wq_img) + 4 * g, a.norm_eps, a.norm_flags, u);
-      if (q < S) {
-#pragma unroll
-        for (int d = 0; d < DF; ++d) *(u32x2*)(op + d * 16) = u[d];
-      }
+      store_frag<DH>(op, u, g, q < S, wide);
       if (q0 + f * 16 < S) head_lora_frag<DH>(a.hl[1], h, a.T, q0 + f * 16, (int64_t)b * S + qc, q < S, u, g, li);   // v_q = d(pre-norm q) (s B_q)^T
-    } else if (q < S) {
+    } else {
+      u32x2 u[DF];
 #pragma unroll
       for (int d = 0; d < DF; ++d) {
-        u32x2 u;
-        u[0] = pack2bf(dq[d][f][0] * a.scale, dq[d][f][1] * a.scale);
-        u[1] = pack2bf(dq[d][f][2] * a.scale, dq[d][f][3] * a.scale);
-        *(u32x2*)(op + d * 16) = u;
+        u[d][0] = pack2bf(dq[d][f][0] * a.scale, dq[d][f][1] * a.scale);
+        u[d][1] = pack2bf(dq[d][f][2] * a.scale, dq[d][f][3] * a.scale);
       }
+      store_frag<DH>(op, u, g, q < S, wide);
     }
   }
 }
@@ -762,17 +796,15 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    bf16_t* kp = a.dK + ((int64_t)b * S + mykey[f]) * a.lddk + h * DH + 4 * g;
-    bf16_t* vp = a.dV + ((int64_t)b * S + mykey[f]) * a.lddv + h * DH + 4 * g;
+    bf16_t* kp = a.dK + ((int64_t)b * S + mykey[f]) * a.lddk + h * DH;
+    bf16_t* vp = a.dV + ((int64_t)b * S + mykey[f]) * a.lddv + h * DH;
+    const bool wide_k = rows_16b(a.dK, a.lddk), wide_v = rows_16b(a.dV, a.lddv);
     if (a.qk_saved) {       // block-uniform: d(pre-norm k) straight from the accumulators (rows past S ride along on row S-1, unstored)
       u32x2 u[DF];
       norm_rope_bwd_row<DH>(dk, f, a.scale, a.qk_saved + ((int64_t)b * S + mykey[f]) * a.ld_saved + a.H * DH + h * DH + 4 * g,
                             a.rope + (int64_t)b * a.rope_bstride + ((int64_t)mykey[f] * (DH / 2) + 2 * g) * 2,
                             (mykey[f] < a.T ? a.wk_txt : a.wk_img) + 4 * g, a.norm_eps, a.norm_flags, u);
-      if (keyok[f]) {
-#pragma unroll
-        for (int d = 0; d < DF; ++d) *(u32x2*)(kp + d * 16) = u[d];
-      }
+      store_frag<DH>(kp, u, g, keyok[f], wide_k);
       if (key0 + f * 16 < S) {      // fragment-uniform: v_k = d(pre-norm k) (s B_k)^T, v_v = dV (s B_v)^T (ABI 6)
         head_lora_frag<DH>(a.hl[2], h, a.T, key0 + f * 16, (int64_t)b * S + mykey[f], keyok[f], u, g, li);
         if (a.hl[3].part != nullptr) {
@@ -782,19 +814,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
         }
       }
     }
-    if (!keyok[f]) continue;
+    u32x2 u[DF];
+    if (!a.qk_saved) {
 #pragma unroll
-    for (int d = 0; d < DF; ++d) {
-      u32x2 u;
-      if (!a.qk_saved) {
-        u[0] = pack2bf(dk[d][f][0] * a.scale, dk[d][f][1] * a.scale);
-        u[1] = pack2bf(dk[d][f][2] * a.scale, dk[d][f][3] * a.scale);
-        *(u32x2*)(kp + d * 16) = u;
+      for (int d = 0; d < DF; ++d) {
+        u[d][0] = pack2bf(dk[d][f][0] * a.scale, dk[d][f][1] * a.scale);
+        u[d][1] = pack2bf(dk[d][f][2] * a.scale, dk[d][f][3] * a.scale);
       }
-      u[0] = pack2bf(dv[d][f][0], dv[d][f][1]);
-      u[1] = pack2bf(dv[d][f][2], dv[d][f][3]);
-      *(u32x2*)(vp + d * 16) = u;
+      store_frag<DH>(kp, u, g, keyok[f], wide_k);
     }
+#pragma unroll
+    for (int d = 0; d < DF; ++d) { u[d][0] = pack2bf(dv[d][f][0], dv[d][f][1]); u[d][1] = pack2bf(dv[d][f][2], dv[d][f][3]); }
+    store_frag<DH>(vp, u, g, keyok[f], wide_v);
   }
 }
 

@@ -14,8 +14,9 @@ names = args.variants.split(",")
 libs = {n: load_variant(n.rstrip("-")) for n in names}
 BF, DEV = torch.bfloat16, "cuda:0"
 out = {}
-for S in [int(x) for x in args.S.split(",")]:
-    Bn, H, dh = 1, 24, 128
+for Sspec in args.S.split(","):      # "S" or "S:H" (heads; 24 by default)
+    S, H = (int(x) for x in (Sspec.split(":") + ["24"])[:2])
+    Bn, dh = 1, 128
     D = H * dh; S_pad = (S + 63) // 64 * 64
     torch.manual_seed(S)
     qkv = torch.randn(Bn, S, 3 * D, device=DEV).to(BF)
