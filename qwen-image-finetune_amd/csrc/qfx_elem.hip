@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const LnFwdBatch bt) {
 
 // ---------------------------------------------------------------- LayerNorm + modulate, backward
 template <int NP>   // passes of 512 columns: NP = ceil(D / 512) (register arrays are sized by it)
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP <= 6 ? 3 : 2, NP <= 6 ? 3 : 2))) void ln_mod_bwd_kernel(const LnBwdBatch bt) {
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   int pi = 0;
