@@ -33,6 +33,10 @@ template <int DH> __device__ __forceinline__ int swz_row(int row) {
   else return (row >> 1) & 7;
 }
 
+// row * ld of a staging source as a FULL-rate 24-bit multiply (v_mul_u32_u24; the 32 / 64-bit forms are quarter rate and sit in
+// every tile iteration): rows and row strides < 2^24 and S * ld < 2^32 are checked by the launchers (check_common).
+__device__ __forceinline__ unsigned row_off(int row, int64_t ld) { return __umul24((unsigned)row, (unsigned)ld); }
+
 // 64 rows x DH tile of a token-major tensor (rows s0..s0+63 clamped to S-1) -> LDS [64][DH], swizzled.
 // base points at element [b, 0, h, 0]; ld = row stride in elements.
 template <int DH>
@@ -46,7 +50,7 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* base, int64_
     const int row = w * 16 + i * RPI + rr;
     int s = s0 + row; s = s < S ? s : S - 1;
     const int sc = c ^ swz_row<DH>(row);
-    glds16(base + (int64_t)s * ld + sc * 8, lds + (w * 16 + i * RPI) * (DH * 2));
+    glds16(base + (row_off(s, ld) + (unsigned)(sc * 8)), lds + (w * 16 + i * RPI) * (DH * 2));
   }
 }
 
@@ -74,7 +78,7 @@ __device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int6
     const int row = w * RPW + i * RPI + rr;
     int s = s0 + row; s = s < S ? s : S - 1;
     const int sc = c ^ swz_row<DH>(row);
-    glds16(base + (int64_t)s * ld + sc * 8, lds + (w * RPW + i * RPI) * (DH * 2));
+    glds16(base + (row_off(s, ld) + (unsigned)(sc * 8)), lds + (w * RPW + i * RPI) * (DH * 2));
   }
 }
 
@@ -470,8 +474,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_kernel(c
       const int row = w * RPW + i * RPI + lane / CPR;
       const int sc8 = ((lane % CPR) ^ swz_row<DH>(row)) * 8;
       int sr = j0 + row; sr = sr < S ? sr : S - 1;
-      glds16(Kb + (unsigned)(sr * a.ldk + sc8), dK_ + (w * RPW + i * RPI) * (DH * 2));
-      glds16(Vb + (unsigned)(sr * a.ldv + sc8), dK_ + TB + (w * RPW + i * RPI) * (DH * 2));
+      glds16(Kb + (row_off(sr, a.ldk) + (unsigned)sc8), dK_ + (w * RPW + i * RPI) * (DH * 2));
+      glds16(Vb + (row_off(sr, a.ldv) + (unsigned)sc8), dK_ + TB + (w * RPW + i * RPI) * (DH * 2));
     }
   };
   stage(0, 0);
@@ -673,8 +677,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
       const int row = w * RPW + i * RPI + ln / CPR;
       const int sc8 = ((ln % CPR) ^ swz_row<DH>(row)) * 8;
       int sr = i0 + row; sr = sr < S ? sr : S - 1;
-      glds16(Qb + (unsigned)(sr * a.ldq + sc8), dQ_ + (w * RPW + i * RPI) * (DH * 2));
-      glds16(dOb + (unsigned)(sr * a.lddo + sc8), dQ_ + TB + (w * RPW + i * RPI) * (DH * 2));
+      glds16(Qb + (row_off(sr, a.ldq) + (unsigned)sc8), dQ_ + (w * RPW + i * RPI) * (DH * 2));
+      glds16(dOb + (row_off(sr, a.lddo) + (unsigned)sc8), dQ_ + TB + (w * RPW + i * RPI) * (DH * 2));
     }
     if (w == 0) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(lseb + i0 + ln), (QFX_AS3 void*)(sStat + buf * 512), 4, 0, 0);
     if (w == 1) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(dsb + i0 + ln), (QFX_AS3 void*)(sStat + buf * 512 + 256), 4, 0, 0);
@@ -843,6 +847,10 @@ int pick_waves(const qfx_attn_args* a) {
 int check_common(const qfx_attn_args* a) {
   if (!a || a->B <= 0 || a->S <= 0 || a->H <= 0 || (a->S_pad % 64) || a->S_pad < a->S) return QFX_EINVAL;
   if (a->dh != 64 && a->dh != 128) return QFX_EUNSUPPORTED;
+  // the tile staging addresses rows as 32-bit element offsets from a per-(batch, head) base, built with 24-bit multiplies
+  const int64_t lds[] = {a->ldq, a->ldk, a->ldv, a->lddo};
+  for (int64_t ld : lds)
+    if (ld < 0 || ld >= (1 << 24) || a->S >= (1 << 24) || (int64_t)a->S * ld >= (1LL << 32)) return QFX_EUNSUPPORTED;
   return QFX_OK;
 }
 
