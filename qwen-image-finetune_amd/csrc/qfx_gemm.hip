@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 // The wide counterparts 160 x 384 (two full rounds for N = 12288; 120 accumulators leave the allocator four registers short: scratch
 // reloads inside the K loop) and 160 x 256 (three rounds) were built and measured +13 % / +24 % against 256 x 256: removed.
 // The launcher picks the geometry per launch from rounds x relative tile time (qfx_gemm_grouped).
-constexpr int NLD = 2;                            // loader waves
+#ifndef QFX_GEMM_NLD
+#define QFX_GEMM_NLD 4
+#endif
+constexpr int NLD = QFX_GEMM_NLD;                 // loader waves
 constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
 constexpr int QFX_NUM_CU = 256;                   // MI355X
@@ -319,10 +322,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     // ================================================================ loader waves
     const int lw = w - 8;
     constexpr int NA = (BMT / 8) / NLD, NB = (TN / 8) / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
-    static_assert(NLD == 2 && (BMT / 8) % NLD == 0 && (TN / 8) % NLD == 0 && NA + NB < 64, "loader split / vmcnt immediate");
+    static_assert(NLD % 2 == 0 && (BMT / 8) % NLD == 0 && (TN / 8) % NLD == 0 && NA + NB < 64, "loader split / vmcnt immediate");
     const int srow = lane >> 3, schunk = lane & 7;
-    // source column incl. the bank swizzle chunk ^ ((row>>1)&7); with NLD == 2 it is the same for every piece
-    const int sc = (schunk ^ ((lw * 4 + (srow >> 1)) & 7)) * 8;
+    // source column incl. the bank swizzle chunk ^ ((row>>1)&7): the same for every piece of a loader wave (piece parity = lw & 1)
+    const int sc = (schunk ^ (((lw & 1) * 4 + (srow >> 1)) & 7)) * 8;     // (piece parity = lw & 1 for an even number of loader waves)
     const bf16_t* pa[NA];
     const bf16_t* pb[NB];
     int ibid = blockIdx.x, it = 0, int1 = 0, intt = 0, ist = 0;
@@ -363,10 +366,17 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       char* sA = smem + ist * STAGE_BYTES;
       char* sB = sA + BMT * BK * 2;
       const int koff = (it < int1 ? it : it - int1) * BK;
+#if defined(QFX_GEMM_ABL_HALF_DMA)   // ablation (results are garbage): every other DMA piece -- is the K loop bound by the L2 -> LDS stream?
+#pragma unroll
+      for (int i = 0; i < NA; i += 2) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
+#pragma unroll
+      for (int i = 0; i < NB; i += 2) glds16(pb[i] + koff, sB + (lw + i * NLD) * 1024);
+#else
 #pragma unroll
       for (int i = 0; i < NA; ++i) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
 #pragma unroll
       for (int i = 0; i < NB; ++i) glds16(pb[i] + koff, sB + (lw + i * NLD) * 1024);
+#endif
       ist = ist + 1 == NSTAGE ? 0 : ist + 1;
       if (++it == intt) {
         it = 0; ibid += gridDim.x; more = ibid < nwg;
@@ -383,7 +393,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       const int ntw = ga.g[gi].K1 / BK + ga.g[gi].K2 / BK;
       for (int t = 0; t < ntw; ++t) {
         // the oldest K tile in flight must have landed; the one issued after it (NA + NB pieces) may still be in flight
+#if defined(QFX_GEMM_ABL_HALF_DMA)
+        if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NA + 1) / 2 + (NB + 1) / 2) : "memory");
+#else
         if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NA + NB) : "memory");
+#endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         --ahead;
