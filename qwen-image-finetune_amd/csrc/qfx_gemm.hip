@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 #ifndef QFX_GEMM_NLD
 #define QFX_GEMM_NLD 4
 #endif
+#ifndef QFX_GEMM_PF_DIST
+#define QFX_GEMM_PF_DIST 0      // K tiles an L2 prefetch runs ahead of the K loop (0 = off), see the compute waves
+#endif
 constexpr int NLD = QFX_GEMM_NLD;                 // loader waves
 constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
@@ -246,7 +249,11 @@ constexpr int QFX_NUM_CU = 256;                   // MI355X
 template <int BMT, int TN> struct TileCfg {
   static constexpr bool WIDE = TN >= 256;           // 2-stage ring + streaming K loop
   static constexpr int STAGE = (BMT + TN) * BK * 2;
+#if defined(QFX_GEMM_ABL_NST2)     // ablation: one K tile in flight on the narrow tiles too (how much of the K loop is DMA latency?)
+  static constexpr int NST = 2;
+#else
   static constexpr int NST = WIDE ? 2 : 3;
+#endif
   static constexpr int WRN = (BMT == 256 && TN == 128) ? 4 : 2;     // compute waves along M
   static constexpr int WCN = 8 / WRN;               // ... along N
   static constexpr int MI = BMT / WRN / 16;         // 16-row MFMA fragments per wave
@@ -282,7 +289,7 @@ typedef const QFX_AS4 GroupedArgs KGroupedArgs;
 typedef const QFX_AS4 qfx_gemm_args KArgs;
 
 template <int BMT, int TN>
-__device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0) {
+__device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0, int* pin = nullptr, int* pgsz = nullptr) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   gi = 0;
@@ -300,6 +307,8 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
   const int in = lt - sg * per;
   m0 = (first + in % gsz) * BMT;
   n0 = (in / gsz) * TN;
+  if (pin) *pin = in;
+  if (pgsz) *pgsz = gsz;
 }
 
 typedef __attribute__((ext_vector_type(8))) int v8i32;
@@ -413,9 +422,12 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   char* stg = smem + NSTAGE * STAGE_BYTES + w * STG_BYTES;
   int buf = 0;
   (void)lane;
+  // destination of the (uncounted) prefetch loads: ONE register reserved for the whole persistent loop -- hipcc considers an asm
+  // load's destination written when the statement ends and would hand the register to something else while the data is in flight
+  unsigned pf_sink = 0;
   for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
-    int gi, m0, n0;
-    tile_coord<BMT, TN>(ga, nwg, bid, gi, m0, n0);
+    int gi, m0, n0, tin, tgsz;
+    tile_coord<BMT, TN>(ga, nwg, bid, gi, m0, n0, &tin, &tgsz);
     KArgs& p = ga.g[gi];
     // Lane-derived values are re-derived per tile -- here for the K loop, once more for the epilogue -- from a lane id the optimiser
     // cannot see through (v_mbcnt in an asm volatile: neither hoisted nor spilled).  Kept in registers across the whole persistent
@@ -436,6 +448,35 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // L2 prefetch.  The K loop is bound by the loaders' L2 -> LDS stream, and that stream by latency: the ring holds at most two K
+    // tiles in flight per CU and every K tile is a first touch for the XCD's L2 (an ablation with the compute waves idle still takes
+    // 92 % of the launch: profiles/r04_gemm_loader_waves.json).  One dword load per 128-byte line, QFX_GEMM_PF_DIST K tiles ahead,
+    // turns the loaders' misses into L2 hits.  The ~32 tiles an XCD runs at a time form an 8 (M) x 4 (N) patch sharing A panels four
+    // ways and B panels eight ways, so a tile touches a quarter of its A rows (wave 0) and an eighth of its B rows (wave 1): one
+    // wave-instruction per K tile each.  Only a hint: ragged patches leave some lines to the loaders' own misses.  The loads are
+    // uncounted (asm) and their results unused.
+    const bf16_t* pfp = nullptr;
+    if constexpr (QFX_GEMM_PF_DIST > 0 && !FP8) {
+      if (w == 0) {
+        constexpr int SH = BMT / 4;
+        int gm = m0 + ((tin / tgsz) & 3) * SH + (l0 < SH ? l0 : SH - 1); gm = gm < p.M ? gm : p.M - 1;
+        pfp = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1;
+      } else if (w == 1) {
+        constexpr int SH = TN / 8;
+        int gn = n0 + ((tin % tgsz) & 7) * SH + (l0 < SH ? l0 : SH - 1); gn = gn < p.N ? gn : p.N - 1;
+        pfp = p.B1 + (int64_t)gn * p.ldb1;
+      }
+    }
+    auto pf = [&](int kt) {
+      if constexpr (QFX_GEMM_PF_DIST > 0 && !FP8) {
+        if (w < 2 && kt < nt1) {
+          asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pfp + kt * BK) : "memory");
+        }
+      }
+    };
+#pragma unroll 1
+    for (int d = 2; d < QFX_GEMM_PF_DIST; ++d) pf(d);
 
     // narrow tiles -- rotated K loop: the second k-step of K tile t-1 is issued AFTER barrier t, under the first fragment reads
     // of tile t, so the matrix pipe does not drain while the post-barrier ds_reads are in flight (+2..6 % in the lab).
@@ -459,7 +500,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     };
     const bool mid_round = nt2 > 0 && !p.seg2_plain;
+#if defined(QFX_GEMM_ABL_NO_COMPUTE)   // ablation (garbage results): the compute waves keep the barrier protocol only -- how long does the operand stream alone take?
+    const bool wave_dead = true;
+#else
     const bool wave_dead = m0 + wr * WROWS >= p.M;   // wave-uniform
+#endif
     if constexpr (FP8) {
       // ---- MX-FP8 base segment: per K tile (128 fp8 per row) the four B operands (chunks g and g+4 of their rows = the two halves
       // of one scaled-MFMA operand) stay resident, the A operands stream one fragment row ahead; scales (one dword = the 4 MX
@@ -550,6 +595,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* st = smem + buf * STAGE_BYTES;
+        pf(t + QFX_GEMM_PF_DIST);
         auto rdA = [&](int kk, int mi) { return *(const bf16x8*)(st + ((offA0 + mi * (16 * BK * 2)) ^ (kk << 6))); };
         auto rdB = [&](int kk, int ni) { return *(const bf16x8*)(st + ((offB0 + ni * (16 * BK * 2)) ^ (kk << 6))); };
         // a compute wave whose rows all lie past M (the text stream's last, partly empty tile) keeps
@@ -598,6 +644,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* st = smem + buf * STAGE_BYTES;
+        pf(t + QFX_GEMM_PF_DIST);
         if (wave_dead) { buf ^= 1; continue; }   // see the narrow-tile loop
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -776,6 +823,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     }
   }
+  asm volatile("" :: "v"(pf_sink));
 }
 
 bool ok256(const qfx_gemm_args* a) {
