@@ -83,6 +83,8 @@ def hbm_bytes_of_call(name, args):
         return sum(2 * x.M * x.K + 4 * x.R * x.K for x in structs(args[0], args[1] if name.endswith("batch") else None))
     if name in ("qfx_lora_grad", "qfx_lora_grad_batch"):
         return sum(2 * x.M * x.K + 4 * x.R * x.M + 4 * x.R * x.K for x in structs(args[0], args[1] if name.endswith("batch") else None))
+    if name == "qfx_lora_head_reduce":       # (list, n): H per-head fp32 partial slabs of [M, R] read once (round 4, ABI 6)
+        return sum(4 * x.H * x.M * x.R for x in structs(args[0], args[1]))
     if name == "qfx_ln_modulate_fwd_batch":
         return sum(4 * x.rows * x.D for x in structs(args[0], args[1]))
     if name == "qfx_ln_modulate_bwd_batch":

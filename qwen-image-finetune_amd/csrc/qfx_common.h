@@ -29,10 +29,16 @@ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
 // two floats -> one dword of bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32.  The scalar form f2bf(lo) | f2bf(hi) << 16 compiles to
 // two half-used v_cvt_pk + v_lshlrev + v_or_b32_sdwa (4 VALU issues per dword: 96 of them per tile and wave in the dK/dV loop).
+// (pack2bf_scalar: the old form, kept for norm_rope_bwd_row in qfx_attn.hip -- see the note there)
+__device__ __forceinline__ uint32_t pack2bf_scalar(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 typedef __attribute__((ext_vector_type(2))) __bf16 qfx_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float qfx_f32x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+#if defined(QFX_PACK2BF_SCALAR)     // the 4-instruction form of rounds 1-3 (A/B lever)
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#else
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((qfx_f32x2){lo, hi}, qfx_bf16x2));
+#endif
 }
 
 // gelu(approximate="tanh"): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3), evaluated with the
