@@ -267,6 +267,56 @@ def test_cfg4_properties_at_1024sq_two_blocks():
     assert abs(l1 - l2) < 1e-5 * abs(l1) and lin < 1e-5 and g1.abs().max().item() > 0 and torch.isfinite(g1).all()
 
 
+def test_cfg4_step_is_bit_reproducible():
+    """Every arena tensor of two identical fused steps at the cfg #4 shape (two blocks, S = 8576: four-wave attention blocks, every
+    fused epilogue) comes out bit-identical when both start from a zeroed arena.  Only the flat LoRA gradient is exempt from the
+    bit test: the weight-gradient launches (and the scalar loss) add with fp32 atomics (order-dependent in the last bit): compared to 1e-5 / 1e-6.
+    Round 4: a codegen change made ~0.1 % of the 16-row fragments of the fused QK-norm backward irreproducible (tools/find_nondet.py
+    locates the launch); nothing else in the suite looks at run-to-run equality."""
+    from qflux_amd.modules import LoraConfig
+    from qflux_amd.trainer import QwenLoraTrainStep
+    hip = _qwen_full(2, None)
+    emb, noise, u = _emb_1024()
+    hip.add_adapter(LoraConfig(r=16, lora_alpha=16), "default", generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if "lora_B" in n:
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(9)).to(p.device) * 1e-2)
+    step = QwenLoraTrainStep(hip)
+    st = hip.lora_store
+    step.forward_backward(emb, noise=noise, u=u); step.zero_grad()
+    plan = list(hip._plans.values())[0]
+    tens, seen = [], set()
+
+    def flat(prefix, obj):
+        if isinstance(obj, torch.Tensor):
+            key = (obj.data_ptr(), obj.numel(), obj.dtype)
+            if obj.numel() and key not in seen:
+                seen.add(key); tens.append((prefix, obj))
+        elif isinstance(obj, dict):
+            for k, v in obj.items():
+                flat(f"{prefix}.{k}", v)
+        elif isinstance(obj, (list, tuple)):
+            for i, v in enumerate(obj):
+                flat(f"{prefix}[{i}]", v)
+    flat("A", plan.A)
+
+    def one():
+        for _, t in tens:
+            t.zero_()
+        loss = step.forward_backward(emb, noise=noise, u=u).item()
+        torch.cuda.synchronize()
+        sums = [int((t if t.is_contiguous() else t.contiguous()).view(torch.uint8).view(-1)[: t.numel() * t.element_size() // 8 * 8].view(torch.int64).sum().item())
+                for _, t in tens]
+        g = st.gflat.clone(); step.zero_grad()
+        return loss, sums, g
+    l1, s1, g1 = one()
+    l2, s2, g2 = one()
+    bad = [tens[i][0] for i in range(len(tens)) if s1[i] != s2[i]]
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and not bad, (l1, l2, bad[:6])      # (the loss is an atomic sum over blocks as well)
+    assert ((g1 - g2).abs().max() / g1.abs().max()).item() < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------- cfg #1 / #5
 FLUX_FULL = dict(patch_size=1, in_channels=64, out_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128,
                  num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,

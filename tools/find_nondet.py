@@ -6,6 +6,7 @@ import argparse, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
 ap = argparse.ArgumentParser(); ap.add_argument("--blocks", type=int, default=2); ap.add_argument("--passes", type=int, default=3)
+ap.add_argument("--res", type=int, default=1024, help="1024: cfg #4 (S = 8576); 512: the headline shape (S = 2432)")
 args = ap.parse_args()
 import test_fullsize_cfgs_gpu as T
 from qflux_amd.modules import LoraConfig
@@ -13,6 +14,11 @@ from qflux_amd.trainer import QwenLoraTrainStep
 from qflux_amd import ops
 hip = T._qwen_full(args.blocks, None)
 emb, noise, u = T._emb_1024()
+if args.res == 512:
+    g_ = torch.Generator().manual_seed(5)
+    emb = dict(image_latents=torch.randn(1, 1024, 64, generator=g_).half(), control_latents=torch.randn(1, 1024, 64, generator=g_).half(),
+               prompt_embeds=(torch.randn(1, 384, 3584, generator=g_) * 4).half(), prompt_embeds_mask=None, img_shapes=[[(1, 32, 32), (1, 32, 32)]])
+    noise = torch.randn(1, 1024, 64, generator=g_); u = torch.tensor([0.37])
 hip.add_adapter(LoraConfig(r=16, lora_alpha=16), "default", generator=torch.Generator().manual_seed(0))
 with torch.no_grad():
     for n, p in hip.named_parameters():
@@ -49,11 +55,26 @@ def sums():
     return out
 
 stream = torch.cuda.current_stream().cuda_stream
+FWD_TRACES = []
 def one_pass():
     for n, t in uniq:                  # identical leftovers: every arena tensor starts a pass zeroed
         t.zero_()
     packed, target, pe, t_in, S_t = step._prepare(emb, noise=noise, u=u) if hasattr(step, "_prepare") else (None,) * 5
-    pred = plan.run_forward(packed, pe, t_in)
+    A = plan.A
+    plan._copy_rows(A["in_img"].view(plan.B, plan.S_i, -1), packed)
+    A["in_txt"].view(plan.B, plan.T, -1).copy_(pe); A["t"].copy_(t_in.reshape(plan.B).float())
+    hip.refresh_lora_operands()
+    torch.cuda.synchronize()
+    ftrace = [sums()]
+    for ent in plan.fwd.calls:
+        fn, a = ent[0], ent[1]
+        if fn is None: a()
+        else: assert fn(*a, stream) == 0, fn.__name__
+        torch.cuda.synchronize()
+        ftrace.append(sums())
+    global FWD_TRACES
+    FWD_TRACES.append(ftrace)
+    pred = A["out"].view(plan.B, plan.S_i, -1)
     loss, dpred = ops.mse_loss_fwd_bwd(pred, target, S_t)
     plan._copy_rows(plan.A["dpred"].view(plan.B, plan.S_i, -1), dpred)
     hip._lora.ensure_grads(); st.gflat.zero_()
@@ -89,6 +110,14 @@ for ps in range(1, args.passes):
     name = "py" if ent[0] is None else ent[0].__name__ + ("@side" if len(ent) > 2 else "")
     print(f"pass {ps}: first difference after call #{first - 1} = {name}; tensors: {bad[:8]}")
 
+# ---- forward program: consecutive passes
+for ps in range(1, len(FWD_TRACES)):
+    a_, b_ = FWD_TRACES[ps - 1], FWD_TRACES[ps]
+    fd = next((i for i in range(1, len(a_)) if a_[i] != b_[i]), None)
+    if fd is None: print(f"forward pass {ps}: identical")
+    else:
+        ent = plan.fwd.calls[fd - 1]
+        print(f"forward pass {ps}: first difference after call #{fd - 1} = {'py' if ent[0] is None else ent[0].__name__}; tensors:", [uniq[j][0] for j in range(len(uniq)) if a_[fd][j] != b_[fd][j]][:6])
 # ---- where inside the offending tensors do two passes differ?
 if first is not None and bad:
     names = dict(uniq)
