@@ -12,9 +12,13 @@ for p in (ROOT, os.path.join(ROOT, "qwen-image-finetune_amd"), os.path.join(ROOT
         sys.path.insert(0, p)
 
 BF = torch.bfloat16
-# Step-parity bars of the tiny-model drivers (HIP path vs the bf16 oracle), ~2x the maxima observed over the whole -m gpu suite
-# (gpurun_out/parity_observed.json of the round-4 run is quoted in DESIGN.md section 4).
-LOSS_BAR, PRED_BAR, GRAD_BAR = 2e-2, 2e-2, 4e-2
+# Step-parity bars of the tiny-model drivers (HIP path vs the bf16 oracle): 2x the maxima observed over the whole -m gpu suite of
+# round 4 (profiles/r04_parity_observed.json: Qwen, 23 runs: loss 1.8e-4, prediction 7.4e-3, worst gradient 1.44e-2 of the tensor
+# maximum; FLUX, 18 runs: 2.7e-3, 1.13e-2, 3.75e-2), never looser than the round-3 bars (2e-2, 2e-2, 4e-2) -- the FLUX gradient
+# bar therefore stays at 4e-2, 1.07x its observed maximum.
+QWEN_BARS = (4e-4, 1.5e-2, 3e-2)     # loss, prediction, gradient
+FLUX_BARS = (6e-3, 2e-2, 4e-2)
+LOSS_BAR, PRED_BAR, GRAD_BAR = FLUX_BARS      # (the looser set: for callers that do not say which model)
 
 
 _OBSERVED = {}
@@ -132,7 +136,7 @@ def run_tiny_step_parity(device="cuda:0", verbose=False, cfg=None, shapes=((1, 4
                 worst, worst_name = e, n
     res["grad_rel_worst"], res["grad_worst_name"], res["grads_nonzero"] = worst, worst_name, nz
     _observe("qwen_tiny_step", res)
-    res["ok"] = bool(res["loss_rel"] < LOSS_BAR and res.get("pred_rel", 0.0) < PRED_BAR and worst < GRAD_BAR and nz == len(og) - dead)
+    res["ok"] = bool(res["loss_rel"] < QWEN_BARS[0] and res.get("pred_rel", 0.0) < QWEN_BARS[1] and worst < QWEN_BARS[2] and nz == len(og) - dead)
     if verbose:
         print(res)
     return res
@@ -205,7 +209,7 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
                 worst, worst_name = e, n
     res["grad_rel_worst"], res["grad_worst_name"], res["n_lora"] = worst, worst_name, len(og)
     _observe("flux_tiny_step", res)
-    res["ok"] = bool(res["loss_rel"] < LOSS_BAR and res.get("pred_rel", 0.0) < PRED_BAR and worst < GRAD_BAR and bad == 0)
+    res["ok"] = bool(res["loss_rel"] < FLUX_BARS[0] and res.get("pred_rel", 0.0) < FLUX_BARS[1] and worst < FLUX_BARS[2] and bad == 0)
     if verbose:
         print(res)
     return res
