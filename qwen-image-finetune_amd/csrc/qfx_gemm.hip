@@ -247,12 +247,21 @@ constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
 constexpr int QFX_NUM_CU = 256;                   // MI355X
 template <int BMT, int TN> struct TileCfg {
-  static constexpr bool WIDE = TN >= 256;           // 2-stage ring + streaming K loop
-  static constexpr int STAGE = (BMT + TN) * BK * 2;
+  static constexpr bool WIDE = TN >= 256;           // streaming K loop
+  // K depth of a ring stage.  The wide tile's operands are 64 KB per 64-deep K tile: two such stages hold ONE tile in flight.
+  // -DQFX_GEMM_WIDE_BK32 builds it with four 32-deep stages instead (32 KB each, three in flight, one barrier per 32 MFMAs and
+  // wave, 64-byte stage rows): measured 4 % SLOWER (148.0 -> 154.1 / 136.6 -> 142.4 us, profiles/r04_gemm_operand_stream.json) --
+  // the wide tile's loop period is not "DMA latency + transfer" after all; kept as an A/B lever.
+#if defined(QFX_GEMM_WIDE_BK32)
+  static constexpr int BKT = WIDE ? 32 : 64;
+#else
+  static constexpr int BKT = 64;
+#endif
+  static constexpr int STAGE = (BMT + TN) * BKT * 2;
 #if defined(QFX_GEMM_ABL_NST2)     // ablation: one K tile in flight on the narrow tiles too (how much of the K loop is DMA latency?)
   static constexpr int NST = 2;
 #else
-  static constexpr int NST = WIDE ? 2 : 3;
+  static constexpr int NST = WIDE ? (BKT == 32 ? 4 : 2) : 3;
 #endif
   static constexpr int WRN = (BMT == 256 && TN == 128) ? 4 : 2;     // compute waves along M
   static constexpr int WCN = 8 / WRN;               // ... along N
@@ -318,6 +327,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   static_assert(!(FP8 && !(BMT == 256 && TN == 128)), "the MX-FP8 instantiation uses the 256x128 tile (the streaming loops have no registers for 8-VGPR operands)");
   using TC = TileCfg<BMT, TN>;
   constexpr int STAGE_BYTES = TC::STAGE, NSTAGE = TC::NST, MI = TC::MI, NI = TC::NI, NG = TC::NG, NGRP = TC::NGRP;
+  constexpr int BKT = TC::BKT;     // K depth of a ring stage (64; 32 on the wide tile)
+  static_assert(!(FP8 && BKT != 64), "the MX-FP8 operands need 64-element (128-byte) stage rows");
   constexpr int WCOLS = 16 * NI;   // columns per compute wave
   __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];
   KGroupedArgs& ga = *(KGroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // == ga_by_value (sole explicit argument)
@@ -330,11 +341,14 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   if (w >= 8) {
     // ================================================================ loader waves
     const int lw = w - 8;
-    constexpr int NA = (BMT / 8) / NLD, NB = (TN / 8) / NLD;   // 1 KiB DMA pieces (8 rows x 128 B) per K tile per loader wave
-    static_assert(NLD % 2 == 0 && (BMT / 8) % NLD == 0 && (TN / 8) % NLD == 0 && NA + NB < 64, "loader split / vmcnt immediate");
-    const int srow = lane >> 3, schunk = lane & 7;
-    // source column incl. the bank swizzle chunk ^ ((row>>1)&7): the same for every piece of a loader wave (piece parity = lw & 1)
-    const int sc = (schunk ^ (((lw & 1) * 4 + (srow >> 1)) & 7)) * 8;     // (piece parity = lw & 1 for an even number of loader waves)
+    constexpr int CPR = BKT / 8, RPP = 64 / CPR;      // 16-byte chunks per stage row, rows per 1 KiB DMA piece (8 x 128 B or 16 x 64 B)
+    constexpr int NA = (BMT / RPP) / NLD, NB = (TN / RPP) / NLD;   // DMA pieces per K stage per loader wave
+    static_assert(NLD % 2 == 0 && (BMT / RPP) % NLD == 0 && (TN / RPP) % NLD == 0 && (NSTAGE - 1) * (NA + NB) < 64, "loader split / vmcnt immediate");
+    const int srow = lane / CPR, schunk = lane % CPR;
+    // source column incl. the bank swizzle, the same for every piece of a loader wave.  128-byte rows: chunk ^ ((row >> 1) & 7) (piece
+    // parity = lw & 1 for an even number of loader waves).  64-byte rows: chunk ^ (-(row >> 2) & 3) -- the four rows r, r+4, r+8, r+12
+    // that share a 64-byte slot of the 256-byte bank row then take four different chunks in every ds_read_b128 lane group.
+    const int sc = BKT == 64 ? (schunk ^ (((lw & 1) * 4 + (srow >> 1)) & 7)) * 8 : (schunk ^ ((0 - (srow >> 2)) & 3)) * 8;
     const bf16_t* pa[NA];
     const bf16_t* pb[NB];
     int ibid = blockIdx.x, it = 0, int1 = 0, intt = 0, ist = 0;
@@ -345,16 +359,16 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       int gi;
       tile_coord<BMT, TN>(ga, nwg, bid, gi, im0, in0);
       KArgs& p = ga.g[gi];
-      int1 = p.K1 / BK; intt = int1 + p.K2 / BK;
+      int1 = p.K1 / BKT; intt = int1 + p.K2 / BKT;
       iA2 = p.A2; iB2 = p.B2; ilda2 = p.lda2; ildb2 = p.ldb2; iM = p.M; iN = p.N;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        int gm = im0 + (lw + i * NLD) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
+        int gm = im0 + (lw + i * NLD) * RPP + srow; gm = gm < p.M ? gm : p.M - 1;
         pa[i] = p.A1 + remap_row(gm, p.rows_per_batch, p.a_batch_rows, p.a_row_off) * p.lda1 + sc;
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        int gn = in0 + (lw + i * NLD) * 8 + srow; gn = gn < p.N ? gn : p.N - 1;
+        int gn = in0 + (lw + i * NLD) * RPP + srow; gn = gn < p.N ? gn : p.N - 1;
         pb[i] = p.B1 + (int64_t)gn * p.ldb1 + sc;
       }
     };
@@ -363,18 +377,18 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       if (it == int1) {  // first K tile of the LoRA segment (A2 rows are never remapped)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          int gm = im0 + (lw + i * NLD) * 8 + srow; gm = gm < iM ? gm : iM - 1;
+          int gm = im0 + (lw + i * NLD) * RPP + srow; gm = gm < iM ? gm : iM - 1;
           pa[i] = iA2 + (int64_t)gm * ilda2 + sc;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          int gn = in0 + (lw + i * NLD) * 8 + srow; gn = gn < iN ? gn : iN - 1;
+          int gn = in0 + (lw + i * NLD) * RPP + srow; gn = gn < iN ? gn : iN - 1;
           pb[i] = iB2 + (int64_t)gn * ildb2 + sc;
         }
       }
       char* sA = smem + ist * STAGE_BYTES;
-      char* sB = sA + BMT * BK * 2;
-      const int koff = (it < int1 ? it : it - int1) * BK;
+      char* sB = sA + BMT * BKT * 2;
+      const int koff = (it < int1 ? it : it - int1) * BKT;
 #if defined(QFX_GEMM_ABL_HALF_DMA)   // ablation (results are garbage): every other DMA piece -- is the K loop bound by the L2 -> LDS stream?
 #pragma unroll
       for (int i = 0; i < NA; i += 2) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
@@ -395,18 +409,22 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     setp(ibid);
     int ahead = 0;  // K tiles issued and not yet handed over
     issue(); ++ahead;
-    if (more && NSTAGE > 2) { issue(); ++ahead; }    // a 2-stage ring holds one K tile ahead only
+#pragma unroll
+    for (int k = 2; k < NSTAGE; ++k)                 // an NSTAGE ring holds NSTAGE - 1 stages ahead
+      if (more) { issue(); ++ahead; }
     for (int wbid = blockIdx.x; wbid < nwg; wbid += gridDim.x) {
       int gi, m0, n0;
       tile_coord<BMT, TN>(ga, nwg, wbid, gi, m0, n0);
-      const int ntw = ga.g[gi].K1 / BK + ga.g[gi].K2 / BK;
+      const int ntw = ga.g[gi].K1 / BKT + ga.g[gi].K2 / BKT;
       for (int t = 0; t < ntw; ++t) {
-        // the oldest K tile in flight must have landed; the one issued after it (NA + NB pieces) may still be in flight
+        // the oldest K stage in flight must have landed; the ones issued after it (PPS pieces each) may still be in flight
 #if defined(QFX_GEMM_ABL_HALF_DMA)
-        if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NA + 1) / 2 + (NB + 1) / 2) : "memory");
+        constexpr int PPS = (NA + 1) / 2 + (NB + 1) / 2;
 #else
-        if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NA + NB) : "memory");
+        constexpr int PPS = NA + NB;
 #endif
+        if (NSTAGE > 3 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * PPS) : "memory");
+        else if (NSTAGE > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         --ahead;
@@ -441,7 +459,11 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     const int swl = (li >> 1) & 7;
     const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
     const int offB0 = BMT * BK * 2 + (wc * WCOLS + li) * (BK * 2) + ((g ^ swl) << 4);
-    const int nt1 = p.K1 / BK, nt2 = p.K2 / BK, nt = nt1 + nt2;
+    const int nt1 = p.K1 / BKT, nt2 = p.K2 / BKT, nt = nt1 + nt2;
+    // 64-byte stage rows (32-deep stages of the wide tile): chunk g of row li sits at g ^ (-(li >> 2) & 3), fragments are 1 KiB apart
+    const int sw32 = (0 - (li >> 2)) & 3;
+    const int offA32 = (wr * WROWS + li) * 64 + ((g ^ sw32) << 4);
+    const int offB32 = BMT * 64 + (wc * WCOLS + li) * 64 + ((g ^ sw32) << 4);
 
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -471,7 +493,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     auto pf = [&](int kt) {
       if constexpr (QFX_GEMM_PF_DIST > 0 && !FP8) {
         if (w < 2 && kt < nt1) {
-          asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pfp + kt * BK) : "memory");
+          asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pfp + kt * BKT) : "memory");
         }
       }
     };
@@ -637,6 +659,34 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+      }
+    } else if constexpr (BKT == 32) {
+      // wide tile, 32-deep stages: one k-step per stage; the NI B fragments stay resident, the MI A fragments pass through the
+      // three-deep register ring as below
+      for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + buf * STAGE_BYTES;
+        pf(t + QFX_GEMM_PF_DIST);
+        if (wave_dead) { buf = buf + 1 == NSTAGE ? 0 : buf + 1; continue; }   // see the narrow-tile loop
+        const char* pA = st + offA32;
+        const char* pB = st + offB32;
+        bf16x8 b[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8*)(pB + ni * 1024);
+        bf16x8 fa0 = *(const bf16x8*)(pA), fa1 = *(const bf16x8*)(pA + 1024), fa2;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if (mi + 2 < MI) fa2 = *(const bf16x8*)(pA + (mi + 2) * 1024);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], fa0, acc[mi][ni], 0, 0, 0);
+          fa0 = fa1; fa1 = fa2;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (mid_round && t == nt1 - 1) round_base();
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
       }
     } else {
       for (int t = 0; t < nt; ++t) {

@@ -1,0 +1,5 @@
+#!/bin/bash
+set -u
+R=$(pwd); mkdir -p gpurun_out; export PYTHONPATH=$R/qwen-image-finetune_amd:$R
+( timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "gemm or lora_linear" 2>&1 | tail -3 )
+timeout 600 python tools/step_ab.py bk64,bk32 --layers 6 --reps 5 --only gemm 2>&1 | grep "n=2\|n=6\|TOTAL\|SUM\|class"
