@@ -218,6 +218,10 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} not found: the gfx950 HIP library is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "at the repo root (needs hipcc). qflux_amd has no CPU / eager fallback by design.")
+    # torch FIRST: the PyTorch-ROCm wheel bundles its own libamdhip64 and libqfx.so's HIP dependency must resolve to THAT instance.
+    # Loaded before torch, libqfx.so pulls in the system runtime, the process ends up with two HIP runtimes and every launch on a
+    # torch stream fails with hipErrorNoDevice (seen when pytest's stale-library rebuild imported the package ahead of torch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -1033,3 +1033,17 @@ def test_ln_down_fused_matches_the_two_separate_launches(D, rows, R, rpb):
     assert ((u0 - u1).abs().max() / u0.abs().max()).item() < 2e-3
     assert ((e0 - e1).abs().max() / e0.abs().max()).item() < 8e-3
     assert mp == rows or u1[:, rows:].abs().max().item() == 0.0
+
+
+def test_package_import_before_torch_still_launches():
+    """`import qflux_amd` in a process that has not imported torch yet: the binding imports torch first so that libqfx.so binds to the
+    HIP runtime bundled with the PyTorch wheel (two runtimes in one process = hipErrorNoDevice on every launch; round 4)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import qflux_amd; from qflux_amd import ops; import torch; "
+            "a = torch.randn(256, 128, device='cuda').bfloat16(); b = torch.randn(256, 128, device='cuda').bfloat16(); "
+            "o = ops.gemm(a, b); torch.cuda.synchronize(); "
+            "assert (o.float() - a.float() @ b.float().t()).abs().max().item() < 0.5; print('OK')") % os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qwen-image-finetune_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-800:]

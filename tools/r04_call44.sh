@@ -1,0 +1,4 @@
+#!/bin/bash
+set -u
+R=$(pwd); mkdir -p gpurun_out; export PYTHONPATH=$R/qwen-image-finetune_amd:$R
+( timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q 2>&1 | tail -30 )
