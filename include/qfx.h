@@ -189,6 +189,12 @@ typedef struct qfx_lora_pack_args {
    * h*hl_dh + 32 ks + 16 db + 4 g + r) of the hi (sel = 0) / lo (sel = 1) split sits at
    *   ((((h * Rp/16 + j/16) * hl_dh/32 + ks) * 2 + sel) * 64 + 16 g + j%16) * 8 + 4 db + r        (bf16 elements). */
   uint16_t* A_hl; uint16_t* Bt_hl; int32_t hl_dh; int32_t reserved;
+  /* ABI 6 (optional, NULL = off): the A rows of this adapter inside the MFMA-FRAGMENT image of a row group that a fused
+   * LayerNorm + down projection reads (qfx_ln_down_args.W_fr): fr_nf = 16-row fragments of the whole group (q, k, v adapters
+   * of one stream: 3 Rp / 16), fr_row0 = first group row of this adapter.  Element (group row j, column k) of the hi split sits at
+   *   ((k/32 * fr_nf + j/16) * 64 + 16 * ((k%32)/8) + j%16) * 8 + k%8      (bf16 elements),
+   * the lo split fr_nf * 16 * K elements further: a fragment of 16 rows x 32 columns is ONE lane-linear 1 KiB piece. */
+  uint16_t* A_fr; int32_t fr_row0; int32_t fr_nf;
 } qfx_lora_pack_args;
 
 /* descs: DEVICE array of n descriptors (one per LoRA target); one launch packs them all. */
@@ -239,6 +245,10 @@ typedef struct qfx_ln_down_args {
   const uint16_t* W_hi; const uint16_t* W_lo; int64_t ldw; int32_t R;
   uint16_t* ext; int64_t ld_ext; uint16_t* Ut_hi; uint16_t* Ut_lo; int64_t ld_ut;
   int32_t group_R; int32_t group_stride;
+  /* ABI 6 (optional): the same weights in MFMA-fragment order (qfx_lora_pack_args.A_fr: hi image, lo image R * D elements further).
+   * Row-major weights are read as 16-byte pieces of 16 different rows per 16 lanes (64 line visits per wave load); the fragment image
+   * as 8 whole lines: 37.4 -> 30.3 us per launch at the headline shape.  NULL: W_hi / W_lo are read. */
+  const uint16_t* W_fr;
 } qfx_ln_down_args;
 int qfx_ln_down_fwd(const qfx_ln_down_args* list, int32_t n, void* stream);
 

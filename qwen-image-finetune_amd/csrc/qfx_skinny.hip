@@ -261,6 +261,12 @@ __global__ __launch_bounds__(512) void ln_down_kernel(const LnDownBatch batch_by
     wh[nf] = p.W_hi + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
     wl[nf] = p.W_lo + (int64_t)(nf * 16 + li) * p.ldw + 8 * g;
   }
+  // fragment image (block-uniform): fragment (ks, nf) is one lane-linear 1 KiB piece; row-major otherwise
+  const bf16_t* fr_h = p.W_fr ? p.W_fr + lane * 8 : nullptr;
+  const bf16_t* fr_l = p.W_fr ? fr_h + (int64_t)NF * 16 * D : nullptr;
+  auto ldw = [&](const bf16_t* rowp, const bf16_t* frp, int ks, int nf) {
+    return frp ? *(const bf16x8*)(frp + (ks * NF + nf) * 512) : *(const bf16x8*)(rowp + ks * 32);
+  };
   f32x4 acc[NF];
 #pragma unroll
   for (int j = 0; j < NF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512) void ln_down_kernel(const LnDownBatch batch_by
     const int ks = w + d * NW;
     if (ks < nks) {
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) { wr_h[d][nf] = *(const bf16x8*)(wh[nf] + ks * 32); wr_l[d][nf] = *(const bf16x8*)(wl[nf] + ks * 32); }
+      for (int nf = 0; nf < NF; ++nf) { wr_h[d][nf] = ldw(wh[nf], fr_h, ks, nf); wr_l[d][nf] = ldw(wl[nf], fr_l, ks, nf); }
     }
   }
 #pragma unroll
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(512) void ln_down_kernel(const LnDownBatch batch_by
     const int ksn = w + (i + DEPTH) * NW;
     if (i + DEPTH < CH && ksn < nks) {
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) { wr_h[i % DEPTH][nf] = *(const bf16x8*)(wh[nf] + ksn * 32); wr_l[i % DEPTH][nf] = *(const bf16x8*)(wl[nf] + ksn * 32); }
+      for (int nf = 0; nf < NF; ++nf) { wr_h[i % DEPTH][nf] = ldw(wh[nf], fr_h, ksn, nf); wr_l[i % DEPTH][nf] = ldw(wl[nf], fr_l, ksn, nf); }
     }
   }
 #pragma unroll
@@ -517,6 +523,11 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const qfx_lora_pack_args
           d.A_hi[(int64_t)j * d.ld_a + k] = hi;
           d.A_lo[(int64_t)j * d.ld_a + k] = lo;
           if (d.A_hl) { d.A_hl[hl_off(k, j, 0)] = hi; d.A_hl[hl_off(k, j, 1)] = lo; }
+          if (d.A_fr) {
+            const int ja = d.fr_row0 + j;
+            const int64_t o = ((int64_t)((k >> 5) * d.fr_nf + (ja >> 4)) * 64 + 16 * ((k >> 3) & 3) + (ja & 15)) * 8 + (k & 7);
+            d.A_fr[o] = hi; d.A_fr[(int64_t)d.fr_nf * 16 * d.K + o] = lo;
+          }
           ph |= (uint32_t)hi << (16 * e); pl |= (uint32_t)lo << (16 * e);
         }
         vh[q] = ph; vl[q] = pl;
@@ -626,6 +637,7 @@ extern "C" int qfx_ln_down_fwd(const qfx_ln_down_args* list, int32_t n, void* st
       R = a.R;
       if (a.ext && (a.group_R <= 0 || (a.R % a.group_R))) return QFX_EINVAL;
       if (a.Ut_hi && (!a.Ut_lo || a.ld_ut < a.ln.rows)) return QFX_EINVAL;
+      if ((uintptr_t)a.W_fr % 16) return QFX_EINVAL;
     }
     b.a[i] = a;
     b.start[i] = blocks;

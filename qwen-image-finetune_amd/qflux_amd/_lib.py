@@ -72,7 +72,7 @@ class LnFwdArgs(C.Structure):
 class LnDownArgs(C.Structure):
     _fields_ = [("ln", LnFwdArgs), ("W_hi", C.c_void_p), ("W_lo", C.c_void_p), ("ldw", C.c_int64), ("R", C.c_int32),
                 ("ext", C.c_void_p), ("ld_ext", C.c_int64), ("Ut_hi", C.c_void_p), ("Ut_lo", C.c_void_p), ("ld_ut", C.c_int64),
-                ("group_R", C.c_int32), ("group_stride", C.c_int32)]
+                ("group_R", C.c_int32), ("group_stride", C.c_int32), ("W_fr", C.c_void_p)]
 
 
 class LnBwdArgs(C.Structure):
@@ -98,6 +98,7 @@ class LoraPackArgs(C.Structure):
         ("WeT", C.c_void_p), ("ld_wet", C.c_int64),
         ("Rp", C.c_int32), ("Kext", C.c_int32),
         ("A_hl", C.c_void_p), ("Bt_hl", C.c_void_p), ("hl_dh", C.c_int32), ("reserved", C.c_int32),
+        ("A_fr", C.c_void_p), ("fr_row0", C.c_int32), ("fr_nf", C.c_int32),
     ]
 
 
@@ -260,4 +261,19 @@ def head_fragment_image(hi, lo, dh):
     for sel, t in ((0, hi), (1, lo)):
         off = ((base + sel) * 64 + 16 * g + j % 16) * 8 + 4 * db + r
         img[off.reshape(-1)] = t.reshape(-1)
+    return img
+
+
+def down_fragment_image(hi, lo):
+    """MFMA-fragment order of a [R, K] bf16 hi / lo split (include/qfx.h, qfx_lora_pack_args.A_fr): what qfx_lora_pack writes for
+    qfx_ln_down_args.W_fr.  Layout statement for tests -- the training path's images come from qfx_lora_pack."""
+    import torch
+    R, K = hi.shape
+    assert R % 16 == 0 and K % 32 == 0
+    j = torch.arange(R, device=hi.device).view(R, 1)
+    k = torch.arange(K, device=hi.device).view(1, K)
+    off = (((k // 32) * (R // 16) + j // 16) * 64 + 16 * ((k % 32) // 8) + j % 16) * 8 + k % 8
+    img = torch.zeros(2 * R * K, dtype=hi.dtype, device=hi.device)
+    img[off.reshape(-1)] = hi.reshape(-1)
+    img[R * K + off.reshape(-1)] = lo.reshape(-1)
     return img

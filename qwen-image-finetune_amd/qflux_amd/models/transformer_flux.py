@@ -518,7 +518,7 @@ class _FluxPlan(_QwenPlan):
         q2 = bb["qkv"].view(M, 3 * D)
         sqk2 = bb["sqk"].view(M, 2 * D)
         fused = grp is not None and self._ln_down(p, [(self._ln_fwd_args(x, mod[:, 0:D], mod[:, D:2 * D], 3 * D, xm, M, D, S, eps),
-                                                       dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"], Ut=bb["Uqkv"],
+                                                       dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], W_fr=grp.get("A_fr"), ldw=D, R=3 * grp["Rp"], Ut=bb["Uqkv"],
                                                             ext=A["ext3_j"], ld_ext=A["ext3_j"].stride(0), group_R=grp["Rp"],
                                                             group_stride=grp["Kext"]))])
         if not fused:

@@ -98,7 +98,7 @@ class _Cfg:
 # prepared device-side weights
 # ----------------------------------------------------------------------------------------------
 class _LoraW:
-    __slots__ = ("mod", "r", "Rp", "Kext", "scale", "A_hi", "A_lo", "Bt_hi", "Bt_lo", "We", "WeT", "gA", "gB", "A_hl", "Bt_hl", "hl_dh")
+    __slots__ = ("mod", "r", "Rp", "Kext", "scale", "A_hi", "A_lo", "Bt_hi", "Bt_lo", "We", "WeT", "gA", "gB", "A_hl", "Bt_hl", "hl_dh", "A_fr", "fr_row0", "fr_nf")
 
 
 class _LinW:
@@ -525,13 +525,16 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
             WeT = torch.zeros(D, 3 * Kext, dtype=BF, device=dev)
         else:
             WeT = WeT(Kext)
-        w[prefix + "qkv_lora"] = dict(Rp=Rp, Kext=Kext, A_hi=A_hi, A_lo=A_lo, WeT=WeT, present=[isinstance(m, QfxLoraLinear) for m in mods])
+        # the same rows in MFMA-fragment order for the fused LayerNorm + down projection (qfx_ln_down_args.W_fr): [hi image | lo image]
+        A_fr = torch.zeros(2 * 3 * Rp * D, dtype=BF, device=dev) if (D % 32 == 0 and os.environ.get("QFX_LN_DOWN_FRAG", "1") != "0") else None
+        w[prefix + "qkv_lora"] = dict(Rp=Rp, Kext=Kext, A_hi=A_hi, A_lo=A_lo, A_fr=A_fr, WeT=WeT, present=[isinstance(m, QfxLoraLinear) for m in mods])
         md = 1
         for sec, (m, lw) in enumerate(zip(mods, w[prefix + "qkv"])):
             if not isinstance(m, QfxLoraLinear):
                 continue
             lo = self._make_lora(m, Rp, Kext, A_hi[sec * Rp:(sec + 1) * Rp], A_lo[sec * Rp:(sec + 1) * Rp],
                                  WeT[:, sec * Kext:(sec + 1) * Kext], dev, hl=hl)
+            lo.A_fr, lo.fr_row0, lo.fr_nf = A_fr, sec * Rp, 3 * Rp // 16
             lw.lora = lo
             descs.append(self._pack_desc(lo))
             md = max(md, lw.N, lw.K)
@@ -570,6 +573,7 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         lo.A_hl = torch.zeros(2 * Rp * K, dtype=BF, device=dev) if hl == "A" else None
         lo.Bt_hl = torch.zeros(2 * Rp * N, dtype=BF, device=dev) if hl == "Bt" else None
         lo.hl_dh = self.config.attention_head_dim
+        lo.A_fr, lo.fr_row0, lo.fr_nf = None, 0, 0
         st = self._lora
         oa, ob = st.offset_of(m.A), st.offset_of(m.B)
         lo.gA = st.gflat[oa:oa + m.A.numel()]
@@ -590,6 +594,8 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         d.A_hl = lo.A_hl.data_ptr() if lo.A_hl is not None else None
         d.Bt_hl = lo.Bt_hl.data_ptr() if lo.Bt_hl is not None else None
         d.hl_dh = lo.hl_dh
+        d.A_fr = lo.A_fr.data_ptr() if lo.A_fr is not None else None
+        d.fr_row0, d.fr_nf = lo.fr_row0, lo.fr_nf
         return d
 
     def refresh_lora_operands(self):
@@ -1165,6 +1171,7 @@ class _QwenPlan:
             if d is not None:
                 a = arr[i]
                 a.W_hi, a.W_lo, a.ldw, a.R = _ptr(d["W_hi"]), _ptr(d["W_lo"]), d["ldw"], d["R"]
+                a.W_fr = _ptr(d.get("W_fr"))
                 a.ext, a.ld_ext = _ptr(d["ext"]), d["ld_ext"]
                 a.Ut_hi, a.Ut_lo, a.ld_ut = _ptr(d["Ut"][0]), _ptr(d["Ut"][1]), d["Ut"][0].stride(0)
                 a.group_R, a.group_stride = d.get("group_R", d["R"]), d.get("group_stride", 0)
@@ -1349,7 +1356,7 @@ class _QwenPlan:
                 if pq_ is not None:
                     ln.yq, ln.ys, ln.ldyq, ln.ys_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
                 lnl.append(ln)
-                ents.append((ln, None if grp is None else dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], ldw=D, R=3 * grp["Rp"],
+                ents.append((ln, None if grp is None else dict(W_hi=grp["A_hi"], W_lo=grp["A_lo"], W_fr=grp.get("A_fr"), ldw=D, R=3 * grp["Rp"],
                                                                Ut=bb["Uqkv." + s], ext=A["ext3"][s], ld_ext=A["ext3"][s].stride(0),
                                                                group_R=grp["Rp"], group_stride=grp["Kext"])))
             # LayerNorm+modulate and the q/k/v down projection of its output in ONE pass over the row block (qfx_ln_down_fwd)

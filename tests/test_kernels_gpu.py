@@ -479,10 +479,16 @@ def test_lora_pack():
     # ABI 6: the head-fragment images of both operands (head dim 64: K = 2 heads, N = 3 heads)
     A_hl = torch.full((2 * Rp * K,), 7.0, dtype=BF, device=DEV); Bt_hl = torch.full((2 * Rp * N,), 7.0, dtype=BF, device=DEV)
     d.A_hl, d.Bt_hl, d.hl_dh = A_hl.data_ptr(), Bt_hl.data_ptr(), 64
+    # ... and the A rows inside the fragment image of a 3-adapter row group (this adapter = rows Rp .. 2 Rp of it)
+    A_fr = torch.zeros(2 * 3 * Rp * K, dtype=BF, device=DEV)
+    d.A_fr, d.fr_row0, d.fr_nf = A_fr.data_ptr(), Rp, 3 * Rp // 16
     t = ops.pack_descs_tensor([d], DEV)
     ops.lora_pack(t, 1, max(K, N))
     torch.cuda.synchronize()
     assert torch.equal(A_hl, L.head_fragment_image(A_hi, A_lo, 64)) and torch.equal(Bt_hl, L.head_fragment_image(Bt_hi, Bt_lo, 64))
+    g_hi = torch.zeros(3 * Rp, K, dtype=BF, device=DEV); g_lo = torch.zeros_like(g_hi)
+    g_hi[Rp:2 * Rp], g_lo[Rp:2 * Rp] = A_hi, A_lo
+    assert torch.equal(A_fr, L.down_fragment_image(g_hi, g_lo))
     Ap = torch.zeros(Rp, K); Ap[:r] = A.cpu()
     Bp = torch.zeros(Rp, N); Bp[:r] = s * Bm.cpu().t()
     check("pack_A", A_hi.float() + A_lo.float(), Ap, 1e-4)
@@ -999,7 +1005,8 @@ def test_ln_down_fused_matches_the_two_separate_launches(D, rows, R, rpb):
     gR, gS = (16, 64) if R == 48 else (R, 0)
     mp = (rows + 127) // 128 * 128
     outs = []
-    for fused in (False, True):
+    w_fr = L.down_fragment_image(a_hi, a_lo)      # ABI 6: the same weights in MFMA-fragment order
+    for fused in (False, True, "fragment image"):
         y = torch.empty(rows, D, dtype=BF, device=DEV)
         ext = torch.zeros(rows, 3 * 64, dtype=BF, device=DEV)
         ut = (torch.zeros(R, mp, dtype=BF, device=DEV), torch.zeros(R, mp, dtype=BF, device=DEV))
@@ -1017,6 +1024,8 @@ def test_ln_down_fused_matches_the_two_separate_launches(D, rows, R, rpb):
                 a.ln.rows, a.ln.D, a.ln.rows_per_batch, a.ln.eps = rows, D, rpb, 1e-6
                 if adapted:
                     a.W_hi, a.W_lo, a.ldw, a.R = a_hi.data_ptr(), a_lo.data_ptr(), D, R
+                    if fused == "fragment image":
+                        a.W_fr = w_fr.data_ptr()
                     a.ext, a.ld_ext = ext.data_ptr(), ext.stride(0)
                     a.Ut_hi, a.Ut_lo, a.ld_ut = ut[0].data_ptr(), ut[1].data_ptr(), mp
                     a.group_R, a.group_stride = gR, gS
@@ -1025,7 +1034,8 @@ def test_ln_down_fused_matches_the_two_separate_launches(D, rows, R, rpb):
             assert torch.equal(y, y2)
         torch.cuda.synchronize()
         outs.append((y.float().cpu(), ext.float().cpu(), ut[0].float().cpu() + ut[1].float().cpu()))
-    (y0, e0, u0), (y1, e1, u1) = outs
+    (y0, e0, u0), (y1, e1, u1), (y2_, e2, u2) = outs
+    assert torch.equal(y1, y2_) and torch.equal(e1, e2) and torch.equal(u1, u2)      # the fragment image changes the loads, not a bit of the result
     # y: same rounding points; the fp32 row statistics are summed in another order -> at most one bf16 ulp on rare elements
     ny = (y0 != y1).float().mean().item()
     assert ny < 2e-3 and ((y0 - y1).abs().max() / y0.abs().max()).item() < 1e-2, ny
