@@ -9,6 +9,7 @@ from step_ab import load_variant
 from qflux_amd import ops, _lib as L
 ap = argparse.ArgumentParser(); ap.add_argument("variants"); ap.add_argument("--entry", default="fwd,dq,dkv"); ap.add_argument("--S", default="2432,8576")
 ap.add_argument("--hl", type=int, default=0, help="rank of a fused out-projection down projection (qfx_head_lora slot 0, forward only); names ending in '-' run without it")
+ap.add_argument("--qk", action="store_true", help="fused QK-norm / RoPE backward epilogues (qk_saved) in dq / dkv; names ending in '-' run without it")
 args = ap.parse_args()
 names = args.variants.split(",")
 libs = {n: load_variant(n.rstrip("-")) for n in names}
@@ -39,6 +40,15 @@ for Sspec in args.S.split(","):      # "S" or "S:H" (heads; 24 by default)
             wts = [L.head_fragment_image(wts[0], wts[1], dh), L.head_fragment_image(wts[2], wts[3], dh)]
             hl.w_pk[0], hl.w_pk[1] = (t.data_ptr() for t in wts)
             a._keep = (wts, part)
+        if args.qk and not n.endswith("-"):
+            sqk = torch.randn(Bn, S, 2 * D, device=DEV).to(BF)
+            ang = torch.rand(S, dh // 2, device=DEV) * 6.28
+            rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+            ws = [(1 + 0.1 * torch.randn(dh, device=DEV)).to(BF) for _ in range(4)]
+            a.qk_saved, a.ld_saved, a.rope, a.rope_bstride = sqk.data_ptr(), 2 * D, rope.data_ptr(), 0
+            a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = (t.data_ptr() for t in ws)
+            a.T, a.norm_flags, a.norm_eps = 384, 0, 1e-6
+            a._keep2 = (sqk, rope, ws)
         bufs[n] = (a, O, lse2, dsum, dqkv)
     st = torch.cuda.current_stream().cuda_stream
     for ent in args.entry.split(","):
