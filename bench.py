@@ -387,7 +387,9 @@ def main():
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(gemm_bytes_of(plan.fwd, plan.bwd) / n_launch),
                      "launches_per_step": n_launch, "avg_launch_us": round(gemm_ms * 1e3 / n_launch, 2),
-                     "gemm_share_of_step": round(gemm_ms / ms_per_step, 3)},
+                     "gemm_share_of_step": round(gemm_ms / ms_per_step, 3),
+                     # round 4: what actually limits these launches (ablations, not this run): the loaders' L2 -> LDS operand stream
+                     "measured_limiter": "L2->LDS operand stream: 92 % of a launch remains with the matrix pipe idle (profiles/r04_gemm_operand_stream.json); priced against the MFMA peak as the contract asks"},
         # the bandwidth-bound kernels of the same replayed step (serial replay: the weight-gradient launches are timed alone here,
         # in the step they overlap the main stream): algorithmic bytes / summed launch time against the 8 TB/s HBM3E peak
         "hbm_kernels": {k: {"GBps": round(v[1] / (sum(a.elapsed_time(b) for a, b in v[0]) * 1e-3) / 1e9, 1),
