@@ -12,6 +12,7 @@
 //
 // lse2 is the log2-domain logsumexp of (scale * q.k + mask): P = exp2(scale*log2e * s + mask*log2e - lse2).
 #include "qfx_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -852,6 +853,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
 // the 256 CUs clearly better (S = 2432: 240 blocks = 94 % vs 456 blocks on 512 half-CU slots = 89 %: 669 -> 710 TF/s).  The dQ
 // kernel measured slower with 8 waves in both cases and always uses 4.
 int pick_waves(const qfx_attn_args* a) {
+  static const int forced = [] { const char* e = getenv("QFX_ATTN_FWD_WAVES"); return e ? atoi(e) : 0; }();   // A/B lever: 4 or 8
+  if (forced == 4 || forced == 8) return forced;
   const long hb = (long)a->H * a->B;
   const long b4 = (long)((a->S + 127) / 128) * hb, b8 = (long)((a->S + 255) / 256) * hb;
   const double e4 = (double)b4 / (double)(((b4 + 511) / 512) * 512), e8 = (double)b8 / (double)(((b8 + 255) / 256) * 256);
