@@ -459,15 +459,17 @@ __global__ __launch_bounds__(256) void lora_head_reduce_kernel(const HeadReduceB
   if (m >= p.M) return;
   const int64_t jrow = remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off);
   const float* src = p.part + jrow * p.ld_part + j;
-  // eight slabs requested at a time (independent loads), added in head order: a one-load-per-iteration loop is H dependent L2
-  // round trips (24 us per launch at H = 24 -- more than the qfx_lora_down launch this replaces)
+  // 24 slabs requested at a time (independent loads: ONE L2 round trip for the DiT's 24 heads), added in head order: a
+  // one-load-per-iteration loop is H dependent round trips (24 us per launch at H = 24 -- more than the qfx_lora_down launch this
+  // replaces), eight at a time three
+  constexpr int HC = 24;
   float v = 0.f;
-  for (int h0 = 0; h0 < p.H; h0 += 8) {
-    float t[8];
+  for (int h0 = 0; h0 < p.H; h0 += HC) {
+    float t[HC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = h0 + i < p.H ? src[(int64_t)(h0 + i) * p.part_hstride] : 0.f;
+    for (int i = 0; i < HC; ++i) t[i] = h0 + i < p.H ? src[(int64_t)(h0 + i) * p.part_hstride] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v += t[i];
+    for (int i = 0; i < HC; ++i) v += t[i];
   }
   const bf16_t hi = f2bf(v);
   const bf16_t lo = f2bf(v - bf2f(hi));
