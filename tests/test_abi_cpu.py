@@ -138,3 +138,33 @@ def test_pos_embed_stand_in_matches_pinned_tables():
         assert vid.dtype == torch.complex64 and vid.shape == v0.shape and txt.shape == t0.shape
         assert torch.equal(vid, v0) and torch.equal(txt, t0)
     assert not [k for k in vars(pe) if isinstance(getattr(pe, k), torch.Tensor)]
+
+
+def test_fragment_image_layout_statements():
+    """The two weight layouts the ABI-6 kernels read (include/qfx.h: qfx_lora_pack_args.A_hl / Bt_hl and A_fr) as the header states
+    them, element by element, on the CPU: the torch helpers the GPU tests compare qfx_lora_pack against are themselves checked
+    against the formulas of the header here."""
+    import torch
+    from qflux_amd import _lib as L
+    BF = torch.bfloat16
+    Rp, dh, H = 32, 64, 3
+    hi = torch.arange(Rp * H * dh, dtype=torch.float32).reshape(Rp, H * dh).to(BF)
+    lo = (hi.float() * 0.5).to(BF)
+    img = L.head_fragment_image(hi, lo, dh)
+    assert img.numel() == 2 * Rp * H * dh
+    for (j, c) in ((0, 0), (17, 5), (31, H * dh - 1), (9, 2 * dh + 37)):
+        h, dd = divmod(c, dh)
+        ks, db, g, r = dd // 32, (dd // 16) % 2, (dd // 4) % 4, dd % 4
+        for sel, t in ((0, hi), (1, lo)):
+            off = ((((h * (Rp // 16) + j // 16) * (dh // 32) + ks) * 2 + sel) * 64 + 16 * g + j % 16) * 8 + 4 * db + r
+            assert img[off] == t[j, c], (j, c, sel)
+    R, K = 48, 256
+    a = torch.arange(R * K, dtype=torch.float32).reshape(R, K).to(BF)
+    b = (a.float() + 0.25).to(BF)
+    fr = L.down_fragment_image(a, b)
+    for (j, k) in ((0, 0), (16, 33), (47, 255), (23, 100)):
+        off = ((k // 32 * (R // 16) + j // 16) * 64 + 16 * ((k % 32) // 8) + j % 16) * 8 + k % 8
+        assert fr[off] == a[j, k] and fr[R * K + off] == b[j, k], (j, k)
+    # a fragment (16 rows x 32 columns) is one contiguous 512-element piece
+    piece = fr[(3 * (R // 16) + 1) * 512:(3 * (R // 16) + 2) * 512].reshape(64, 8)      # k-step 3, row group 1
+    assert torch.equal(piece[16 * 2 + 5], a[16 + 5, 96 + 16:96 + 24])                       # lane (g = 2, li = 5)
