@@ -547,22 +547,25 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ 
   constexpr int LPI = DH / 8;        // lanes per (token, q|k, head) item
   constexpr int IPB = 256 / LPI;     // items per block
   const int sub = threadIdx.x % LPI;
-  const int64_t item = (int64_t)blockIdx.x * IPB + threadIdx.x / LPI;
-  const int64_t nitems = (int64_t)B * S * 2 * H;
+  // item -> (token, q | k, head) in 32-bit arithmetic with TWO divisions (the launcher checks B * S * 2 * H < 2^31): the 64-bit
+  // divisions and remainders of rounds 1-3 were most of this kernel's VALU work (VALUBusy 52 % for an HBM-bound pass)
+  const unsigned item = blockIdx.x * IPB + threadIdx.x / LPI;
+  const unsigned nitems = (unsigned)B * S * 2 * H;
   const bool valid = item < nitems;
-  const int64_t it = valid ? item : nitems - 1;
-  const int64_t token = it / (2 * H);
-  const int rem = (int)(it % (2 * H));
-  const int which = rem / H, h = rem % H;
-  const int s = (int)(token % S);
+  const unsigned it = valid ? item : nitems - 1;
+  const unsigned token = it / (unsigned)(2 * H);
+  const int rem = (int)(it - token * (unsigned)(2 * H));
+  const int which = rem >= H ? 1 : 0, h = rem - which * H;
+  const unsigned bidx = token / (unsigned)S;
+  const int s = (int)(token - bidx * (unsigned)S);
   const int Dm = H * DH;
-  bf16_t* px = qkv + token * 3 * Dm + which * Dm + h * DH + sub * 8;
-  bf16_t* ps = saved ? saved + token * 2 * Dm + which * Dm + h * DH + sub * 8 : nullptr;
+  bf16_t* px = qkv + (int64_t)token * 3 * Dm + which * Dm + h * DH + sub * 8;
+  bf16_t* ps = saved ? saved + (int64_t)token * 2 * Dm + which * Dm + h * DH + sub * 8 : nullptr;
   const bf16_t* wsel = (s < T) ? (which ? wk_txt : wq_txt) : (which ? wk_img : wq_img);
   float w[8], cs[8];
   ld8(wsel + sub * 8, w);
   {
-    const float* rp = rope + (token / S) * rope_bs + ((int64_t)s * (DH / 2) + sub * 4) * 2;
+    const float* rp = rope + (int64_t)bidx * rope_bs + ((int64_t)s * (DH / 2) + sub * 4) * 2;
     const f32x4 c0 = *(const f32x4*)(rp);
     const f32x4 c1 = *(const f32x4*)(rp + 4);
     cs[0] = c0[0]; cs[1] = c0[1]; cs[2] = c0[2]; cs[3] = c0[3];
@@ -1123,6 +1126,7 @@ static int launch_qk(bool bwd, uint16_t* qkv, uint16_t* saved, const float* rope
   if (!qkv || !rope || !wq_txt || !wk_txt || !wq_img || !wk_img || B <= 0 || S <= 0 || T < 0 || T > S || H <= 0) return QFX_EINVAL;
   if (bwd && !saved) return QFX_EINVAL;
   const int64_t nitems = (int64_t)B * S * 2 * H;
+  if (nitems >= (1LL << 31) - 64) return QFX_EUNSUPPORTED;      // the kernel indexes items in 32 bits
   hipStream_t s = (hipStream_t)stream;
   if (dh == 128) {
     const int ipb = 256 / 16;
