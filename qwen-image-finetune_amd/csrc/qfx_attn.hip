@@ -99,6 +99,38 @@ __device__ __forceinline__ void attn_block_coord(int nx, int H, int& xb, int& h,
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Bisection levers for the run-to-run differences of the fused dQ epilogue (tools/nondet_bisect.py, profiles/r05_nondeterminism.md):
+// -DQFX_NRB_PACK1 = one-instruction packing in norm_rope_bwd_row; -DQFX_NRB_FENCE=<bitmask> = 32 idle states + a scheduling barrier
+// at point <bit> of the epilogue.  Both off in the product build.
+#ifndef QFX_NRB_FENCE
+#define QFX_NRB_FENCE 0
+#endif
+#ifndef QFX_NRB_NOPS
+#define QFX_NRB_NOPS 1
+#endif
+#ifndef QFX_NRB_OPQ
+// bitmask: make a group of intermediates opaque to the SLP vectoriser (no v_pk_*_f32 across it); zero instructions.  Bit 0 (the
+// products acc * out_scale) is ON in the product build: it is the one group whose packed form was needed for the run-to-run
+// differences of round 4 (profiles/r05_nondeterminism.md: 11 / 11 launches differ with it packed, 0 / 11 and 0 / 15 with it opaque;
+// -fno-slp-vectorize likewise 0 / 15) -- the packed v_pk_mul_f32 vdst, s[scale:scale+1], v[accumulator pair] read MFMA accumulator
+// pairs directly.
+#define QFX_NRB_OPQ 1
+#endif
+#define NRB_OPQ4(bit, a, b, c, d)                                                          \
+  do {                                                                                     \
+    if constexpr (((QFX_NRB_OPQ) >> (bit)) & 1) {                                          \
+      asm volatile("" : "+v"(a)); asm volatile("" : "+v"(b)); asm volatile("" : "+v"(c)); asm volatile("" : "+v"(d)); \
+    }                                                                                      \
+  } while (0)
+#define NRB_FENCE(bit)                                                  \
+  do {                                                                  \
+    if constexpr (((QFX_NRB_FENCE) >> (bit)) & 1) {                     \
+      __builtin_amdgcn_sched_barrier(0);                                \
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                \
+      __builtin_amdgcn_sched_barrier(0);                                \
+    }                                                                   \
+  } while (0)
+
 // Rank-r down projection of ONE 16-row fragment held in the accumulator layout (ABI 6, qfx_head_lora): lane (g, li) owns row li,
 // x[d] = the packed bf16 pairs of columns 16 d + 4 g + {0,1 | 2,3} of this head's dh columns -- exactly what the epilogues store.
 //   part[h][row][c0 + j] = sum_n x[row][n] * (W_hi + W_lo)[j][h*dh + n]
@@ -110,6 +142,7 @@ template <int DH>
 __device__ __forceinline__ void head_lora_frag(const qfx_head_lora& hl, int h, int T, int frow, int64_t jrow, bool row_ok,
                                                const u32x2 (&x)[DH / 16], int g, int li) {
   if (hl.part == nullptr) return;                                  // block-uniform
+  NRB_FENCE(7);
   const bf16_t* wp = hl.w_pk[frow >= T ? 0 : 1];                   // wave-uniform
   if (wp == nullptr) return;
   constexpr int KS = DH / 32;
@@ -144,8 +177,10 @@ __device__ __forceinline__ void store_frag(bf16_t* rowp, const u32x2 (&u)[DH / 1
     const int c0 = 16 * (g & 1) + 4 * (g & 2);
 #pragma unroll
     for (int p = 0; p < DH / 32; ++p) {
+      NRB_FENCE(5);
       const auto s0 = __builtin_amdgcn_permlane16_swap(u[2 * p][0], u[2 * p + 1][0], false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(u[2 * p][1], u[2 * p + 1][1], false, false);
+      NRB_FENCE(6);
       if (ok) *(u32x4*)(rowp + 32 * p + c0) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
     }
   } else if (ok) {
@@ -409,11 +444,13 @@ __device__ __forceinline__ void norm_rope_bwd_row(const f32x4 (&acc)[DH / 16][2]
   constexpr int DF = DH / 16;
   float xh[DF][4], dn[DF][4];
   float ss = 0.f;
+  NRB_FENCE(0);
 #pragma unroll
   for (int d = 0; d < DF; ++d) {
     const u32x2 ux = *(const u32x2*)(xrow + d * 16);
     xh[d][0] = __uint_as_float(ux[0] << 16); xh[d][1] = __uint_as_float(ux[0] & 0xffff0000u);
     xh[d][2] = __uint_as_float(ux[1] << 16); xh[d][3] = __uint_as_float(ux[1] & 0xffff0000u);
+    NRB_OPQ4(4, xh[d][0], xh[d][1], xh[d][2], xh[d][3]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ss += xh[d][r] * xh[d][r];
   }
@@ -421,36 +458,66 @@ __device__ __forceinline__ void norm_rope_bwd_row(const f32x4 (&acc)[DH / 16][2]
   ss += __shfl_xor(ss, 32);
   const float rstd = rsqrtf(ss / (float)DH + eps);
   float dot = 0.f;
+  NRB_FENCE(1);
 #pragma unroll
   for (int d = 0; d < DF; ++d) {
     const f32x4 cs = *(const f32x4*)(rrow + d * 16);            // (cos, sin) of the pairs (16 d + 4 g)/2 and +1
     const u32x2 uw = *(const u32x2*)(wrow + d * 16);
     const float w0 = __uint_as_float(uw[0] << 16), w1 = __uint_as_float(uw[0] & 0xffff0000u);
     const float w2 = __uint_as_float(uw[1] << 16), w3 = __uint_as_float(uw[1] & 0xffff0000u);
-    const float e0 = rbf(acc[d][f][0] * out_scale), e1 = rbf(acc[d][f][1] * out_scale);
-    const float e2 = rbf(acc[d][f][2] * out_scale), e3 = rbf(acc[d][f][3] * out_scale);
-    const float d0 = rbf(e0 * cs[0] + e1 * cs[1]), d1 = rbf(-e0 * cs[1] + e1 * cs[0]);     // dy * conj(f)
-    const float d2 = rbf(e2 * cs[2] + e3 * cs[3]), d3 = rbf(-e2 * cs[3] + e3 * cs[2]);
+    float e0 = rbf(acc[d][f][0] * out_scale), e1 = rbf(acc[d][f][1] * out_scale);
+    float e2 = rbf(acc[d][f][2] * out_scale), e3 = rbf(acc[d][f][3] * out_scale);
+    NRB_OPQ4(0, e0, e1, e2, e3);
+    float d0 = rbf(e0 * cs[0] + e1 * cs[1]), d1 = rbf(-e0 * cs[1] + e1 * cs[0]);     // dy * conj(f)
+    float d2 = rbf(e2 * cs[2] + e3 * cs[3]), d3 = rbf(-e2 * cs[3] + e3 * cs[2]);
+    NRB_OPQ4(1, d0, d1, d2, d3);
     dn[d][0] = (flags & 1) ? d0 * w0 : rbf(d0 * w0);
     dn[d][1] = (flags & 1) ? d1 * w1 : rbf(d1 * w1);
     dn[d][2] = (flags & 1) ? d2 * w2 : rbf(d2 * w2);
     dn[d][3] = (flags & 1) ? d3 * w3 : rbf(d3 * w3);
+    NRB_OPQ4(2, dn[d][0], dn[d][1], dn[d][2], dn[d][3]);
+    if constexpr (((QFX_NRB_FENCE) >> 9) & 1) {
+      asm volatile("s_nop 1" : "+v"(dn[d][0]), "+v"(dn[d][1]), "+v"(dn[d][2]), "+v"(dn[d][3]));
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { xh[d][r] *= rstd; dot += dn[d][r] * xh[d][r]; }
+    NRB_OPQ4(3, xh[d][0], xh[d][1], xh[d][2], xh[d][3]);
   }
+  NRB_FENCE(2);
   dot += __shfl_xor(dot, 16);
   dot += __shfl_xor(dot, 32);
   dot /= (float)DH;
+  NRB_FENCE(3);
+  // pack2bf_scalar, not pack2bf (round 4), and QFX_NRB_OPQ bit 0 (round 5).  With the one-instruction packing, hipcc's SLP vectoriser
+  // re-shapes the whole function into v_pk_*_f32 pairs, and the dQ kernel then came out different from run to run: in ~0.3 % of the
+  // 16-row fragments ONE column -- an odd r of lane group g = 3, i.e. the HIGH register of a packed pair, lanes 48-63 -- is wrong in
+  // all 16 rows BEFORE the row statistics are formed (every other column then moves by an ulp through `dot`).  Round 5 bisection
+  // (tools/nondet_bisect.py, tools/hazard_probe/, profiles/r05_nondeterminism.md): not a missing wait (-amdgpu-waitcnt-forcezero: still
+  // 11 / 11), not a fixed-distance hazard (32 idle states at 11 places, 2-16 between producer and consumer: still differs), not the
+  // store tail or the head-LoRA MFMAs (off: still differs); gone with -fno-slp-vectorize and gone when ONLY the products
+  // acc * out_scale are kept scalar.  The instruction pairs replayed in isolation (2e9 checks each, with VMEM returns, SALU rewrites
+  // of the unused SGPR half and a partner wave's MFMAs) never fail: the trigger needs this kernel's surroundings and was not reduced
+  // further.  Both guards stay; tests/test_kernels_gpu.py::test_attention_kernels_are_bit_reproducible watches all three kernels.
 #pragma unroll
-  // pack2bf_scalar, not pack2bf: with the one-instruction packing this function's output came out different in ~0.1 % of the 16-row
-  // fragments from run to run at S = 8576 (whole fragments, last-bit differences of cancelling terms; found by the power-of-two
-  // linearity test of tests/test_fullsize_cfgs_gpu.py and located with tools/find_nondet.py: every other launch of the backward
-  // program is bit-reproducible).  The cause was not found in the ISA; the scalar form restores the code of rounds 1-3 here and the
-  // backward program is bit-reproducible again (profiles/r04_negative_results.md).
   for (int d = 0; d < DF; ++d) {
+#if defined(QFX_NRB_PACK1)
+    float o0 = (dn[d][0] - xh[d][0] * dot) * rstd, o1 = (dn[d][1] - xh[d][1] * dot) * rstd;
+    float o2 = (dn[d][2] - xh[d][2] * dot) * rstd, o3 = (dn[d][3] - xh[d][3] * dot) * rstd;
+    NRB_OPQ4(5, o0, o1, o2, o3);
+    if constexpr (((QFX_NRB_FENCE) >> 8) & 1) {       // producers (possibly v_pk_*_f32) | 2 idle states | consumers (v_cvt_pk_bf16_f32)
+      asm volatile("s_nop %c4" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) : "i"(QFX_NRB_NOPS));
+    }
+    out[d][0] = pack2bf(o0, o1);
+    out[d][1] = pack2bf(o2, o3);
+    if constexpr (((QFX_NRB_FENCE) >> 10) & 1) {      // consumers | 2 idle states | the next d's producers (WAR on the cvt's sources)
+      asm volatile("s_nop 1" : "+v"(out[d][0]), "+v"(out[d][1]));
+    }
+#else
     out[d][0] = pack2bf_scalar((dn[d][0] - xh[d][0] * dot) * rstd, (dn[d][1] - xh[d][1] * dot) * rstd);
     out[d][1] = pack2bf_scalar((dn[d][2] - xh[d][2] * dot) * rstd, (dn[d][3] - xh[d][3] * dot) * rstd);
+#endif
   }
+  NRB_FENCE(4);
 }
 
 // =============================================================================================

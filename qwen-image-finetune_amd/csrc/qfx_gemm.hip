@@ -18,6 +18,7 @@
 #include "qfx_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 namespace {
@@ -906,43 +907,72 @@ int validate(const qfx_gemm_args* a) {
 // overrides the three efficiency factors (A/B experiments).  Both are read once per process.
 struct Geo { int bmt, tn; double area, eff; bool on; };
 constexpr int NGEO = 3;
-Geo g_geo[NGEO] = {
+struct GeoTable { Geo g[NGEO]; };
+// Process-wide tuning state: guarded by a mutex, initialised exactly once from the environment, and every launch works on
+// its own SNAPSHOT of the table -- qfx_gemm_tune() from one thread can no longer tear the table under a launch from another
+// (side-stream / data-parallel hook threads launch GEMMs concurrently with the main thread).
+GeoTable g_geo_tab = {{
     {256, 128, 1.0, 1.00, true},
     {256, 256, 2.0, 1.09, true},
     {160, 192, 0.9375, 0.965, true},      // round 4: 0.9375 of the work at ~0.965 of the per-flop speed (profiles/r04_gemm_tiles.json)
-};
-bool g_geo_init = false;
+}};
+std::mutex g_geo_mu;
+std::once_flag g_geo_once;
 
-int geo_set(const char* tiles, const char* eff) {
+// `tiles`: "legacy" | "all" | comma list of exact BMTxTN names; `eff`: three comma-separated factors.  All-or-nothing: a value
+// that does not parse leaves the table untouched and returns QFX_EINVAL.  Caller holds g_geo_mu.
+int geo_set_locked(const char* tiles, const char* eff) {
+  GeoTable t = g_geo_tab;
   if (tiles && *tiles) {
     const std::string v(tiles);
-    if (v == "legacy") { for (int i = 0; i < NGEO; ++i) g_geo[i].on = i < 2; }
-    else if (v == "all") { for (auto& gg : g_geo) gg.on = true; }
+    if (v == "legacy") { for (int i = 0; i < NGEO; ++i) t.g[i].on = i < 2; }
+    else if (v == "all") { for (auto& gg : t.g) gg.on = true; }
     else {
-      bool on[NGEO], any = false;
-      for (int i = 0; i < NGEO; ++i) {
-        char name[32];
-        snprintf(name, sizeof name, "%dx%d", g_geo[i].bmt, g_geo[i].tn);
-        on[i] = v.find(name) != std::string::npos;
-        any = any || on[i];
+      bool on[NGEO] = {false, false, false};
+      size_t pos = 0;
+      while (pos <= v.size()) {                   // exact comma-split tokens (a substring match would accept "1256x1280")
+        const size_t e = v.find(',', pos);
+        const std::string tok = v.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        bool known = false;
+        for (int i = 0; i < NGEO; ++i) {
+          char name[32];
+          snprintf(name, sizeof name, "%dx%d", t.g[i].bmt, t.g[i].tn);
+          if (tok == name) { on[i] = true; known = true; }
+        }
+        if (!known) return QFX_EINVAL;
+        if (e == std::string::npos) break;
+        pos = e + 1;
       }
-      if (!any) return QFX_EINVAL;
-      for (int i = 0; i < NGEO; ++i) g_geo[i].on = on[i];
+      for (int i = 0; i < NGEO; ++i) t.g[i].on = on[i];
     }
   }
   if (eff && *eff) {
     double e[NGEO];
-    if (sscanf(eff, "%lf,%lf,%lf", &e[0], &e[1], &e[2]) != NGEO) return QFX_EINVAL;
+    char tail = 0;
+    if (sscanf(eff, "%lf,%lf,%lf%c", &e[0], &e[1], &e[2], &tail) != NGEO) return QFX_EINVAL;
     for (int i = 0; i < NGEO; ++i) if (!(e[i] > 0.1 && e[i] < 10.0)) return QFX_EINVAL;
-    for (int i = 0; i < NGEO; ++i) g_geo[i].eff = e[i];
+    for (int i = 0; i < NGEO; ++i) t.g[i].eff = e[i];
   }
+  g_geo_tab = t;
   return QFX_OK;
 }
 
 void geo_init() {
-  if (g_geo_init) return;
-  g_geo_init = true;
-  (void)geo_set(getenv("QFX_GEMM_TILES"), getenv("QFX_GEMM_EFF"));     // an unparsable environment value keeps the defaults
+  std::call_once(g_geo_once, [] {
+    std::lock_guard<std::mutex> lk(g_geo_mu);
+    const char* tiles = getenv("QFX_GEMM_TILES");
+    const char* eff = getenv("QFX_GEMM_EFF");
+    if (geo_set_locked(tiles, nullptr) != QFX_OK)
+      fprintf(stderr, "libqfx: QFX_GEMM_TILES=\"%s\" not understood (legacy | all | comma list of 256x128,256x256,160x192): ignored\n", tiles);
+    if (geo_set_locked(nullptr, eff) != QFX_OK)
+      fprintf(stderr, "libqfx: QFX_GEMM_EFF=\"%s\" not understood (three factors in (0.1, 10)): ignored\n", eff);
+  });
+}
+
+GeoTable geo_snapshot() {
+  geo_init();
+  std::lock_guard<std::mutex> lk(g_geo_mu);
+  return g_geo_tab;
 }
 
 template <int E, bool FP8>
@@ -960,7 +990,7 @@ void launch_geo(int gi, int grid, hipStream_t s, const GroupedArgs& ga) {
 
 template <bool FP8>
 int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo, int epi, hipStream_t s) {
-  const int bmt = g_geo[geo].bmt, tn = g_geo[geo].tn;
+  const int bmt = g_geo_tab.g[geo].bmt, tn = g_geo_tab.g[geo].tn;      // tile shapes are compile-time constants of the table: never tuned
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
     ga.tile_start[i] = tiles;
@@ -987,7 +1017,9 @@ int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo
 
 extern "C" int qfx_gemm_tune(const char* tiles, const char* eff) {
   geo_init();
-  return geo_set(tiles, eff);
+  std::lock_guard<std::mutex> lk(g_geo_mu);
+  const int rc = geo_set_locked(tiles, nullptr);
+  return rc != QFX_OK ? rc : geo_set_locked(nullptr, eff);
 }
 
 extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream) {
@@ -1004,13 +1036,13 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
     ga.g[i] = groups[i];
     probs[i] = &groups[i];
   }
-  geo_init();
+  const GeoTable geo = geo_snapshot();
   // e.g. B = 1, N = 3072: 240 tiles of 256x128 (one round, cost 1.0) vs 256 tiles of 160x192 (one round, 0.9375 / eff); the q/k/v
   // launch: 720 vs 768 narrow tiles (three rounds either way); N = 12288: 480 tiles of 256x256 (two rounds of 240).
   int best = -1;
   double best_cost = 0.0;
   for (int c = 0; c < NGEO; ++c) {
-    const Geo& gg = g_geo[c];
+    const Geo& gg = geo.g[c];
     if (!gg.on) continue;
     if (gg.tn >= 256 && !n256) continue;     // the wide tile keeps whole tiles along N (round-1 contract)
     long t = 0;

@@ -667,6 +667,16 @@ extern "C" int qfx_lora_head_reduce(const qfx_lora_head_reduce_args* list, int32
     if (!a.part || a.H <= 0 || a.M <= 0 || a.R <= 0 || a.R > 256 || (a.R % 16) || a.ld_part < a.R || a.group_R <= 0 || (a.R % a.group_R) ||
         a.rows_per_batch <= 0 || (!a.ext && !a.Ut_hi) || ((a.Ut_hi == nullptr) != (a.Ut_lo == nullptr)))
       return QFX_EINVAL;
+    // the kernel writes Ut[j * ld_ut + m], ext[m * ld_ext + group * group_stride + {0, 1, 2} * group_R + j'] and reads
+    // part[h * part_hstride + row * ld_part + j] unchecked: a descriptor that does not cover them is an error, not a memory stomp
+    if (a.Ut_hi && a.ld_ut < a.M) return QFX_EINVAL;
+    if (a.ext && (a.group_stride < 0 || a.ld_ext < (int64_t)(a.R / a.group_R - 1) * a.group_stride + 3 * a.group_R)) return QFX_EINVAL;
+    {
+      const int64_t nb = (a.M + a.rows_per_batch - 1) / a.rows_per_batch;
+      const int64_t last_row = a.x_batch_rows == 0 ? (int64_t)a.M - 1
+                                                     : (nb - 1) * a.x_batch_rows + a.x_row_off + ((a.M - 1) % a.rows_per_batch);
+      if (a.x_row_off < 0 || a.x_batch_rows < 0 || a.part_hstride < (last_row + 1) * (int64_t)a.ld_part) return QFX_EINVAL;
+    }
     b.a[i] = a;
     b.start[i] = blocks;
     const int rpb_ = 256 / a.R;

@@ -125,6 +125,7 @@ class FluxTransformer2DModel(QwenImageTransformer2DModel):
         self._lora_prep = None
         self._plans = PlanCache()
         self._version = 0
+        self._adapter_gen = 0      # bumped ONLY by add_adapter / load_lora_adapter / load_state_dict: what a data-parallel resync keys on
         self._rope_cache = {}
 
     _HEAD_SITES = {"x_embedder": "x_in", "context_embedder": "c_in", "proj_out": "proj_out"}

@@ -195,6 +195,7 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         self._lora_prep = None     # packed-operand buffers + descriptors
         self._plans = PlanCache()
         self._version = 0
+        self._adapter_gen = 0      # bumped ONLY by add_adapter / load_lora_adapter / load_state_dict: what a data-parallel resync keys on
 
     # ------------------------------------------------------------------ reference-surface methods
     @classmethod
@@ -282,6 +283,7 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self._invalidate()
+        self._adapter_gen += 1
         return r
 
     def add_adapter(self, adapter_config, adapter_name: str = "default", generator: torch.Generator | None = None):
@@ -318,11 +320,14 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         self.peft_config[adapter_name] = cfg
         self._hf_peft_config_loaded = True
         self._invalidate()
+        self._adapter_gen += 1
         # The reference wraps its LoRA container in DDP right after this call (base_trainer.py:384-393); the kernels write dA / dB
         # straight into the flat gradient buffer, so the model exchanges them itself.  Under an initialised multi-rank process
         # group that happens without an extra line in the trainer (no-op otherwise; call enable_data_parallel(...) again to
         # choose a process group / bucket size).
-        if self._dp is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # Opt-out: QFX_AUTO_DP=0 (a trainer that wraps / exchanges the LoRA gradients itself).
+        if (self._dp is None and os.environ.get("QFX_AUTO_DP", "1") != "0" and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1):
             self.enable_data_parallel()
         return names
 
@@ -398,6 +403,7 @@ class QwenImageTransformer2DModel(DataParallelMixin, nn.Module):
         from ..lora_io import load_lora_adapter
         names = load_lora_adapter(self, path, adapter_name, lora_alpha)
         self._invalidate()
+        self._adapter_gen += 1
         return names
 
     def quantize_trunk(self, mode: str | None = "mxfp8"):
@@ -775,6 +781,9 @@ class _QwenPlan:
         1-3: q / k / v adapters, which need the fused QK-norm backward).  Returns {stream: H} for the streams whose out-projection
         down projection now rides in qfx_attn_fwd; the backward streams are recorded in a._hl_qkv."""
         a._hl_qkv = {}
+        # the fused projections pick the text / image adapter by `row >= a.T`: set it HERE, not only in _fuse_qk_bwd (which returns
+        # early under QFX_FUSE_QKNORM_BWD=0 and used to leave T = 0: every text row then took the image adapter -- ADVICE r4)
+        a.T = self.T
         if not getattr(self, "head_lora", False):
             return {}
         A, B, S, H = self.A, self.B, self.S, self.H

@@ -108,14 +108,21 @@ class QwenLoraTrainStep:
 
     def _ensure_synced(self):
         """Rank 0's adapter + optimizer state reaches every rank before the first step AND again whenever the model's adapter set
-        was rebuilt since (dit._version moves on add_adapter / load_lora_adapter / load_state_dict / .to()): a re-injected or
-        re-loaded adapter must not depend on every rank having produced identical weights."""
-        ver = getattr(self.dit, "_version", 0)
+        was re-injected or re-loaded since (dit._adapter_gen moves on add_adapter / load_lora_adapter / load_state_dict ONLY): a
+        re-loaded adapter must not depend on every rank having produced identical weights.  Purely local actions that rebuild the
+        plans (.to(), set_adapter, merge / unmerge, quantize_trunk: dit._version) do NOT trigger the collective -- a rank-0-only
+        validation or merge would otherwise leave the ranks with mismatched collectives and hang the job; call
+        resync() on every rank after such an action if the adapter weights themselves were changed by it."""
+        ver = getattr(self.dit, "_adapter_gen", 0)
         if not self._synced or self._synced_version != ver:
             self._synced, self._synced_version = True, ver
             if self.world > 1:
                 self.dit.lora_store
                 self.broadcast_state()
+
+    def resync(self):
+        """Explicit collective resync (every rank must call it): rank 0's adapter + optimizer state to all ranks at the next step."""
+        self._synced = False
 
     # ------------------------------------------------------------------ sampling (CPU RNG like the reference)
     def sample_timesteps(self, batch_size, u=None):

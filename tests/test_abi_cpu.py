@@ -36,6 +36,21 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.qfx_attn_fwd(C.byref(a), None) == -1
     with pytest.raises(_lib.QfxError):
         _lib.check(-1, "x")
+    # qfx_gemm_tune: exact comma-split tile names, all-or-nothing, no launch involved
+    t = _lib.lib.qfx_gemm_tune
+    assert t(b"1256x1280", None) == -1 and t(b"256x128,", None) == -1 and t(b"256x128,17x3", None) == -1
+    assert t(b"256x128,160x192", None) == 0 and t(None, b"1,1.09,0.965") == 0 and t(None, b"1,1.09,0.965,7") == -1
+    assert t(b"all", None) == 0
+    # qfx_lora_head_reduce: descriptors that do not cover what the kernel writes / reads are rejected, never launched
+    r = _lib.LoraHeadReduceArgs()
+    r.part, r.part_hstride, r.ld_part, r.H, r.M, r.R = 0x1000, 64 * 16, 16, 4, 64, 16
+    r.group_R, r.group_stride, r.rows_per_batch = 16, 0, 64
+    r.Ut_hi, r.Ut_lo, r.ld_ut = 0x2000, 0x3000, 63                      # ld_ut < M
+    assert _lib.lib.qfx_lora_head_reduce(C.byref(r), 1, None) == -1
+    r.Ut_hi, r.Ut_lo, r.ext, r.ld_ext = 0, 0, 0x4000, 47                 # ld_ext < 3 * group_R
+    assert _lib.lib.qfx_lora_head_reduce(C.byref(r), 1, None) == -1
+    r.ld_ext, r.part_hstride = 48, 63 * 16                              # a head slab shorter than the rows read from it
+    assert _lib.lib.qfx_lora_head_reduce(C.byref(r), 1, None) == -1
 
 
 def test_map_mask_to_latent_host_helper_matches_reference_vectors():

@@ -349,6 +349,7 @@ def _worker_advice_r3(rank, world, port, q):
     toy = _toy_model(with_cond=False)
     toy._dp = LoraGradSync(toy)            # what dit.enable_data_parallel() installs (add_adapter does it under a process group)
     toy._version = 0
+    toy._adapter_gen = 0
     st = toy.lora_store
     step = QwenLoraTrainStep(toy)
     ok = True
@@ -387,9 +388,17 @@ def _worker_advice_r3(rank, world, port, q):
         st.pflat.fill_(float(30 + rank))
     step._ensure_synced()                   # same version: no broadcast
     ok = ok and bool(st.pflat.eq(30.0 + rank).all())
-    toy._version += 1                       # load_lora_adapter / add_adapter / .to() bump it
+    toy._version += 1                       # a purely LOCAL plan rebuild (.to(), set_adapter, merge, quantize_trunk): NO collective --
+    step._ensure_synced()                   # a rank-0-only validation / merge must not leave the ranks with mismatched broadcasts
+    ok = ok and bool(st.pflat.eq(30.0 + rank).all())
+    toy._adapter_gen += 1                   # add_adapter / load_lora_adapter / load_state_dict: rank 0's state goes out again
     step._ensure_synced()
     ok = ok and bool(st.pflat.eq(30.0).all())
+    with torch.no_grad():
+        st.pflat.fill_(float(40 + rank))
+    step.resync()                           # the explicit form
+    step._ensure_synced()
+    ok = ok and bool(st.pflat.eq(40.0).all())
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

