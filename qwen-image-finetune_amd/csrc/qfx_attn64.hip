@@ -1,0 +1,431 @@
+// qfx_attn64.hip -- attention forward with 64-query waves, ONE wave per SIMD, on v_mfma_f32_32x32x16_bf16 (gfx950, dh = 128).
+//
+// Replaces, for the device work of transformer_qwenimage.py:329-337 (joint SDPA), the 8 x 32-query form of qfx_attn.hip where the
+// launcher selects it (qfx_attn_fwd, QFX_ATTN_FWD64).  Structure (cdna_hip_programming.md "4-wave, one-wave-per-SIMD" note):
+//   * block = 4 waves x 64 queries = 256 queries of one head; each wave owns a whole SIMD and its 512 registers;
+//   * the accumulator half of the register file is allocated BY HAND: a[0:127] = O^T (4 d-blocks x 2 query blocks x 16), a[128:191] = the
+//     wave's Q fragments.  Every MFMA is an asm statement that names those registers, so hipcc can neither park Q in the accumulator
+//     half and copy it back (8 v_accvgpr_read per MFMA pair: the 142 us prototype of round 3) nor move the O accumulators;
+//   * scores are computed swapped (S^T = K Q^T): a lane owns one query column, 32 of its 64 scores per tile (the partner lane l ^ 32 owns
+//     the other 32), so the online softmax is lane-local; the packed bf16 P registers are directly the B operand of the PV MFMA
+//     under a key permutation that the V^T transpose read applies too -- no cross-lane traffic in the tile loop;
+//   * the two 32-query blocks of a wave are SKEWED by half a tile: T1 QK^T(qb 0) | T2 QK^T(qb 1) with softmax(qb 0) in the MFMA gaps |
+//     T3 PV(qb 0) with softmax(qb 1) in the gaps | T4 PV(qb 1).  Each "slot" = one 32-cycle MFMA + <= 8 other issues, pinned by
+//     sched_barrier; K rows are read twice per tile (once per query block), V^T twice: LDS traffic per flop = the old kernel's,
+//     MFMA count half, softmax instructions per score 4.2 instead of 8.4;
+//   * K / V tiles by LDS-DMA into a two-deep ring (one barrier per tile); K keeps the b128 swizzle of qfx_attn.hip, V gets its own:
+//     a half wave's transpose read covers 4 rows x 64 bytes, chunk' = chunk ^ ((row & 3) << 2) puts the four rows on four different
+//     64-byte bank groups;
+//   * epilogue: O / l is staged through LDS (row stride 272 B: conflict-free 8-byte writes and reads) and re-read in the 16-row
+//     fragment layout of qfx_attn.hip, so the wide stores and the fused rank-r projection (qfx_head_lora) are the SAME code.
+// Register audit after every edit (tools/agpr_audit.py): no scratch, no compiler v_accvgpr_* outside the asm statements.
+#include "qfx_attn_common.h"
+#include <utility>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#ifndef ATTN_DEFER_MAX
+#define ATTN_DEFER_MAX 8.0f
+#endif
+
+// every statement that writes the hand-allocated half names all of it: the compiler then holds nothing there across our statements
+#define A64_CLOB \
+  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", \
+      "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", \
+      "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", \
+      "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", \
+      "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", \
+      "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", \
+      "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", \
+      "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", \
+      "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", \
+      "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", \
+      "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", \
+      "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", \
+      "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+      "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", \
+      "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", \
+      "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", \
+      "a253", "a254", "a255"
+
+constexpr int A_O = 0;        // O^T block (db, qb): a[A_O + 16 * (2 db + qb) .. + 15]
+constexpr int A_Q = 128;      // Q fragment (qb, ks): a[A_Q + 4 * (8 qb + ks) .. + 3]
+constexpr int A_K = 192;      // K fragment (ks, kb) of the current tile: a[A_K + 4 * (2 ks + kb) .. + 3]
+
+template <int R> __device__ __forceinline__ void agpr_write(uint32_t v) {
+  asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "i"(R) : A64_CLOB);
+}
+template <int R> __device__ __forceinline__ float agpr_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(R));
+  return x;
+}
+// S^T block += K fragment (A: 32 keys x 16 d) x Q fragment (B), BOTH in the accumulator half.  WAIT >= 0: the statement first waits until at
+// most WAIT LDS operations are outstanding (the fragment was requested by k_load WAIT + 1 requests ago; counts of hipcc's own LDS
+// traffic can only make the wait stricter, never laxer: LDS operations return in order).
+template <int KREG, int QREG, int WAIT, bool FIRST> __device__ __forceinline__ void mfma_qk(f32x16& s) {
+  if constexpr (FIRST) {
+    if constexpr (WAIT >= 0)
+      asm volatile("s_waitcnt lgkmcnt(%c5)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=&v"(s) : "i"(KREG), "i"(KREG + 3), "i"(QREG), "i"(QREG + 3), "i"(WAIT));
+    else
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=&v"(s) : "i"(KREG), "i"(KREG + 3), "i"(QREG), "i"(QREG + 3));
+  } else {
+    if constexpr (WAIT >= 0)
+      asm volatile("s_waitcnt lgkmcnt(%c5)\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(KREG), "i"(KREG + 3), "i"(QREG), "i"(QREG + 3), "i"(WAIT));
+    else
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(s) : "i"(KREG), "i"(KREG + 3), "i"(QREG), "i"(QREG + 3));
+  }
+}
+// K fragment LDS -> accumulator half (uncounted by hipcc: the consumer waits, see mfma_qk)
+template <int KREG, int OFF> __device__ __forceinline__ void k_load(uint32_t lds_addr) {
+  asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(lds_addr), "i"(KREG), "i"(KREG + 3), "i"(OFF) : A64_CLOB, "memory");
+}
+// O^T block (accumulator half) += V^T fragment (A: 32 d x 16 keys) x P fragment (B: 16 keys x 32 queries)
+template <int OREG> __device__ __forceinline__ void mfma_pv(const bf16x8& vf, const u32x4& pf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(OREG), "i"(OREG + 15) : A64_CLOB);
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {      // one instruction, no canonicalising v_max on the asm-produced scores
+  float m;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  return m;
+}
+__device__ __forceinline__ float fexp2_(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <class F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int TB = 64 * 128 * 2;          // bytes of a K (or V) tile
+constexpr int STG_LD = 272;               // staging row stride of the epilogue (bytes)
+
+__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args a) {
+  constexpr int DH = 128;
+  // FOUR [K | V] stages (128 KB).  At the top of tile j a wave waits for all but its 8 youngest LDS-DMA requests (vmcnt(8)): tiles <= j + 1
+  // have landed, tile j + 2 (requested in T4 of tile j - 1, where a piece costs ~25 issue cycles against ~40 in T1) stays in flight for
+  // another tile time.  After the barrier tile j + 1 is known complete for EVERY wave, so the first K fragments of tile j + 1 are
+  // requested at the end of tile j, across the next barrier (with two stages every tile opened with an exposed LDS round trip), and
+  // the stage of tile j - 1 is free for tile j + 3.  The epilogue's staging slabs (4 x 17 KB) re-use the ring after a last barrier.
+  __shared__ __attribute__((aligned(16))) char smem[8 * TB];
+  static_assert(8 * TB >= 4 * 64 * STG_LD, "staging slabs must fit the ring");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, lj = lane & 31;
+  int xb, h, b;
+  attn_block_coord((a.S + 255) / 256, a.H, xb, h, b);
+  const int S = a.S;
+  const int q0 = xb * 256 + w * 64;
+  const bool live = q0 < S;                 // wave-uniform: a wave whose rows all lie past S only stages tiles and keeps the barrier protocol
+  const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
+  const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
+  const int ntiles = (S + 63) / 64;
+
+  // ---- LDS-DMA staging: wave w brings rows 16 w .. 16 w + 15 of both tiles, 4 pieces of 4 rows (1 KiB) each per tile.  Piece i < 4: K rows
+  // 16 w + 4 i ..; piece i >= 4: V rows.  Rows past S clamp to S - 1 (a tile past the last one is staged into the idle buffer and
+  // never read: no branch in the tile body).
+  auto stage_piece = [&](int jt, int buf, int i) {
+    char* dK = smem + buf * 2 * TB;
+    const int rr = lane >> 4, c = lane & 15, ii = i & 3;
+    const int row = 16 * w + 4 * ii + rr;
+    int s = jt * 64 + row; s = s < S ? s : S - 1;
+    if (i < 4) glds16(Kb + (row_off(s, a.ldk) + (unsigned)((c ^ swz_row<DH>(row)) * 8)), dK + (16 * w + 4 * ii) * 256);
+    else glds16(Vb + (row_off(s, a.ldv) + (unsigned)((c ^ (rr << 2)) * 8)), dK + TB + (16 * w + 4 * ii) * 256);
+  };
+  auto stage = [&](int jt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_piece(jt, buf, i);
+  };
+  stage(0, 0);
+  stage(1, 1);
+  stage(2, 2);
+
+  // ---- Q fragments -> a[128:191], O^T = 0 -> a[0:127]
+  if (live) {
+    sfor<2>([&](auto QB) {
+      int q = q0 + 32 * QB.value + lj; q = q < S ? q : S - 1;
+      const bf16_t* qp = a.Q + ((int64_t)b * S + q) * a.ldq + h * DH + 8 * hi;
+      u32x4 qv[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qv[ks] = *(const u32x4*)(qp + 16 * ks);
+      sfor<8>([&](auto KS) {
+        sfor<4>([&](auto I) { agpr_write<A_Q + 4 * (8 * QB.value + KS.value) + I.value>(qv[KS.value][I.value]); });
+      });
+    });
+    sfor<128>([&](auto I) { agpr_write<A_O + I.value>(0u); });
+  }
+
+  float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+  const float c2 = a.scale * LOG2E;
+  const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
+
+  // lane-constant LDS offsets.  K fragment (A operand of S^T): row = 32 kb + lj, 16-byte chunk 2 ks + hi under the b128 swizzle.
+  const int koff0 = lj * 256 + ((hi ^ swz_row<DH>(lj)) << 4);             // ^ (ks << 5), + kb * 8192
+  // V^T fragment (A operand of O^T) by transpose read: 16-lane group G = lane / 16 covers d columns 32 db + 16 (G & 1) .. + 15 and the
+  // key rows 16 t + 4 hi + j' (first read) / + 8 (second), j' = (lane & 15) / 4; source lane m = lane & 3 points at columns + 4 m.
+  const int jq = (lane & 15) >> 2, mq = lane & 3, gq = (lane >> 4) & 1;
+  const int toff0 = (4 * hi + jq) * 256 + ((((2 * gq + (mq >> 1)) ^ (jq << 2))) << 4) + (mq & 1) * 8;   // ^ (db << 6), + t * 4096 (+ 2048)
+
+  f32x16 S0[2], S1[2];       // score blocks of query block 0 / 1: [kb]
+  u32x4 P0[4], P1[4];        // packed P, B operand of k-step t = 2 kb + u
+
+#if defined(QFX_A64_TIMING)
+  uint64_t tph[6] = {0, 0, 0, 0, 0, 0}, tmark = 0;      // barrier, T1, T2, T3, T4, rest
+#define A64_T(i) do { asm volatile("s_nop 0" ::: "memory"); const uint64_t n_ = __builtin_readcyclecounter(); tph[i] += n_ - tmark; tmark = n_; } while (0)
+#else
+#define A64_T(i) do { } while (0)
+#endif
+  int b_cur = 0, b_nxt = 1, b_nn = 2, b_dma = 3;       // ring stages of tile jt, jt + 1 (landed), jt + 2 (landing), jt + 3 (to be requested)
+  for (int jt = 0; jt < ntiles; ++jt) {
+    // see the ring description at the top: my pieces of tiles <= jt + 1 have landed, tile jt + 2's may stay in flight
+    A64_T(5);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    A64_T(0);
+    if (!live) {
+      stage(jt + 3, b_dma);
+      const int t_ = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = b_dma; b_dma = t_;
+      continue;
+    }
+    const char* sK = smem + b_cur * 2 * TB;
+    const char* sV = sK + TB;
+    const uint32_t kb_next = (uint32_t)(uintptr_t)(smem + b_nxt * 2 * TB);
+    const int j0 = jt * 64;
+    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);     // wave-uniform
+    // the tile body exists twice: MASKED (ragged last tile / additive key mask: scores are scaled and masked before the maximum,
+    // cs = 1) and the plain one of the headline shapes (the scale rides in the FMA that feeds v_exp)
+    auto tile = [&](auto MASKED) {
+    constexpr bool masked = MASKED.value;
+    const float cs = masked ? 1.0f : c2;
+
+    // Fragment plumbing.  K: 16 fragments (ks, kb) are read ONCE per tile into a[192:255] during T1 (requested PFK slots ahead, asm,
+    // waited for by the consuming MFMA statement) and serve T1 AND T2.  V^T: 16 fragments (t, db) are read once during T3 (PFV slots
+    // ahead, hipcc counts them) into 64 VGPRs and serve T3 AND T4.  LDS traffic per tile and wave: 32 KB (the 32-query kernels: 2 x 32).
+    uint32_t kaddr[8], vaddr[4];
+    {
+      const uint32_t kb0 = (uint32_t)(uintptr_t)sK, vb0 = (uint32_t)(uintptr_t)sV;      // LDS byte addresses (low 32 bits of the generic pointer)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) kaddr[ks] = kb0 + (uint32_t)(koff0 ^ (ks << 5));
+#pragma unroll
+      for (int db = 0; db < 4; ++db) vaddr[db] = vb0 + (uint32_t)(toff0 ^ (db << 6));
+    }
+    constexpr int PFK = 6, PFV = 4;
+    auto kreq = [&](auto N) {       // request K fragment n = 2 ks + kb
+      constexpr int n = N.value;
+      if constexpr (n < 16) k_load<A_K + 4 * n, (n & 1) * 8192>(kaddr[n >> 1]);
+    };
+    bf16x8 vc[16];
+    auto vreq = [&](auto N) {       // request V^T fragment n = 4 t + db
+      constexpr int n = N.value;
+      if constexpr (n < 16) {
+        const char* vp = (const char*)(uintptr_t)0;      // LDS address space pointer from the 32-bit address
+        (void)vp;
+        QFX_AS3 char* p3 = (QFX_AS3 char*)(uintptr_t)vaddr[n & 3];
+        const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(p3 + (n >> 2) * 4096));
+        const bf16x4v hv = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(p3 + (n >> 2) * 4096 + 2048));
+        const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hv);
+        bf16x8 r;
+        r[0] = l4[0]; r[1] = l4[1]; r[2] = l4[2]; r[3] = l4[3]; r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
+        vc[n] = r;
+      }
+    };
+    if (jt == 0) sfor<PFK>([&](auto P) { kreq(P); });       // later tiles: requested at the end of the previous tile's T4
+    // one slot of QK^T for query block QB: K fragment n = I (k-step ks = I / 2, key block kb = I % 2)
+    auto qk_slot = [&](auto QB, auto I, f32x16 (&Sx)[2]) {
+      constexpr int n = I.value, ks = n / 2, kb = n % 2;
+      if constexpr (QB.value == 0) {
+        kreq(std::integral_constant<int, n + PFK>{});
+        constexpr int wait = (15 - n) < PFK ? (15 - n) : PFK;          // requests issued after fragment n
+        mfma_qk<A_K + 4 * n, A_Q + 4 * ks, wait, ks == 0>(Sx[kb]);
+        vreq(I);       // T1 is MFMA-bound with idle issue slots: ALL V^T fragments of the tile are requested here (hipcc counts them;
+                       // its own requests younger than a K fragment only make that fragment's wait stricter)
+      } else {
+        mfma_qk<A_K + 4 * n, A_Q + 4 * (8 + ks), -1, ks == 0>(Sx[kb]);
+      }
+    };
+    // one slot of PV for query block QB: V^T fragment n = I (k-step t = I / 4, d block db = I % 4)
+    auto pv_slot = [&](auto QB, auto I, const u32x4 (&Px)[4]) {
+      constexpr int n = I.value, t = n / 4, db = n % 4;
+      mfma_pv<A_O + 16 * (2 * db + QB.value)>(vc[n], Px[t]);
+    };
+    // softmax of query block QB spread over 16 slots.  Lane (lj, hi) holds, of query column lj, the scores of keys
+    // 32 kb + 8 (r / 4) + 4 hi + r % 4 (r = 0..15): value index k = 16 kb + r.
+    float mxa = 0.f, mxb = 0.f, negm = 0.f, lsum = 0.f, lsum2 = 0.f, pe0 = 0.f, pe1 = 0.f;
+    auto sm_slot = [&](auto QB, auto I, f32x16 (&Sx)[2], u32x4 (&Px)[4]) {
+      constexpr int qb = QB.value, i = I.value;
+      if constexpr (i < 2) {
+        f32x16& sv = Sx[i];
+        if constexpr (masked) {        // off the headline path: scale + additive mask here, -inf for keys past S
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int key0 = j0 + 32 * i + 8 * c + 4 * hi;           // four consecutive keys
+            f32x4 mk4 = {0.f, 0.f, 0.f, 0.f};
+            if (maskb != nullptr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mk4[r] = maskb[(key0 + r) < S ? (key0 + r) : S - 1] * LOG2E;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sv[4 * c + r] = (key0 + r) < S ? sv[4 * c + r] * c2 + mk4[r] : -INFINITY;
+          }
+        }
+        // four v_max3 chains in ONE statement (dependent instructions >= 2 apart; as separate statements hipcc pads every dependent pair)
+        float ma, mb_, mc_, md_;
+        asm volatile(
+            "v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15\n\t"
+            "v_max3_f32 %0, %0, %16, %17\n\tv_max3_f32 %1, %1, %18, %19\n\tv_max_f32 %2, %2, %3\n\tv_max3_f32 %0, %0, %1, %2"
+            : "=&v"(ma), "=&v"(mb_), "=&v"(mc_), "=&v"(md_)
+            : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]), "v"(sv[8]), "v"(sv[9]), "v"(sv[10]),
+              "v"(sv[11]), "v"(sv[12]), "v"(sv[13]), "v"(sv[14]), "v"(sv[15]));
+        if constexpr (i == 0) mxa = ma; else mxb = ma;
+      }
+      if constexpr (i == 2) {
+        float mx = fmaxf(mxa, mxb);
+        // lazy reference maximum (qfx_attn.hip): the reference of a row moves only when a score of this tile exceeds it by > 2^8
+        if (__builtin_expect(!__all(mx * cs - mrow[qb] <= ATTN_DEFER_MAX), 0)) {
+          const uint32_t u1 = __float_as_uint(mx);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+          mx = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+          const float mnew = fmaxf(mrow[qb], mx * cs);
+          const float alpha = fexp2_(mrow[qb] - ((mnew == -INFINITY) ? 0.f : mnew));
+          mrow[qb] = mnew;
+          lrow[qb] *= alpha;
+          if (jt > 0) {          // O^T(., qb) *= alpha: no MFMA on these accumulators is in flight in T2 (qb 0) / T3 (qb 1)
+            sfor<64>([&](auto R) {
+              constexpr int reg = A_O + 16 * (2 * (R.value / 16) + qb) + R.value % 16;
+              agpr_write<reg>(__float_as_uint(agpr_read<reg>() * alpha));
+            });
+            asm volatile("s_nop 1");
+          }
+        }
+        negm = (mrow[qb] == -INFINITY) ? 0.f : -mrow[qb];
+        lsum = 0.f; lsum2 = 0.f; pe0 = 0.f; pe1 = 0.f;      // pe = 0: the first statement "finishes" a pair that adds nothing
+      }
+      // pairs of scores -> p = exp2(s * cs - m), row sum, one packed dword of the PV B operand: pair pi (values 2 pi, 2 pi + 1)
+      constexpr int np = i < 2 ? 0 : (i == 3 || i == 4) ? 2 : 1;
+      constexpr int p0 = i < 2 ? 0 : i == 2 ? 0 : i == 3 ? 1 : i == 4 ? 3 : i;        // i >= 5: pair i
+#pragma unroll
+      for (int pp = 0; pp < np; ++pp) {
+        const int pi = p0 + pp, k = 2 * pi;
+        // ONE statement per pair, so that the work stays in THIS slot (as plain C++ hipcc's instruction selection sinks every pair to
+        // its consumer, the PV MFMA of the next phase, and the gaps of this phase stay empty), software-pipelined by one pair: the
+        // statement starts pair pi (fma, exp) and finishes pair pi - 1 (row sums on two accumulators, packing) -- no instruction
+        // depends on one less than three places before it, a lone wave on its SIMD has nobody to hide a dependent-issue stall.
+        float t0, t1;
+        uint32_t pw;
+        asm volatile(
+            "v_fma_f32 %5, %7, %9, %10\n\tv_fma_f32 %6, %8, %9, %10\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %4\n\t"
+            "v_cvt_pk_bf16_f32 %0, %3, %4\n\tv_exp_f32 %3, %5\n\tv_exp_f32 %4, %6"
+            : "=&v"(pw), "+v"(lsum), "+v"(lsum2), "+v"(pe0), "+v"(pe1), "=&v"(t0), "=&v"(t1)
+            : "v"(Sx[k >> 4][k & 15]), "v"(Sx[k >> 4][(k & 15) + 1]), "v"(cs), "v"(negm));
+        if (pi > 0) Px[(pi - 1) >> 2][(pi - 1) & 3] = pw;
+      }
+      if constexpr (i == 15) {      // finish pair 15
+        uint32_t pw;
+        asm volatile("v_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %4\n\tv_cvt_pk_bf16_f32 %0, %3, %4" : "=&v"(pw), "+v"(lsum), "+v"(lsum2) : "v"(pe0), "v"(pe1));
+        Px[3][3] = pw;
+        lrow[qb] += lsum + lsum2;
+      }
+    };
+
+    // T1: QK^T of query block 0
+    sfor<16>([&](auto I) {
+      qk_slot(std::integral_constant<int, 0>{}, I, S0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(1);
+    // T2: QK^T of query block 1, softmax of block 0 in the gaps
+    sfor<16>([&](auto I) {
+      qk_slot(std::integral_constant<int, 1>{}, I, S1);
+      sm_slot(std::integral_constant<int, 0>{}, I, S0, P0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(2);
+    // T3: PV of query block 0, softmax of block 1 in the gaps
+    sfor<16>([&](auto I) {
+      pv_slot(std::integral_constant<int, 0>{}, I, P0);
+      sm_slot(std::integral_constant<int, 1>{}, I, S1, P1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(3);
+    // T4: PV of query block 1
+    sfor<16>([&](auto I) {
+      pv_slot(std::integral_constant<int, 1>{}, I, P1);
+      // the LDS-DMA pieces of tile jt + 3 ride in the gaps of this phase (8 x ~40 issue cycles at the loop head stall a lone wave's MFMAs;
+      // T4 has nothing else between its MFMAs)
+      if constexpr (I.value < 8) stage_piece(jt + 3, b_dma, I.value);
+      // the first K fragments of tile jt + 1 (its stage landed a tile ago) are requested here, across the coming barrier
+      if constexpr (I.value >= 16 - PFK) {
+        constexpr int n = I.value - (16 - PFK);
+        k_load<A_K + 4 * n, (n & 1) * 8192>(kb_next + (uint32_t)(koff0 ^ ((n >> 1) << 5)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(4);
+    };   // tile
+    if (need_mask) tile(std::true_type{}); else tile(std::false_type{});
+    { const int t_ = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = b_dma; b_dma = t_; }
+  }
+#if defined(QFX_A64_TIMING)
+  if (lane == 0 && blockIdx.x < 16) {      // caller over-allocates lse2 by 16 * 4 * 8 floats in the timing build
+    float* dbg = a.lse2 + ((int64_t)a.B * a.H) * a.S_pad + (blockIdx.x * 4 + w) * 8;
+    for (int i = 0; i < 6; ++i) dbg[i] = (float)tph[i];
+    dbg[6] = (float)ntiles;
+  }
+#endif
+  // every wave is done with the ring and every stray LDS-DMA piece (tiles past the last one are staged, never read) has landed:
+  // the ring becomes the staging slabs
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (!live) return;
+
+  // ---- epilogue: O = O^T / l -> bf16 -> staging slab [64 rows][272 B] of this wave -> 16-row fragments of the qfx_attn.hip layout
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last PV MFMAs have written the accumulators
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the K requests for the tile past the last one
+  char* stg = smem + w * (64 * STG_LD);
+  float lse_out[2];
+  sfor<2>([&](auto QB) {
+    constexpr int qb = QB.value;
+    float l = lrow[qb];
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    lse_out[qb] = mrow[qb] + log2f(l);
+    sfor<4>([&](auto DB) {
+      sfor<4>([&](auto C) {
+        constexpr int reg = A_O + 16 * (2 * DB.value + qb) + 4 * C.value;
+        const float o0 = agpr_read<reg>() * inv, o1 = agpr_read<reg + 1>() * inv, o2 = agpr_read<reg + 2>() * inv, o3 = agpr_read<reg + 3>() * inv;
+        const u32x2 u = {pack2bf(o0, o1), pack2bf(o2, o3)};
+        *(u32x2*)(stg + (32 * qb + lj) * STG_LD + (32 * DB.value + 8 * C.value + 4 * hi) * 2) = u;
+      });
+    });
+    const int q = q0 + 32 * qb + lj;
+    if (q < S && hi == 0) a.lse2[((int64_t)b * a.H + h) * a.S_pad + q] = lse_out[qb];
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is private to the wave: no block barrier
+  const int g = lane >> 4, li = lane & 15;
+  const bool wide = rows_16b(a.O, a.ldo);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    if (q0 + 16 * f >= S) break;                           // wave-uniform
+    u32x2 u[DH / 16];
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d) u[d] = *(const u32x2*)(stg + (16 * f + li) * STG_LD + (16 * d + 4 * g) * 2);
+    const int q = q0 + 16 * f + li;
+    const int qc = q < S ? q : S - 1;
+    store_frag<DH>(a.O + ((int64_t)b * S + qc) * a.ldo + h * DH, u, g, q < S, wide);
+    head_lora_frag<DH>(a.hl[0], h, a.T, q0 + 16 * f, (int64_t)b * S + qc, q < S, u, g, li);
+  }
+}
+
+}  // namespace
+
+namespace qfxi {
+// launcher used by qfx_attn_fwd (qfx_attn.hip); arguments are validated there
+int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream) {
+  dim3 grid(((a->S + 255) / 256) * a->H * a->B);
+  hipLaunchKernelGGL(attn_fwd64_kernel, grid, dim3(256), 0, stream, *a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? QFX_OK : -(1000 + (int)e);
+}
+}  // namespace qfxi

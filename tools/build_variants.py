@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "qwen-image-finetune_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_ab")
-SOURCES = ["qfx_gemm.hip", "qfx_gemm_fp8.hip", "qfx_skinny.hip", "qfx_elem.hip", "qfx_attn.hip", "qfx_cond.hip"]
+SOURCES = ["qfx_gemm.hip", "qfx_gemm_fp8.hip", "qfx_skinny.hip", "qfx_elem.hip", "qfx_attn.hip", "qfx_attn64.hip", "qfx_cond.hip"]
+EXTRA_FLAGS = {"qfx_attn64.hip": ["-fno-slp-vectorize"]}
 
 
 def main():
@@ -24,13 +25,13 @@ def main():
         objs = []
         for src in SOURCES:
             text = (open(os.path.join(CSRC, src)).read() + open(os.path.join(CSRC, "qfx_common.h")).read() +
-                    open(os.path.join(ROOT, "include", "qfx.h")).read())
+                    open(os.path.join(CSRC, "qfx_attn_common.h")).read() + open(os.path.join(ROOT, "include", "qfx.h")).read())
             rel = [f for f in flags if re.sub(r"^-D", "", f).split("=")[0] in text]
             key = hashlib.sha1((src + "|" + " ".join(rel) + "|" + hashlib.sha1(text.encode()).hexdigest()).encode()).hexdigest()[:16]
             obj = os.path.join(OUT, f"{src[:-4]}_{key}.o")
             if not os.path.exists(obj) and obj not in jobs:
                 cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-                       *rel, "-c", os.path.join(CSRC, src), "-o", obj]
+                       *EXTRA_FLAGS.get(src, []), *rel, "-c", os.path.join(CSRC, src), "-o", obj]
                 jobs[obj] = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             objs.append(obj)
         plans.append((name, objs))
