@@ -749,6 +749,21 @@ int pick_waves(const qfx_attn_args* a) {
   return e8 > 1.04 * e4 ? 8 : 4;
 }
 
+// The 64-query forward runs one 256-query block per CU: it wins where those blocks fill their last round of CUs (S = 2432: 240 blocks,
+// 83 vs 91 us; S = 4608 / 4864: 0.84 / 0.89 of two rounds, 258 vs 278 / 276 vs 315 us) and loses where they do not (S = 3584: 336 blocks =
+// 0.66 of two rounds, 208 vs 193 us; S = 1280: 120 blocks, 44 vs 34 us; S = 8576: 0.80 of four rounds, 931 vs 874 us) --
+// profiles/r05_attn_fwd64.json.
+bool pick_fwd64(const qfx_attn_args* a) {
+  const char* e = getenv("QFX_ATTN_FWD64");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  const long hb = (long)a->H * a->B;
+  const long b64 = (long)((a->S + 255) / 256) * hb, b4 = (long)((a->S + 127) / 128) * hb;
+  const double e64 = (double)b64 / (double)(((b64 + 255) / 256) * 256);
+  const double e4 = (double)b4 / (double)(((b4 + 511) / 512) * 512);
+  const double eo = e64 > e4 ? e64 : e4;      // the 32-query kernels: 8 waves x 256 queries quantise like the 64-query blocks, 4 x 128 like b4
+  return e64 > 0.82 && e64 >= eo - 0.02;
+}
+
 int check_common(const qfx_attn_args* a) {
   if (!a || a->B <= 0 || a->S <= 0 || a->H <= 0 || (a->S_pad % 64) || a->S_pad < a->S) return QFX_EINVAL;
   if (a->dh != 64 && a->dh != 128) return QFX_EUNSUPPORTED;
@@ -782,12 +797,10 @@ extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return QFX_EINVAL;
   if ((rc = check_head_lora(a, 0, 0))) return rc;
-  // dh = 128: 64-query waves, one per SIMD, on the 32x32x16 MFMA with hand-allocated accumulator registers (qfx_attn64.hip, round 5).
-  // QFX_ATTN_FWD64=0 selects the 32-query kernels below (A/B lever; read per launch so that a test can compare both in one process).
-  if (a->dh == 128) {
-    const char* e = getenv("QFX_ATTN_FWD64");
-    if (!(e && e[0] == '0')) return qfxi::launch_attn_fwd64(a, (hipStream_t)stream);
-  }
+  // dh = 128: 64-query waves, one per SIMD, on the 32x32x16 MFMA with hand-allocated accumulator registers (qfx_attn64.hip, round 5)
+  // where its 256-query blocks fill whole rounds of the 256 CUs (pick_fwd64).  QFX_ATTN_FWD64 = 0 / 1 forces the 32-query kernels /
+  // the 64-query kernel (A/B lever and tests; read per launch so that one process can compare both).
+  if (a->dh == 128 && pick_fwd64(a)) return qfxi::launch_attn_fwd64(a, (hipStream_t)stream);
   const int nw = pick_waves(a);
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
   if (a->dh == 128) {

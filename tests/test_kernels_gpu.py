@@ -795,12 +795,80 @@ def test_attention_kernels_are_bit_reproducible(S):
                 for i, (x, y) in enumerate(zip(cur, ref)):
                     assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), f"{fn.__name__}: output {i} differs between two launches on identical inputs"
 
-    run(L.lib.qfx_attn_fwd, [O, lse2, parts[0]])
+    import os
+    for mode in ("0", "1"):       # the 32-query and the 64-query forward
+        os.environ["QFX_ATTN_FWD64"] = mode
+        try:
+            run(L.lib.qfx_attn_fwd, [O, lse2, parts[0]])
+        finally:
+            os.environ.pop("QFX_ATTN_FWD64", None)
     a.qk_saved, a.ld_saved, a.rope, a.rope_bstride = sqk.data_ptr(), 2 * D, rope.data_ptr(), 0
     a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = (t.data_ptr() for t in ws)
     a.norm_flags, a.norm_eps = 0, 1e-6
     run(L.lib.qfx_attn_bwd_dq, [dqkv, dsum, parts[1]])
     run(L.lib.qfx_attn_bwd_dkv, [dqkv, parts[2], parts[3]])
+
+
+@pytest.mark.parametrize("S,H,Bn,mask,R", [(2432, 24, 1, 0, 16), (333, 2, 2, 0, 16), (333, 2, 2, 1, 0), (200, 3, 2, 2, 32), (64, 1, 1, 0, 0), (1000, 4, 1, 0, 16),
+                                          (257, 2, 1, 1, 16), (4608, 24, 1, 0, 0)])
+def test_attention_fwd64_matches_sdpa_and_the_32_query_kernel(S, H, Bn, mask, R, monkeypatch):
+    """Round 5: qfx_attn_fwd on the 64-query / 32x32x16 kernel (qfx_attn64.hip; forced with QFX_ATTN_FWD64=1, the launcher's own policy
+    only takes it where its 256-query blocks fill the CUs) against fp32 SDPA and against the 32-query kernels (QFX_ATTN_FWD64=0) on the
+    same inputs: ragged S, additive and -inf key masks, several heads / samples, the fused rank-r projection of the epilogue."""
+    import ctypes as C
+    import math
+    from qflux_amd import _lib as L
+    ops = _ops()
+    dh = 128
+    D = H * dh
+    S_pad = (S + 63) // 64 * 64
+    T = 48 if S > 64 else 16
+    g = torch.Generator(device=DEV).manual_seed(S + H)
+    qkv = torch.randn(Bn, S, 3 * D, device=DEV, generator=g).to(torch.bfloat16)
+    ld = 3 * D
+    kmask = None
+    if mask:
+        kmask = torch.zeros(Bn, S, device=DEV)
+        kmask[:, S - S // 5:] = -1e4 if mask == 1 else float("-inf")
+    wpk = None
+    if R:
+        wts = [(torch.randn(R, D, device=DEV, generator=g) * 0.1).to(torch.bfloat16) for _ in range(4)]
+        wpk = [L.head_fragment_image(wts[0], wts[1], dh), L.head_fragment_image(wts[2], wts[3], dh)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("QFX_ATTN_FWD64", mode)
+        O = torch.zeros(Bn, S, D, dtype=torch.bfloat16, device=DEV)
+        lse2 = torch.zeros(Bn, H, S_pad, device=DEV)
+        part = torch.zeros(H, Bn * S, max(R, 1), device=DEV)
+        a = ops.attn_args(Bn, S, S_pad, H, dh, 1 / math.sqrt(dh), Q=qkv[:, :, :D], K=qkv[:, :, D:2 * D], V=qkv[:, :, 2 * D:], ldq=ld, ldk=ld, ldv=ld,
+                          O=O, ldo=D, lse2=lse2)
+        if kmask is not None:
+            a.key_mask = kmask.data_ptr()
+        a.T = T
+        if R:
+            hl = a.hl[0]
+            hl.part, hl.part_hstride, hl.ld_part, hl.c0, hl.R = part.data_ptr(), Bn * S * R, R, 0, R
+            hl.w_pk[0], hl.w_pk[1] = wpk[0].data_ptr(), wpk[1].data_ptr()
+        L.check(L.lib.qfx_attn_fwd(C.byref(a), ops.stream_ptr()), "qfx_attn_fwd")
+        torch.cuda.synchronize()
+        res[mode] = (O.float(), lse2[:, :, :S].clone(), part.clone())
+    q, k, v = (qkv[:, :, i * D:(i + 1) * D].float().view(Bn, S, H, dh).transpose(1, 2) for i in range(3))
+    sc = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    if kmask is not None:
+        sc = sc + kmask[:, None, None, :]
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(Bn, S, D)
+    lse_ref = torch.logsumexp(sc, -1) * 1.4426950408889634
+
+    def rel(x, y):
+        return ((x - y).abs().max() / (y.abs().max() + 1e-12)).item()
+    new, old = res["1"], res["0"]
+    assert torch.isfinite(new[0]).all()
+    e_new, e_old = rel(new[0], ref), rel(old[0], ref)
+    assert e_new < 6e-3 and e_new <= 1.25 * e_old + 1e-4, (e_new, e_old)          # bf16 output: ~2^-8 of the largest value
+    assert rel(new[1], lse_ref) < 1e-5                                            # fp32 statistics
+    assert rel(new[0], old[0]) < 6e-3
+    if R:
+        assert rel(new[2], old[2]) < 2e-3                                         # rank-r partial sums of bf16 O rows that differ by an ulp
 
 
 @pytest.mark.parametrize("seed", range(8))
