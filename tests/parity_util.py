@@ -213,3 +213,41 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
     if verbose:
         print(res)
     return res
+
+
+def assert_step_bit_reproducible(plan, run_step, gflat, zero_grad, what=""):
+    """Two identical fused steps, each started from a ZEROED arena: every arena tensor must come out bit-identical (check-sums over
+    the raw bytes).  Only the flat LoRA gradient and the scalar loss are exempt from the bit test -- the weight-gradient launches add
+    with fp32 atomics (order-dependent in the last bit): 1e-5 / 1e-6.  `run_step()` -> loss tensor; `gflat` the flat gradient buffer."""
+    tens, seen = [], set()
+
+    def flat(prefix, obj):
+        if isinstance(obj, torch.Tensor):
+            key = (obj.data_ptr(), obj.numel(), obj.dtype)
+            if obj.numel() and key not in seen:
+                seen.add(key)
+                tens.append((prefix, obj))
+        elif isinstance(obj, dict):
+            for k, v in obj.items():
+                flat(f"{prefix}.{k}", v)
+        elif isinstance(obj, (list, tuple)):
+            for i, v in enumerate(obj):
+                flat(f"{prefix}[{i}]", v)
+    flat("A", plan.A)
+
+    def one():
+        for _, t in tens:
+            t.zero_()
+        loss = run_step().item()
+        torch.cuda.synchronize()
+        sums = [int((t if t.is_contiguous() else t.contiguous()).view(torch.uint8).view(-1)[: t.numel() * t.element_size() // 8 * 8].view(torch.int64).sum().item())
+                for _, t in tens]
+        g = gflat.clone()
+        zero_grad()
+        return loss, sums, g
+    l1, s1, g1 = one()
+    l2, s2, g2 = one()
+    bad = [tens[i][0] for i in range(len(tens)) if s1[i] != s2[i]]
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and not bad, (what, l1, l2, bad[:6])
+    assert ((g1 - g2).abs().max() / g1.abs().max()).item() < 1e-5, what
+    return len(tens)
