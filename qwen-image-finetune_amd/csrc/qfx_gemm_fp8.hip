@@ -7,7 +7,7 @@
 // reads the 16-byte chunks g and g+4 of row li -- in the bf16 kernel two k-steps, here the two halves of ONE scaled MFMA operand.
 // Hardware K order of that operand (measured, tools/mx_probe): k = (byte/16)*64 + g*16 + byte%16, and the scale supplied by lane
 // group g covers hardware k in [32g, 32g+32) = chunks {2g', 2g'+1} of the row with g' = g: i.e. exactly the MX block g of the K
-// tile when lane group g holds chunks (g, g+4) ... see the mapping table in DESIGN.md section 3.
+// tile when lane group g holds chunks (g, g+4) ... see the MX-FP8 row of the kernel table in profiles/HISTORY.md section 3.
 #include "qfx_common.h"
 
 namespace {

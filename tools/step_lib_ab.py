@@ -2,7 +2,7 @@
 """Sustained-load A/B of kernel-variant libraries on the REAL training step (60 blocks, side-stream gradient launches, optimizer):
     python tools/step_lib_ab.py base,<variant>[,...] [--steps 30] [--rounds 3]
 Unlike tools/step_ab.py (per-launch events, bursts: the chip never reaches its power cap there) this runs whole steps back to
-back, so a variant that only saves ENERGY shows up as time -- the step is package-power-limited.  One model,
+back, so a variant that only saves ENERGY shows up as time -- the step is package-power-limited (profiles/HISTORY.md).  One model,
 one plan; the launch programs' C calls are re-bound to the same symbol of each variant library, rounds alternate."""
 from __future__ import annotations
 
