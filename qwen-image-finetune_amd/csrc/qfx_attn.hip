@@ -13,7 +13,10 @@
 // lse2 is the log2-domain logsumexp of (scale * q.k + mask): P = exp2(scale*log2e * s + mask*log2e - lse2).
 #include "qfx_attn_common.h"
 
-namespace qfxi { int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream); }      // qfx_attn64.hip
+namespace qfxi {      // qfx_attn64.hip
+int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream);
+int launch_attn_bwd_dq64(const qfx_attn_args* a, hipStream_t stream);
+}
 
 namespace {
 
@@ -254,92 +257,6 @@ __global__ __launch_bounds__(256) void attn_prep_kernel(const qfx_attn_args a) {
   }
 }
 
-
-// Backward of QK RMSNorm + RoPE on one gradient row held in the 16x16 accumulator layout (lane (g, li): row li of fragment f,
-// columns 16 d + 4 g + r): the arithmetic of qk_norm_rope_kernel<DH, true> (qfx_elem.hip) on the bf16-rounded attention gradient
-//   dn = [rbf](rbf(dy * conj(rope)) * w) ;  xh = x * rstd ;  out = (dn - xh * mean(dn * xh)) * rstd
-// with the row statistics folded over the four lane groups by two shuffles.  x = the saved pre-norm row, out packed bf16 per d.
-template <int DH>
-__device__ __forceinline__ void norm_rope_bwd_row(const f32x4 (&acc)[DH / 16][2], int f, float out_scale, const bf16_t* xrow,
-                                                  const float* rrow, const bf16_t* wrow, float eps, int flags, u32x2 (&out)[DH / 16]) {
-  constexpr int DF = DH / 16;
-  float xh[DF][4], dn[DF][4];
-  float ss = 0.f;
-  NRB_FENCE(0);
-#pragma unroll
-  for (int d = 0; d < DF; ++d) {
-    const u32x2 ux = *(const u32x2*)(xrow + d * 16);
-    xh[d][0] = __uint_as_float(ux[0] << 16); xh[d][1] = __uint_as_float(ux[0] & 0xffff0000u);
-    xh[d][2] = __uint_as_float(ux[1] << 16); xh[d][3] = __uint_as_float(ux[1] & 0xffff0000u);
-    NRB_OPQ4(4, xh[d][0], xh[d][1], xh[d][2], xh[d][3]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ss += xh[d][r] * xh[d][r];
-  }
-  ss += __shfl_xor(ss, 16);
-  ss += __shfl_xor(ss, 32);
-  const float rstd = rsqrtf(ss / (float)DH + eps);
-  float dot = 0.f;
-  NRB_FENCE(1);
-#pragma unroll
-  for (int d = 0; d < DF; ++d) {
-    const f32x4 cs = *(const f32x4*)(rrow + d * 16);            // (cos, sin) of the pairs (16 d + 4 g)/2 and +1
-    const u32x2 uw = *(const u32x2*)(wrow + d * 16);
-    const float w0 = __uint_as_float(uw[0] << 16), w1 = __uint_as_float(uw[0] & 0xffff0000u);
-    const float w2 = __uint_as_float(uw[1] << 16), w3 = __uint_as_float(uw[1] & 0xffff0000u);
-    float e0 = rbf(acc[d][f][0] * out_scale), e1 = rbf(acc[d][f][1] * out_scale);
-    float e2 = rbf(acc[d][f][2] * out_scale), e3 = rbf(acc[d][f][3] * out_scale);
-    NRB_OPQ4(0, e0, e1, e2, e3);
-    float d0 = rbf(e0 * cs[0] + e1 * cs[1]), d1 = rbf(-e0 * cs[1] + e1 * cs[0]);     // dy * conj(f)
-    float d2 = rbf(e2 * cs[2] + e3 * cs[3]), d3 = rbf(-e2 * cs[3] + e3 * cs[2]);
-    NRB_OPQ4(1, d0, d1, d2, d3);
-    dn[d][0] = (flags & 1) ? d0 * w0 : rbf(d0 * w0);
-    dn[d][1] = (flags & 1) ? d1 * w1 : rbf(d1 * w1);
-    dn[d][2] = (flags & 1) ? d2 * w2 : rbf(d2 * w2);
-    dn[d][3] = (flags & 1) ? d3 * w3 : rbf(d3 * w3);
-    NRB_OPQ4(2, dn[d][0], dn[d][1], dn[d][2], dn[d][3]);
-    if constexpr (((QFX_NRB_FENCE) >> 9) & 1) {
-      asm volatile("s_nop 1" : "+v"(dn[d][0]), "+v"(dn[d][1]), "+v"(dn[d][2]), "+v"(dn[d][3]));
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { xh[d][r] *= rstd; dot += dn[d][r] * xh[d][r]; }
-    NRB_OPQ4(3, xh[d][0], xh[d][1], xh[d][2], xh[d][3]);
-  }
-  NRB_FENCE(2);
-  dot += __shfl_xor(dot, 16);
-  dot += __shfl_xor(dot, 32);
-  dot /= (float)DH;
-  NRB_FENCE(3);
-  // pack2bf_scalar, not pack2bf (round 4), and QFX_NRB_OPQ bit 0 (round 5).  With the one-instruction packing, hipcc's SLP vectoriser
-  // re-shapes the whole function into v_pk_*_f32 pairs, and the dQ kernel then came out different from run to run: in ~0.3 % of the
-  // 16-row fragments ONE column -- an odd r of lane group g = 3, i.e. the HIGH register of a packed pair, lanes 48-63 -- is wrong in
-  // all 16 rows BEFORE the row statistics are formed (every other column then moves by an ulp through `dot`).  Round 5 bisection
-  // (tools/nondet_bisect.py, tools/hazard_probe/, profiles/r05_nondeterminism.md): not a missing wait (-amdgpu-waitcnt-forcezero: still
-  // 11 / 11), not a fixed-distance hazard (32 idle states at 11 places, 2-16 between producer and consumer: still differs), not the
-  // store tail or the head-LoRA MFMAs (off: still differs); gone with -fno-slp-vectorize and gone when ONLY the products
-  // acc * out_scale are kept scalar.  The instruction pairs replayed in isolation (2e9 checks each, with VMEM returns, SALU rewrites
-  // of the unused SGPR half and a partner wave's MFMAs) never fail: the trigger needs this kernel's surroundings and was not reduced
-  // further.  Both guards stay; tests/test_kernels_gpu.py::test_attention_kernels_are_bit_reproducible watches all three kernels.
-#pragma unroll
-  for (int d = 0; d < DF; ++d) {
-#if defined(QFX_NRB_PACK1)
-    float o0 = (dn[d][0] - xh[d][0] * dot) * rstd, o1 = (dn[d][1] - xh[d][1] * dot) * rstd;
-    float o2 = (dn[d][2] - xh[d][2] * dot) * rstd, o3 = (dn[d][3] - xh[d][3] * dot) * rstd;
-    NRB_OPQ4(5, o0, o1, o2, o3);
-    if constexpr (((QFX_NRB_FENCE) >> 8) & 1) {       // producers (possibly v_pk_*_f32) | 2 idle states | consumers (v_cvt_pk_bf16_f32)
-      asm volatile("s_nop %c4" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) : "i"(QFX_NRB_NOPS));
-    }
-    out[d][0] = pack2bf(o0, o1);
-    out[d][1] = pack2bf(o2, o3);
-    if constexpr (((QFX_NRB_FENCE) >> 10) & 1) {      // consumers | 2 idle states | the next d's producers (WAR on the cvt's sources)
-      asm volatile("s_nop 1" : "+v"(out[d][0]), "+v"(out[d][1]));
-    }
-#else
-    out[d][0] = pack2bf_scalar((dn[d][0] - xh[d][0] * dot) * rstd, (dn[d][1] - xh[d][1] * dot) * rstd);
-    out[d][1] = pack2bf_scalar((dn[d][2] - xh[d][2] * dot) * rstd, (dn[d][3] - xh[d][3] * dot) * rstd);
-#endif
-  }
-  NRB_FENCE(4);
-}
 
 // =============================================================================================
 // dQ: block = 128 queries (4 waves x 32), loop over 64-key tiles (K, V row tiles + K^T column tile)
@@ -753,9 +670,8 @@ int pick_waves(const qfx_attn_args* a) {
 // 83 vs 91 us; S = 4608 / 4864: 0.84 / 0.89 of two rounds, 258 vs 278 / 276 vs 315 us) and loses where they do not (S = 3584: 336 blocks =
 // 0.66 of two rounds, 208 vs 193 us; S = 1280: 120 blocks, 44 vs 34 us; S = 8576: 0.80 of four rounds, 931 vs 874 us) --
 // profiles/r05_attn_fwd64.json.
-bool pick_fwd64(const qfx_attn_args* a) {
-  const char* e = getenv("QFX_ATTN_FWD64");
-  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+// Whole-round test shared by the 64-query kernels: their 256-query blocks run one per CU.
+bool fills_rounds64(const qfx_attn_args* a) {
   const long hb = (long)a->H * a->B;
   const long b64 = (long)((a->S + 255) / 256) * hb, b4 = (long)((a->S + 127) / 128) * hb;
   const double e64 = (double)b64 / (double)(((b64 + 255) / 256) * 256);
@@ -763,6 +679,13 @@ bool pick_fwd64(const qfx_attn_args* a) {
   const double eo = e64 > e4 ? e64 : e4;      // the 32-query kernels: 8 waves x 256 queries quantise like the 64-query blocks, 4 x 128 like b4
   return e64 > 0.82 && e64 >= eo - 0.02;
 }
+bool pick_fwd64(const qfx_attn_args* a) {
+  const char* e = getenv("QFX_ATTN_FWD64");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return fills_rounds64(a);
+}
+// dQ on 64-query waves (qfx_attn64.hip): 118 vs 136 us at S = 2432, 1312 vs 1326 us at S = 8576 (profiles/r05_attn_dq64.json); same policy
+bool pick_dq64(const qfx_attn_args* a) { return fills_rounds64(a); }
 
 int check_common(const qfx_attn_args* a) {
   if (!a || a->B <= 0 || a->S <= 0 || a->H <= 0 || (a->S_pad % 64) || a->S_pad < a->S) return QFX_EINVAL;
@@ -834,6 +757,11 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
   if ((rc = check_head_lora(a, 1, 1))) return rc;
+  {   // dh = 128: the 64-query kernel of qfx_attn64.hip; QFX_ATTN_DQ64 = 0 / 1 forces the 32-query / 64-query kernel, default: pick_dq64
+    const char* e = getenv("QFX_ATTN_DQ64");
+    const bool forced = e && (e[0] == '0' || e[0] == '1');
+    if (a->dh == 128 && (forced ? e[0] == '1' : pick_dq64(a))) return qfxi::launch_attn_bwd_dq64(a, (hipStream_t)stream);
+  }
   const int nw = 4;   /* see pick_waves */
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
   if (a->dh == 128) {

@@ -98,6 +98,34 @@ template <class F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, st
 }
 template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// chunk' = chunk ^ swz64(row): one 16-byte-chunk swizzle of a [rows][256 B] LDS tile that serves ds_read_b128 fragments (the rows of a
+// 16-lane read group on one chunk) AND the transpose read of the 32x32x16 layout (4 rows x 4 chunks per half wave)
+__device__ __forceinline__ int swz64(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// Per-wave B-operand fragments (Q, dO; O for dsum) of a 32-row query block.  A lane of the MFMA layout owns ONE row: loading its
+// fragments straight from HBM touches 32 rows per wave instruction (48 such loads took 20 k cycles of the dQ prologue, 10 us).  Instead:
+// coalesced 16-byte loads in row order (a wave instruction = 4 whole rows) -> a wave-private 8 KB LDS slab (swz64) -> ds_read_b128 in
+// fragment order.  rows_issue() only requests (all tensors of a query block in flight together), rows_to_frags() does the LDS round trip.
+__device__ __forceinline__ void rows_issue(const bf16_t* base, int64_t ld, int row0, int S, int lane, u32x4 (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int r = row0 + 4 * i + (lane >> 4); r = r < S ? r : S - 1;
+    v[i] = *(const u32x4*)(base + (int64_t)r * ld + (lane & 15) * 8);
+  }
+}
+__device__ __forceinline__ void rows_to_frags(char* slab, int lane, const u32x4 (&v)[8], u32x4 (&f)[8]) {
+  const int lj = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = 4 * i + (lane >> 4);
+    *(u32x4*)(slab + r * 256 + (((lane & 15) ^ swz64(r)) << 4)) = v[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) f[ks] = *(const u32x4*)(slab + lj * 256 + (((2 * ks + hi) ^ swz64(lj)) << 4));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is rewritten by the next tensor
+}
+
 constexpr int TB = 64 * 128 * 2;          // bytes of a K (or V) tile
 constexpr int STG_LD = 272;               // staging row stride of the epilogue (bytes)
 
@@ -141,14 +169,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args 
   stage(1, 1);
   stage(2, 2);
 
-  // ---- Q fragments -> a[128:191], O^T = 0 -> a[0:127]
+  // ---- Q fragments -> a[128:191] (through the wave's slab in ring stage 3, free until the first tile issues LDS-DMA into it -- after the
+  // first barrier), O^T = 0 -> a[0:127]
   if (live) {
+    char* slab = smem + 3 * 2 * TB + w * 8192;
+    const bf16_t* qbase = a.Q + (int64_t)b * S * a.ldq + h * DH;
+    u32x4 qr[2][8];
+    rows_issue(qbase, a.ldq, q0, S, lane, qr[0]);
+    rows_issue(qbase, a.ldq, q0 + 32, S, lane, qr[1]);
     sfor<2>([&](auto QB) {
-      int q = q0 + 32 * QB.value + lj; q = q < S ? q : S - 1;
-      const bf16_t* qp = a.Q + ((int64_t)b * S + q) * a.ldq + h * DH + 8 * hi;
       u32x4 qv[8];
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) qv[ks] = *(const u32x4*)(qp + 16 * ks);
+      rows_to_frags(slab, lane, qr[QB.value], qv);
       sfor<8>([&](auto KS) {
         sfor<4>([&](auto I) { agpr_write<A_Q + 4 * (8 * QB.value + KS.value) + I.value>(qv[KS.value][I.value]); });
       });
@@ -171,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args 
   u32x4 P0[4], P1[4];        // packed P, B operand of k-step t = 2 kb + u
 
 #if defined(QFX_A64_TIMING)
-  uint64_t tph[6] = {0, 0, 0, 0, 0, 0}, tmark = 0;      // barrier, T1, T2, T3, T4, rest
+  uint64_t tph[6] = {0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();      // barrier, T1, T2, T3, T4, rest
 #define A64_T(i) do { asm volatile("s_nop 0" ::: "memory"); const uint64_t n_ = __builtin_readcyclecounter(); tph[i] += n_ - tmark; tmark = n_; } while (0)
 #else
 #define A64_T(i) do { } while (0)
@@ -418,6 +449,334 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args 
   }
 }
 
+
+// =============================================================================================================================
+// dQ with 64-query waves (round 5).  Per 64-key tile and wave: S^T = K Q^T and dP^T = V dO^T (2 x 32 MFMAs), dS = P (dP - dsum) on the VALU,
+// dQ^T += K^T dS (32 MFMAs) -- 96 MFMAs against ~290 VALU instructions: 3 per MFMA where the forward has 4.5, so unlike the forward this
+// loop can be bound by the matrix pipe.  Accumulator half: a[0:127] = dQ^T (4 d-blocks x 2 query blocks), a[128:191] = Q fragments,
+// a[192:255] = dO fragments (both B operands).  Every LDS fragment (K / V rows for S / dP, K^T by transpose read for dQ) feeds TWO MFMAs, one per
+// query block -- with one fragment per MFMA the four waves read 320 KB of LDS per tile, more than the 3072 MFMA cycles of a tile can
+// deliver (first build: 132 us, 30 % of the wave cycles in s_waitcnt) -- and the tile is skewed by KEY halves instead of query blocks:
+//   A  S(., kb 0), dP(., kb 0)     32 MFMAs | 16 K / V fragment reads
+//   B  S(., kb 1), dP(., kb 1)     32 MFMAs | 16 fragment reads, dS pairs 0..7 of both query blocks (the kb 0 values)
+//   C  dQ(.) += K^T dS, k-steps 0,1 16 MFMAs | 8 K^T fragments, pairs 8..11 (k-step 2)
+//   D  k-steps 2,3                  16 MFMAs | 8 K^T fragments, pairs 12..15 before k-step 3, the LDS-DMA pieces of tile jt + 3
+// Both tiles use ONE swizzle that serves ds_read_b128 (rows of a 16-lane group on one chunk) and the transpose read (4 rows x 4 chunks
+// per half wave): chunk' = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)).
+template <int BREG, bool FIRST> __device__ __forceinline__ void mfma_vb(f32x16& s, const bf16x8& af) {      // D (VGPR) (+)= A (VGPR) x B (AGPR)
+  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(af), "i"(BREG), "i"(BREG + 3));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(af), "i"(BREG), "i"(BREG + 3));
+}
+
+constexpr int A_DQ = 0, A_QF = 128, A_DO = 192;
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const qfx_attn_args a) {
+  constexpr int DH = 128;
+  __shared__ __attribute__((aligned(16))) char smem[8 * TB];       // 4 x [K | V] stages (see the forward); epilogue slabs re-use it
+  static_assert(8 * TB >= 4 * 64 * 512, "staging slabs must fit the ring");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, lj = lane & 31;
+#if defined(QFX_A64_TIMING)
+  const uint64_t t_entry = __builtin_readcyclecounter();
+#endif
+  int xb, h, b;
+  attn_block_coord((a.S + 255) / 256, a.H, xb, h, b);
+  const int S = a.S;
+  const int q0 = xb * 256 + w * 64;
+  const bool live = q0 < S;
+  const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
+  const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
+  const int ntiles = (S + 63) / 64;
+
+  auto stage_piece = [&](int jt, int buf, int i) {
+    char* dK = smem + buf * 2 * TB;
+    const int rr = lane >> 4, c = lane & 15, ii = i & 3;
+    const int row = 16 * w + 4 * ii + rr;
+    int s = jt * 64 + row; s = s < S ? s : S - 1;
+    const unsigned sc = (unsigned)((c ^ swz64(row)) * 8);
+    if (i < 4) glds16(Kb + (row_off(s, a.ldk) + sc), dK + (16 * w + 4 * ii) * 256);
+    else glds16(Vb + (row_off(s, a.ldv) + sc), dK + TB + (16 * w + 4 * ii) * 256);
+  };
+  auto stage = [&](int jt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_piece(jt, buf, i);
+  };
+  stage(0, 0);
+  stage(1, 1);
+  stage(2, 2);
+
+  // ---- Q, dO fragments -> accumulator half; dsum[q] = sum_d dO[q, d] O[q, d] (computed here, published for dK / dV); lse2[q]
+  float nlse[2] = {0.f, 0.f}, dsm[2] = {0.f, 0.f};
+  if (live) {
+    char* slab = smem + 3 * 2 * TB + w * 8192;      // ring stage 3 is free until tile 0 issues LDS-DMA into it (after the first barrier)
+    const bf16_t* qbase = a.Q + (int64_t)b * S * a.ldq + h * DH;
+    const bf16_t* dbase = a.dO + (int64_t)b * S * a.lddo + h * DH;
+    const bf16_t* obase = a.O + (int64_t)b * S * a.ldo + h * DH;
+    sfor<2>([&](auto QB) {
+      constexpr int qb = QB.value;
+      u32x4 qr[8], dr[8], orw[8], qv[8], dv[8], ov[8];
+      rows_issue(qbase, a.ldq, q0 + 32 * qb, S, lane, qr);
+      rows_issue(dbase, a.lddo, q0 + 32 * qb, S, lane, dr);
+      rows_issue(obase, a.ldo, q0 + 32 * qb, S, lane, orw);
+      int q = q0 + 32 * qb + lj; q = q < S ? q : S - 1;
+      nlse[qb] = -a.lse2[((int64_t)b * a.H + h) * a.S_pad + q];
+      rows_to_frags(slab, lane, qr, qv);
+      rows_to_frags(slab, lane, dr, dv);
+      rows_to_frags(slab, lane, orw, ov);
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          part += __uint_as_float(dv[ks][j] << 16) * __uint_as_float(ov[ks][j] << 16);
+          part += __uint_as_float(dv[ks][j] & 0xffff0000u) * __uint_as_float(ov[ks][j] & 0xffff0000u);
+        }
+      part += __shfl_xor(part, 32);
+      dsm[qb] = part;
+      if (hi == 0 && q0 + 32 * qb + lj < S) a.dsum[((int64_t)b * a.H + h) * a.S_pad + q] = part;
+      sfor<8>([&](auto KS) {
+        sfor<4>([&](auto I) {
+          agpr_write<A_QF + 4 * (8 * qb + KS.value) + I.value>(qv[KS.value][I.value]);
+          agpr_write<A_DO + 4 * (8 * qb + KS.value) + I.value>(dv[KS.value][I.value]);
+        });
+      });
+    });
+    sfor<128>([&](auto I) { agpr_write<A_DQ + I.value>(0u); });
+  }
+  const float c2 = a.scale * LOG2E;
+  const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
+
+  // lane-constant LDS offsets under swz64.  b128 fragment of a row tile: row 32 kb + lj, chunk 2 ks + hi.  Transposed fragment: rows
+  // 16 t + 4 hi + j' (first read, (row >> 2) & 3 = hi) and + 8 (second, = hi ^ 2), d columns 32 db + 16 gq + 4 mq.
+  const int koff0 = lj * 256 + ((hi ^ swz64(lj)) << 4);                   // ^ (ks << 5), + kb * 8192
+  const int jq = (lane & 15) >> 2, mq = lane & 3, gq = (lane >> 4) & 1;
+  const int tbase = (4 * hi + jq) * 256 + (mq & 1) * 8;
+  const int toffa = tbase + (((2 * gq + (mq >> 1)) ^ ((jq << 2) | hi)) << 4);              // ^ (db << 6), + t * 4096
+  const int toffb = tbase + 2048 + (((2 * gq + (mq >> 1)) ^ ((jq << 2) | (hi ^ 2))) << 4);
+
+  f32x16 Sq[2][2], Dq[2][2];              // scores and dP: [query block][key block]
+  u32x4 Pq[2][4];                         // packed dS of a query block, B operand of k-step t
+  int b_cur = 0, b_nxt = 1, b_nn = 2, b_dma = 3;
+#if defined(QFX_A64_TIMING)
+  uint64_t tph[6] = {0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
+  const uint64_t t_loop0 = tmark;
+#endif
+  for (int jt = 0; jt < ntiles; ++jt) {
+    A64_T(5);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    A64_T(0);
+    if (!live) {
+      stage(jt + 3, b_dma);
+      const int t_ = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = b_dma; b_dma = t_;
+      continue;
+    }
+    const char* sK = smem + b_cur * 2 * TB;
+    const char* sV = sK + TB;
+    const int j0 = jt * 64;
+    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);
+    const float cs = need_mask ? 1.0f : c2;
+
+    // K / V fragment m of a key half (m = 0..15: ks = m / 2, even = K, odd = V), through a 6-deep ring requested 5 fragments ahead, two
+    // MFMAs (query block 0, 1) per fragment; K^T fragment n (n = 0..15: k-step t = n / 4, d block db = n & 3) through a 4-deep ring
+    // requested 3 ahead.  hipcc counts all of these LDS reads.
+    constexpr int PF = 5, RING = 6, PFT = 3, RINGT = 4;
+    bf16x8 fr[RING], kt[RINGT];
+    auto frag = [&](int g) {                // g = 0..31 over both key halves: kb = g / 16
+      const int kb = g >> 4, ks = (g & 15) >> 1;
+      return *(const bf16x8*)(((g & 1) ? sV : sK) + kb * 8192 + (koff0 ^ (ks << 5)));
+    };
+    auto ktreq = [&](auto N) {
+      constexpr int n = N.value;
+      if constexpr (n < 16) {
+        const char* pa = sK + (toffa ^ ((n & 3) << 6)) + (n >> 2) * 4096;
+        const char* pb = sK + (toffb ^ ((n & 3) << 6)) + (n >> 2) * 4096;
+        const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)pa);
+        const bf16x4v hv = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)pb);
+        const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hv);
+        bf16x8 r;
+        r[0] = l4[0]; r[1] = l4[1]; r[2] = l4[2]; r[3] = l4[3]; r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
+        kt[n % RINGT] = r;
+      }
+    };
+    // one fragment of phase A / B: g = 16 KB + m -> S (even m) or dP (odd m) of BOTH query blocks, key block KB
+    auto sd_frag = [&](auto KB, auto M, auto&& mid) {
+      constexpr int kb = KB.value, m = M.value, ks = m >> 1, g = 16 * kb + m;
+      if constexpr (g + PF < 32) fr[(g + PF) % RING] = frag(g + PF);
+      if constexpr ((m & 1) == 0) mfma_vb<A_QF + 4 * ks, ks == 0>(Sq[0][kb], fr[g % RING]);
+      else mfma_vb<A_DO + 4 * ks, ks == 0>(Dq[0][kb], fr[g % RING]);
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((m & 1) == 0) mfma_vb<A_QF + 4 * (8 + ks), ks == 0>(Sq[1][kb], fr[g % RING]);
+      else mfma_vb<A_DO + 4 * (8 + ks), ks == 0>(Dq[1][kb], fr[g % RING]);
+    };
+    // dS of one pair of keys (values k, k + 1 of query block qb; k = 16 kb + r): p = exp2(s cs - lse), ds = p (dp - dsum), packed -- in TWO
+    // statements of five instructions, one behind each of the two MFMAs of a fragment: a lone wave hides <= 5 single-issue instructions
+    // per 32x32x16 MFMA gap (MI355X_MICROARCH "one wave per SIMD"); ten behind the second MFMA and none behind the first measured fully
+    // additive (phase B 1769 instead of ~1100 cycles).
+    float pt0 = 0.f, pt1 = 0.f, pu0 = 0.f, pu1 = 0.f;
+    auto ds_half1 = [&](auto QB, auto PI) {
+      constexpr int qb = QB.value, k = 2 * PI.value;
+      float t0, t1, u0, u1;        // (locals: clang does not capture a variable that is named only in an asm constraint of a nested generic lambda)
+      asm volatile("v_fma_f32 %0, %4, %8, %9\n\tv_fma_f32 %1, %5, %8, %9\n\tv_sub_f32 %2, %6, %10\n\tv_sub_f32 %3, %7, %10\n\tv_exp_f32 %0, %0"
+                   : "=&v"(t0), "=&v"(t1), "=&v"(u0), "=&v"(u1)
+                   : "v"(Sq[qb][k >> 4][k & 15]), "v"(Sq[qb][k >> 4][(k & 15) + 1]), "v"(Dq[qb][k >> 4][k & 15]), "v"(Dq[qb][k >> 4][(k & 15) + 1]), "v"(cs),
+                     "v"(nlse[qb]), "v"(dsm[qb]));
+      pt0 = t0; pt1 = t1; pu0 = u0; pu1 = u1;
+    };
+    auto ds_half2 = [&](auto QB, auto PI) {
+      constexpr int qb = QB.value, pi = PI.value;
+      uint32_t pw;
+      float t0 = pt0, t1 = pt1;
+      const float u0 = pu0, u1 = pu1;
+      asm volatile("v_exp_f32 %2, %2\n\tv_mul_f32 %1, %1, %3\n\tv_mul_f32 %2, %2, %4\n\tv_cvt_pk_bf16_f32 %0, %1, %2"
+                   : "=&v"(pw), "+v"(t0), "+v"(t1) : "v"(u0), "v"(u1));
+      Pq[qb][pi >> 2][pi & 3] = pw;
+    };
+    auto mask_block = [&](f32x16& sv, int kb) {      // off the headline path: scale + additive mask, -inf (=> p = 0) for keys past S
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int key0 = j0 + 32 * kb + 8 * c + 4 * hi;
+        f32x4 mk4 = {0.f, 0.f, 0.f, 0.f};
+        if (maskb != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mk4[r] = maskb[(key0 + r) < S ? (key0 + r) : S - 1] * LOG2E;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[4 * c + r] = (key0 + r) < S ? sv[4 * c + r] * c2 + mk4[r] : -INFINITY;
+      }
+    };
+    // one K^T fragment of phase C / D: dQ^T(db, qb) += K^T(t, db) dS(qb, t) for both query blocks
+    auto dq_frag = [&](auto N, auto&& mid) {
+      constexpr int n = N.value, t = n >> 2, db = n & 3;
+      ktreq(std::integral_constant<int, n + PFT>{});
+      mfma_pv<A_DQ + 16 * (2 * db + 0)>(kt[n % RINGT], Pq[0][t]);
+      mid();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pv<A_DQ + 16 * (2 * db + 1)>(kt[n % RINGT], Pq[1][t]);
+    };
+
+    sfor<PF>([&](auto P) { fr[P.value % RING] = frag(P.value); });
+    // A: key half 0; the LDS-DMA pieces of tile jt + 3, one per four MFMAs
+    sfor<16>([&](auto M) {
+      constexpr int m = M.value;
+      sd_frag(std::integral_constant<int, 0>{}, M, [&] { if constexpr (m % 2 == 1) stage_piece(jt + 3, b_dma, m / 2); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(1);
+    // B: key half 1; dS pairs 0..7 of both query blocks, one per fragment (the MFMAs that wrote S / dP of key half 0 are >= 2 back)
+    sfor<16>([&](auto M) {
+      constexpr int m = M.value;
+      using QB = std::integral_constant<int, m & 1>;
+      using PI = std::integral_constant<int, m / 2>;
+      if constexpr (m == 0) { if (need_mask) { mask_block(Sq[0][0], 0); mask_block(Sq[1][0], 0); } }
+      sd_frag(std::integral_constant<int, 1>{}, M, [&] { ds_half1(QB{}, PI{}); });
+      ds_half2(QB{}, PI{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(2);
+    // C: k-steps 0, 1 of dQ; dS pairs 8..11 (k-step 2) of both query blocks
+    sfor<PFT>([&](auto P) { ktreq(P); });
+    sfor<8>([&](auto N) {
+      constexpr int n = N.value;
+      using QB = std::integral_constant<int, n & 1>;
+      using PI = std::integral_constant<int, 8 + n / 2>;
+      if constexpr (n == 0) { if (need_mask) { mask_block(Sq[0][1], 1); mask_block(Sq[1][1], 1); } }
+      dq_frag(N, [&] { ds_half1(QB{}, PI{}); });
+      ds_half2(QB{}, PI{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(3);
+    // D: k-steps 2, 3.  Every MFMA of k-step 3 (fragments 12..15) reads all of pairs 12..15, and those need S / dP of key half 1, complete only
+    // at the end of B: 16 pairs for the 12 fragments of C and D's first half.  The four fragments of k-step 2 therefore carry TWO pairs
+    // each (9 instructions per gap instead of 5: ~ +200 cycles per tile); the pair state lives in statement-local registers.
+    sfor<8>([&](auto N) {
+      constexpr int n = N.value;
+      if constexpr (n < 4) {
+        using P0 = std::integral_constant<int, 12 + n>;
+        dq_frag(std::integral_constant<int, 8 + n>{}, [&] { ds_half1(std::integral_constant<int, 0>{}, P0{}); ds_half2(std::integral_constant<int, 0>{}, P0{}); });
+        ds_half1(std::integral_constant<int, 1>{}, P0{});
+        ds_half2(std::integral_constant<int, 1>{}, P0{});
+      } else {
+        dq_frag(std::integral_constant<int, 8 + n>{}, [&] {});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    A64_T(4);
+    { const int t_ = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = b_dma; b_dma = t_; }
+  }
+#if defined(QFX_A64_TIMING)
+  if (lane == 0 && blockIdx.x < 16) {      // caller over-allocates dsum by 16 * 4 * 8 floats in the timing build
+    float* dbg = a.dsum + ((int64_t)a.B * a.H) * a.S_pad + (blockIdx.x * 4 + w) * 8;
+    for (int i = 0; i < 6; ++i) dbg[i] = (float)tph[i];
+    dbg[6] = (float)ntiles;
+    dbg[7] = (float)(t_loop0 - t_entry);       // prologue
+  }
+  const uint64_t t_loop1 = __builtin_readcyclecounter();
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (!live) return;
+
+  // ---- epilogue: ALL of dQ^T (fp32) leaves the accumulator half first (the compiler's own MFMAs of the fused rank-r projection below take
+  // accumulator registers of their choosing) -> LDS slab of this wave [64 rows][512 B], 16-byte chunks XOR-swizzled by row & 7 -> the
+  // 16-row fragment layout of qfx_attn.hip -> its epilogue code (QK-norm + RoPE backward, wide stores, fused projection)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  char* stg = smem + w * (64 * 512);
+  const int g = lane >> 4, li = lane & 15;
+  const bool wide = rows_16b(a.dQ, a.lddq);
+  sfor<2>([&](auto QB) {
+    sfor<4>([&](auto DB) {
+      sfor<4>([&](auto C) {
+        constexpr int reg = A_DQ + 16 * (2 * DB.value + QB.value) + 4 * C.value;
+        const f32x4 v = {agpr_read<reg>(), agpr_read<reg + 1>(), agpr_read<reg + 2>(), agpr_read<reg + 3>()};
+        const int row = 32 * QB.value + lj, chunk = 8 * DB.value + 2 * C.value + hi;
+        *(f32x4*)(stg + row * 512 + ((chunk ^ (row & 7)) << 4)) = v;
+      });
+    });
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int f4 = 0; f4 < 4; ++f4) {
+    const int qf0 = q0 + 16 * f4;
+    if (qf0 >= S) break;                                // wave-uniform
+    f32x4 dq[DH / 16][2];
+    const int row = 16 * f4 + li;
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d) {
+      dq[d][0] = *(const f32x4*)(stg + row * 512 + (((4 * d + g) ^ (row & 7)) << 4));
+      dq[d][1] = dq[d][0];
+    }
+    const int q = qf0 + li;
+    const int qc = q < S ? q : S - 1;
+    bf16_t* op = a.dQ + ((int64_t)b * S + qc) * a.lddq + h * DH;
+    u32x2 u[DH / 16];
+    if (a.qk_saved) {
+      norm_rope_bwd_row<DH>(dq, 0, a.scale, a.qk_saved + ((int64_t)b * S + qc) * a.ld_saved + h * DH + 4 * g,
+                            a.rope + (int64_t)b * a.rope_bstride + ((int64_t)qc * (DH / 2) + 2 * g) * 2,
+                            (qc < a.T ? a.wq_txt : a.wq_img) + 4 * g, a.norm_eps, a.norm_flags, u);
+      store_frag<DH>(op, u, g, q < S, wide);
+      head_lora_frag<DH>(a.hl[1], h, a.T, qf0, (int64_t)b * S + qc, q < S, u, g, li);
+    } else {
+#pragma unroll
+      for (int d = 0; d < DH / 16; ++d) {
+        u[d][0] = pack2bf(dq[d][0][0] * a.scale, dq[d][0][1] * a.scale);
+        u[d][1] = pack2bf(dq[d][0][2] * a.scale, dq[d][0][3] * a.scale);
+      }
+      store_frag<DH>(op, u, g, q < S, wide);
+    }
+  }
+#if defined(QFX_A64_TIMING)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && blockIdx.x < 16) {
+    float* dbg = a.dsum + ((int64_t)a.B * a.H) * a.S_pad + (blockIdx.x * 4 + w) * 8;
+    dbg[5] = (float)(__builtin_readcyclecounter() - t_loop1);      // epilogue (overwrites "loop rest")
+  }
+#endif
+}
+
 }  // namespace
 
 namespace qfxi {
@@ -425,6 +784,12 @@ namespace qfxi {
 int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream) {
   dim3 grid(((a->S + 255) / 256) * a->H * a->B);
   hipLaunchKernelGGL(attn_fwd64_kernel, grid, dim3(256), 0, stream, *a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? QFX_OK : -(1000 + (int)e);
+}
+int launch_attn_bwd_dq64(const qfx_attn_args* a, hipStream_t stream) {
+  dim3 grid(((a->S + 255) / 256) * a->H * a->B);
+  hipLaunchKernelGGL(attn_bwd_dq64_kernel, grid, dim3(256), 0, stream, *a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? QFX_OK : -(1000 + (int)e);
 }

@@ -188,5 +188,91 @@ __device__ __forceinline__ bool rows_16b(const void* base, int64_t ld_elems) {
 }
 
 
+// Backward of QK RMSNorm + RoPE on one gradient row held in the 16x16 accumulator layout (lane (g, li): row li of fragment f,
+// columns 16 d + 4 g + r): the arithmetic of qk_norm_rope_kernel<DH, true> (qfx_elem.hip) on the bf16-rounded attention gradient
+//   dn = [rbf](rbf(dy * conj(rope)) * w) ;  xh = x * rstd ;  out = (dn - xh * mean(dn * xh)) * rstd
+// with the row statistics folded over the four lane groups by two shuffles.  x = the saved pre-norm row, out packed bf16 per d.
+template <int DH>
+__device__ __forceinline__ void norm_rope_bwd_row(const f32x4 (&acc)[DH / 16][2], int f, float out_scale, const bf16_t* xrow,
+                                                  const float* rrow, const bf16_t* wrow, float eps, int flags, u32x2 (&out)[DH / 16]) {
+  constexpr int DF = DH / 16;
+  float xh[DF][4], dn[DF][4];
+  float ss = 0.f;
+  NRB_FENCE(0);
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    const u32x2 ux = *(const u32x2*)(xrow + d * 16);
+    xh[d][0] = __uint_as_float(ux[0] << 16); xh[d][1] = __uint_as_float(ux[0] & 0xffff0000u);
+    xh[d][2] = __uint_as_float(ux[1] << 16); xh[d][3] = __uint_as_float(ux[1] & 0xffff0000u);
+    NRB_OPQ4(4, xh[d][0], xh[d][1], xh[d][2], xh[d][3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss += xh[d][r] * xh[d][r];
+  }
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float rstd = rsqrtf(ss / (float)DH + eps);
+  float dot = 0.f;
+  NRB_FENCE(1);
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    const f32x4 cs = *(const f32x4*)(rrow + d * 16);            // (cos, sin) of the pairs (16 d + 4 g)/2 and +1
+    const u32x2 uw = *(const u32x2*)(wrow + d * 16);
+    const float w0 = __uint_as_float(uw[0] << 16), w1 = __uint_as_float(uw[0] & 0xffff0000u);
+    const float w2 = __uint_as_float(uw[1] << 16), w3 = __uint_as_float(uw[1] & 0xffff0000u);
+    float e0 = rbf(acc[d][f][0] * out_scale), e1 = rbf(acc[d][f][1] * out_scale);
+    float e2 = rbf(acc[d][f][2] * out_scale), e3 = rbf(acc[d][f][3] * out_scale);
+    NRB_OPQ4(0, e0, e1, e2, e3);
+    float d0 = rbf(e0 * cs[0] + e1 * cs[1]), d1 = rbf(-e0 * cs[1] + e1 * cs[0]);     // dy * conj(f)
+    float d2 = rbf(e2 * cs[2] + e3 * cs[3]), d3 = rbf(-e2 * cs[3] + e3 * cs[2]);
+    NRB_OPQ4(1, d0, d1, d2, d3);
+    dn[d][0] = (flags & 1) ? d0 * w0 : rbf(d0 * w0);
+    dn[d][1] = (flags & 1) ? d1 * w1 : rbf(d1 * w1);
+    dn[d][2] = (flags & 1) ? d2 * w2 : rbf(d2 * w2);
+    dn[d][3] = (flags & 1) ? d3 * w3 : rbf(d3 * w3);
+    NRB_OPQ4(2, dn[d][0], dn[d][1], dn[d][2], dn[d][3]);
+    if constexpr (((QFX_NRB_FENCE) >> 9) & 1) {
+      asm volatile("s_nop 1" : "+v"(dn[d][0]), "+v"(dn[d][1]), "+v"(dn[d][2]), "+v"(dn[d][3]));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xh[d][r] *= rstd; dot += dn[d][r] * xh[d][r]; }
+    NRB_OPQ4(3, xh[d][0], xh[d][1], xh[d][2], xh[d][3]);
+  }
+  NRB_FENCE(2);
+  dot += __shfl_xor(dot, 16);
+  dot += __shfl_xor(dot, 32);
+  dot /= (float)DH;
+  NRB_FENCE(3);
+  // pack2bf_scalar, not pack2bf (round 4), and QFX_NRB_OPQ bit 0 (round 5).  With the one-instruction packing, hipcc's SLP vectoriser
+  // re-shapes the whole function into v_pk_*_f32 pairs, and the dQ kernel then came out different from run to run: in ~0.3 % of the
+  // 16-row fragments ONE column -- an odd r of lane group g = 3, i.e. the HIGH register of a packed pair, lanes 48-63 -- is wrong in
+  // all 16 rows BEFORE the row statistics are formed (every other column then moves by an ulp through `dot`).  Round 5 bisection
+  // (tools/nondet_bisect.py, tools/hazard_probe/, profiles/r05_nondeterminism.md): not a missing wait (-amdgpu-waitcnt-forcezero: still
+  // 11 / 11), not a fixed-distance hazard (32 idle states at 11 places, 2-16 between producer and consumer: still differs), not the
+  // store tail or the head-LoRA MFMAs (off: still differs); gone with -fno-slp-vectorize and gone when ONLY the products
+  // acc * out_scale are kept scalar.  The instruction pairs replayed in isolation (2e9 checks each, with VMEM returns, SALU rewrites
+  // of the unused SGPR half and a partner wave's MFMAs) never fail: the trigger needs this kernel's surroundings and was not reduced
+  // further.  Both guards stay; tests/test_kernels_gpu.py::test_attention_kernels_are_bit_reproducible watches all three kernels.
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+#if defined(QFX_NRB_PACK1)
+    float o0 = (dn[d][0] - xh[d][0] * dot) * rstd, o1 = (dn[d][1] - xh[d][1] * dot) * rstd;
+    float o2 = (dn[d][2] - xh[d][2] * dot) * rstd, o3 = (dn[d][3] - xh[d][3] * dot) * rstd;
+    NRB_OPQ4(5, o0, o1, o2, o3);
+    if constexpr (((QFX_NRB_FENCE) >> 8) & 1) {       // producers (possibly v_pk_*_f32) | 2 idle states | consumers (v_cvt_pk_bf16_f32)
+      asm volatile("s_nop %c4" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3) : "i"(QFX_NRB_NOPS));
+    }
+    out[d][0] = pack2bf(o0, o1);
+    out[d][1] = pack2bf(o2, o3);
+    if constexpr (((QFX_NRB_FENCE) >> 10) & 1) {      // consumers | 2 idle states | the next d's producers (WAR on the cvt's sources)
+      asm volatile("s_nop 1" : "+v"(out[d][0]), "+v"(out[d][1]));
+    }
+#else
+    out[d][0] = pack2bf_scalar((dn[d][0] - xh[d][0] * dot) * rstd, (dn[d][1] - xh[d][1] * dot) * rstd);
+    out[d][1] = pack2bf_scalar((dn[d][2] - xh[d][2] * dot) * rstd, (dn[d][3] - xh[d][3] * dot) * rstd);
+#endif
+  }
+  NRB_FENCE(4);
+}
+
 }  // namespace
 

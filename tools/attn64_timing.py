@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
 from qflux_amd import _lib as L
 var = C.CDLL(os.path.join(ROOT, "tools", "_ab", "libqfx_a64t.so"))
 var.qfx_attn_fwd.argtypes = [C.POINTER(L.AttnArgs), C.c_void_p]; var.qfx_attn_fwd.restype = C.c_int
+var.qfx_attn_bwd_dq.argtypes = [C.POINTER(L.AttnArgs), C.c_void_p]; var.qfx_attn_bwd_dq.restype = C.c_int
+os.environ["QFX_ATTN_FWD64"] = "1"; os.environ["QFX_ATTN_DQ64"] = "1"
 BF = torch.bfloat16; DEV = "cuda:0"
 for S in (2432, 8576):
     Bn, H, dh = 1, 24, 128; D = H * dh; S_pad = (S + 63) // 64 * 64
@@ -27,3 +29,14 @@ for S in (2432, 8576):
     print(f"S={S} tiles={nt:.0f}: cycles per tile and wave (mean over waves 0-1 of 16 blocks): " + "  ".join(f"{n} {live[:, :, i].mean().item() / nt:.0f}" for i, n in enumerate(names)) +
           f"   total {live[:, :, :6].sum(-1).mean().item() / nt:.0f}")
     print("   block 0 per wave:", [[round(x / nt) for x in d[0, w, :6].tolist()] for w in range(4)])
+    # dQ
+    dO = torch.randn(Bn, S, D, device=DEV).to(BF); dsum = torch.zeros(Bn * H * S_pad + 16 * 4 * 8, device=DEV); dqkv = torch.zeros_like(qkv)
+    a.dO, a.lddo, a.dsum = dO.data_ptr(), D, dsum.data_ptr()
+    a.dQ, a.dK, a.dV = dqkv.data_ptr(), dqkv.data_ptr() + 2 * D, dqkv.data_ptr() + 4 * D
+    a.lddq = a.lddk = a.lddv = 3 * D
+    for _ in range(3): assert var.qfx_attn_bwd_dq(C.byref(a), st) == 0
+    torch.cuda.synchronize()
+    d = dsum[Bn * H * S_pad:].view(16, 4, 8).cpu()
+    live = d[:, :2]
+    print(f"S={S} dQ64: cycles per tile and wave: " + "  ".join(f"{n} {live[:, :, i].mean().item() / nt:.0f}" for i, n in enumerate(names[:5])) + f"   loop total {live[:, :, :5].sum(-1).mean().item() / nt:.0f}"
+          f"   per wave: prologue {live[:, :, 7].mean().item():.0f}  loop {live[:, :, :5].sum(-1).mean().item():.0f}  epilogue {live[:, :, 5].mean().item():.0f} cycles")
