@@ -15,6 +15,7 @@
 
 namespace qfxi {      // qfx_attn64.hip
 int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream);
+int launch_attn_fwd64p(const qfx_attn_args* a, hipStream_t stream);
 int launch_attn_bwd_dq64(const qfx_attn_args* a, hipStream_t stream);
 }
 
@@ -723,7 +724,14 @@ extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   // dh = 128: 64-query waves, one per SIMD, on the 32x32x16 MFMA with hand-allocated accumulator registers (qfx_attn64.hip, round 5)
   // where its 256-query blocks fill whole rounds of the 256 CUs (pick_fwd64).  QFX_ATTN_FWD64 = 0 / 1 forces the 32-query kernels /
   // the 64-query kernel (A/B lever and tests; read per launch so that one process can compare both).
-  if (a->dh == 128 && pick_fwd64(a)) return qfxi::launch_attn_fwd64(a, (hipStream_t)stream);
+  if (a->dh == 128 && pick_fwd64(a)) {
+    // two 64-query forms exist: query blocks skewed by half a tile (default; 84.5 us at S = 2432) and a continuous pipeline over 32-key
+    // sub-tiles ("1p"; 88.0 us: a lone wave issues one instruction per ~6.4 cycles whatever their placement, and the pipeline needs ~30
+    // more of them per tile -- profiles/r05_attn_fwd64.json)
+    const char* e = getenv("QFX_ATTN_FWD64");
+    const bool piped = e && e[0] == '1' && e[1] == 'p';
+    return piped ? qfxi::launch_attn_fwd64p(a, (hipStream_t)stream) : qfxi::launch_attn_fwd64(a, (hipStream_t)stream);
+  }
   const int nw = pick_waves(a);
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
   if (a->dh == 128) {

@@ -26,6 +26,13 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// ablation lever (wrong results): -DQFX_A64_NOEXP replaces the exponentials of the pipelined forward by moves -- what do they cost a lone wave?
+#if defined(QFX_A64_NOEXP)
+#define A64_EXP "v_mov_b32"
+#else
+#define A64_EXP "v_exp_f32"
+#endif
+
 #ifndef ATTN_DEFER_MAX
 #define ATTN_DEFER_MAX 8.0f
 #endif
@@ -86,6 +93,10 @@ template <int KREG, int OFF> __device__ __forceinline__ void k_load(uint32_t lds
 template <int OREG> __device__ __forceinline__ void mfma_pv(const bf16x8& vf, const u32x4& pf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pf), "i"(OREG), "i"(OREG + 15) : A64_CLOB);
 }
+template <int BREG, bool FIRST> __device__ __forceinline__ void mfma_vb(f32x16& s, const bf16x8& af) {      // D (VGPR) (+)= A (VGPR) x B (AGPR)
+  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(af), "i"(BREG), "i"(BREG + 3));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(af), "i"(BREG), "i"(BREG + 3));
+}
 __device__ __forceinline__ float vmax3(float a, float b, float c) {      // one instruction, no canonicalising v_max on the asm-produced scores
   float m;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
@@ -97,6 +108,16 @@ template <class F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, st
   (f(std::integral_constant<int, I>{}), ...);
 }
 template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// LDS-DMA piece issued from an asm statement (cdna_hip_programming.md 5.7: M0 is written in the statement that reads it).  hipcc does not
+// know these writes to LDS exist.  With the builtin it does, cannot tell which ring stage a ds_read touches, and puts an
+// s_waitcnt vmcnt(0) in front of fragment reads -- the whole asynchronous ring then waits for its youngest pieces inside the tile loop
+// (found in round 5: X phases of 1200 instead of ~800 cycles).  Completion is tracked by hand: vmcnt(8) / vmcnt(0) at the tile seams.
+__device__ __forceinline__ void glds16a(const bf16_t* g, char* lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+}
 
 // chunk' = chunk ^ swz64(row): one 16-byte-chunk swizzle of a [rows][256 B] LDS tile that serves ds_read_b128 fragments (the rows of a
 // 16-lane read group on one chunk) AND the transpose read of the 32x32x16 layout (4 rows x 4 chunks per half wave)
@@ -158,8 +179,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args 
     const int rr = lane >> 4, c = lane & 15, ii = i & 3;
     const int row = 16 * w + 4 * ii + rr;
     int s = jt * 64 + row; s = s < S ? s : S - 1;
-    if (i < 4) glds16(Kb + (row_off(s, a.ldk) + (unsigned)((c ^ swz_row<DH>(row)) * 8)), dK + (16 * w + 4 * ii) * 256);
-    else glds16(Vb + (row_off(s, a.ldv) + (unsigned)((c ^ (rr << 2)) * 8)), dK + TB + (16 * w + 4 * ii) * 256);
+    if (i < 4) glds16a(Kb + (row_off(s, a.ldk) + (unsigned)((c ^ swz_row<DH>(row)) * 8)), dK + (16 * w + 4 * ii) * 256);
+    else glds16a(Vb + (row_off(s, a.ldv) + (unsigned)((c ^ (rr << 2)) * 8)), dK + TB + (16 * w + 4 * ii) * 256);
   };
   auto stage = [&](int jt, int buf) {
 #pragma unroll
@@ -451,6 +472,321 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args 
 
 
 // =============================================================================================================================
+// Forward, third form (round 5): a CONTINUOUS software pipeline over 32-key sub-tiles.  The skewed kernel above puts the softmax of a
+// query block into the gaps of 16 MFMAs (8-9 instructions per gap) and leaves the gaps of the other two phases almost empty; a lone wave
+// hides <= 5 single-issue instructions per 32x32x16 MFMA gap.  Here iteration i issues
+//   X_i  the 16 QK^T MFMAs of sub-tile i + 1 (8 K fragments, each feeding BOTH query blocks -- no fragment cache needed), then
+//   Y_i  the 16 PV MFMAs of sub-tile i (8 V^T fragments, both query blocks),
+// with the online softmax of sub-tile i (2 x 16 scores per lane) laid into those 32 gaps: maxima (4 + 4 instructions per query block),
+// the lazy-reference vote, ten pair statements (7 instructions) in X, six more and the two finishing statements in the first gaps of
+// Y -- P of k-step 0 is complete before Y starts, P of k-step 1 before its first MFMA -- then the LDS-DMA pieces of tile j + 3.  The
+// online softmax runs per 32-key sub-tile (reference maximum, row sum and the rare rescale of O^T; the rescale sits in X, where only
+// QK^T MFMAs are in flight).  Scores are double-buffered across sub-tiles (2 x 32 registers); barriers, ring and prologue as above.
+__global__ __launch_bounds__(256, 1) void attn_fwd64p_kernel(const qfx_attn_args a) {
+  constexpr int DH = 128;
+  __shared__ __attribute__((aligned(16))) char smem[8 * TB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, lj = lane & 31;
+  int xb, h, b;
+  attn_block_coord((a.S + 255) / 256, a.H, xb, h, b);
+  const int S = a.S;
+  const int q0 = xb * 256 + w * 64;
+  const bool live = q0 < S;
+  const bf16_t* Kb = a.K + (int64_t)b * S * a.ldk + h * DH;
+  const bf16_t* Vb = a.V + (int64_t)b * S * a.ldv + h * DH;
+  const int ntiles = (S + 63) / 64;
+
+  auto stage_piece = [&](int jt, int buf, int i) {
+    char* dK = smem + buf * 2 * TB;
+    const int rr = lane >> 4, c = lane & 15, ii = i & 3;
+    const int row = 16 * w + 4 * ii + rr;
+    int s = jt * 64 + row; s = s < S ? s : S - 1;
+    const unsigned sc = (unsigned)((c ^ swz64(row)) * 8);
+    if (i < 4) glds16a(Kb + (row_off(s, a.ldk) + sc), dK + (16 * w + 4 * ii) * 256);
+    else glds16a(Vb + (row_off(s, a.ldv) + sc), dK + TB + (16 * w + 4 * ii) * 256);
+  };
+  auto stage = [&](int jt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_piece(jt, buf, i);
+  };
+  stage(0, 0);
+  stage(1, 1);
+  stage(2, 2);
+
+  if (live) {
+    char* slab = smem + 3 * 2 * TB + w * 8192;
+    const bf16_t* qbase = a.Q + (int64_t)b * S * a.ldq + h * DH;
+    u32x4 qr[2][8];
+    rows_issue(qbase, a.ldq, q0, S, lane, qr[0]);
+    rows_issue(qbase, a.ldq, q0 + 32, S, lane, qr[1]);
+    sfor<2>([&](auto QB) {
+      u32x4 qv[8];
+      rows_to_frags(slab, lane, qr[QB.value], qv);
+      sfor<8>([&](auto KS) {
+        sfor<4>([&](auto I) { agpr_write<A_Q + 4 * (8 * QB.value + KS.value) + I.value>(qv[KS.value][I.value]); });
+      });
+    });
+    sfor<128>([&](auto I) { agpr_write<A_O + I.value>(0u); });
+  }
+
+  float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+  const float c2 = a.scale * LOG2E;
+  const float* maskb = a.key_mask ? a.key_mask + (int64_t)b * S : nullptr;
+
+  // lane-constant LDS offsets under swz64 (both tiles): b128 fragment row 32 kb + lj, chunk 2 ks + hi; transposed fragment rows
+  // 16 t + 4 hi + j' (+ 8), d columns 32 db + 16 gq + 4 mq
+  const int koff0 = lj * 256 + ((hi ^ swz64(lj)) << 4);
+  const int jq = (lane & 15) >> 2, mq = lane & 3, gq = (lane >> 4) & 1;
+  const int tbase = (4 * hi + jq) * 256 + (mq & 1) * 8;
+  const int toffa = tbase + (((2 * gq + (mq >> 1)) ^ ((jq << 2) | hi)) << 4);
+  const int toffb = tbase + 2048 + (((2 * gq + (mq >> 1)) ^ ((jq << 2) | (hi ^ 2))) << 4);
+
+  f32x16 Sa[2], Sb[2];       // scores of the current / next sub-tile per query block (roles swap every sub-tile)
+  u32x4 Pw[2][2];            // packed P of the current sub-tile: [query block][k-step u]
+  constexpr int RK = 4, PFK = 3, RV = 4, PFV = 3;
+  bf16x8 kf[RK], vf[RV];
+  float mxs[2] = {0.f, 0.f}, negm[2] = {0.f, 0.f}, ls0[2] = {0.f, 0.f}, ls1[2] = {0.f, 0.f}, pe0[2] = {0.f, 0.f}, pe1[2] = {0.f, 0.f};
+  float mt[2][4];
+
+  int b_cur = 0, b_nxt = 1, b_nn = 2, b_dma = 3;
+  if (live) {
+    // tile 0 has landed (16 younger requests -- tiles 1, 2 -- may be in flight); every wave's has
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (live) {      // QK^T of sub-tile 0 -> Sa (no softmax to overlap yet)
+    const char* sK0 = smem;
+    sfor<8>([&](auto KS) {
+      const bf16x8 f = *(const bf16x8*)(sK0 + (koff0 ^ (KS.value << 5)));
+      mfma_vb<A_Q + 4 * KS.value, KS.value == 0>(Sa[0], f);
+      mfma_vb<A_Q + 4 * (8 + KS.value), KS.value == 0>(Sa[1], f);
+    });
+    sfor<PFK>([&](auto P) { kf[P.value % RK] = *(const bf16x8*)(sK0 + 8192 + (koff0 ^ (P.value << 5))); });
+  }
+
+#if defined(QFX_A64_TIMING)
+  uint64_t tph[6] = {0, 0, 0, 0, 0, 0}, tmark = __builtin_readcyclecounter();
+#endif
+  for (int jt = 0; jt < ntiles; ++jt) {
+    A64_T(5);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    A64_T(0);
+    if (!live) {
+      stage(jt + 3, b_dma);
+      const int t_ = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = b_dma; b_dma = t_;
+      continue;
+    }
+    const char* sKc = smem + b_cur * 2 * TB;        // tile jt
+    const char* sVc = sKc + TB;
+    const char* sKn = smem + b_nxt * 2 * TB;        // tile jt + 1
+    const int j0 = jt * 64;
+    const bool need_mask = (j0 + 64 > S) || (maskb != nullptr);
+    const float cs = need_mask ? 1.0f : c2;
+
+    // one sub-tile iteration: KB = which 32-key half of tile jt is "current"; HASNEXT = a sub-tile follows (QK^T MFMAs exist)
+    auto subtile = [&](auto KBc, auto HASNEXT, f32x16 (&Sc)[2], f32x16 (&Sn)[2]) {
+      constexpr int kb = KBc.value;
+      constexpr bool has_next = HASNEXT.value;
+      const char* sKx = kb == 0 ? sKc + 8192 : sKn;           // K rows of sub-tile i + 1: (tile jt, half 1) or (tile jt + 1, half 0)
+      const char* sKy = kb == 0 ? sKn : sKn + 8192;           // ... of sub-tile i + 2: its first fragments are requested at the end of Y
+      auto kreq = [&](auto N) { if constexpr (N.value < 8 && has_next) kf[N.value % RK] = *(const bf16x8*)(sKx + (koff0 ^ (N.value << 5))); };
+      auto kreq_next = [&](auto N) { kf[N.value % RK] = *(const bf16x8*)(sKy + (koff0 ^ (N.value << 5))); };
+      auto vreq = [&](auto N) {      // V^T fragment n = 4 u + db of the current sub-tile
+        constexpr int n = N.value;
+        if constexpr (n < 8) {
+          constexpr int t = 2 * kb + (n >> 2), db = n & 3;
+          const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(sVc + (toffa ^ (db << 6)) + t * 4096));
+          const bf16x4v hv = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((QFX_AS3 bf16x4v*)(sVc + (toffb ^ (db << 6)) + t * 4096));
+          const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hv);
+          bf16x8 r;
+          r[0] = l4[0]; r[1] = l4[1]; r[2] = l4[2]; r[3] = l4[3]; r[4] = h4[0]; r[5] = h4[1]; r[6] = h4[2]; r[7] = h4[3];
+          vf[n % RV] = r;
+        }
+      };
+      // ---- softmax pieces of the current sub-tile (lane (lj, hi): value r = key 8 (r / 4) + 4 hi + r % 4 of the 32-key half)
+      auto mask_cur = [&](int qb) {
+        f32x16& sv = Sc[qb];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int key0 = j0 + 32 * kb + 8 * c + 4 * hi;
+          f32x4 mk4 = {0.f, 0.f, 0.f, 0.f};
+          if (maskb != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk4[r] = maskb[(key0 + r) < S ? (key0 + r) : S - 1] * LOG2E;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[4 * c + r] = (key0 + r) < S ? sv[4 * c + r] * c2 + mk4[r] : -INFINITY;
+        }
+      };
+      auto max_a = [&](auto QB) {
+        constexpr int qb = QB.value;
+        const f32x16& sv = Sc[qb];
+        float c0, c1, c2_, c3;
+        asm volatile("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %7, %8, %9\n\tv_max3_f32 %2, %10, %11, %12\n\tv_max3_f32 %3, %13, %14, %15"
+                     : "=&v"(c0), "=&v"(c1), "=&v"(c2_), "=&v"(c3)
+                     : "v"(sv[0]), "v"(sv[1]), "v"(sv[2]), "v"(sv[3]), "v"(sv[4]), "v"(sv[5]), "v"(sv[6]), "v"(sv[7]), "v"(sv[8]), "v"(sv[9]), "v"(sv[10]), "v"(sv[11]));
+        mt[qb][0] = c0; mt[qb][1] = c1; mt[qb][2] = c2_; mt[qb][3] = c3;
+      };
+      auto max_b = [&](auto QB) {
+        constexpr int qb = QB.value;
+        const f32x16& sv = Sc[qb];
+        float c0 = mt[qb][0], c1 = mt[qb][1], c2_ = mt[qb][2];
+        const float c3 = mt[qb][3];
+        asm volatile("v_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max_f32 %2, %2, %3\n\tv_max3_f32 %0, %0, %1, %2"
+                     : "+v"(c0), "+v"(c1), "+v"(c2_) : "v"(c3), "v"(sv[12]), "v"(sv[13]), "v"(sv[14]), "v"(sv[15]));
+        mxs[qb] = c0;
+      };
+      auto vote = [&](auto QB) {
+        constexpr int qb = QB.value;
+        float mx = mxs[qb];
+        if (__builtin_expect(!__all(mx * cs - mrow[qb] <= ATTN_DEFER_MAX), 0)) {
+          const uint32_t u1 = __float_as_uint(mx);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+          mx = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+          const float mnew = fmaxf(mrow[qb], mx * cs);
+          const float alpha = fexp2_(mrow[qb] - ((mnew == -INFINITY) ? 0.f : mnew));
+          const bool had = mrow[qb] != -INFINITY;        // (lane-varying; the rescale below is skipped wave-wide only for the first sub-tile)
+          (void)had;
+          mrow[qb] = mnew;
+          lrow[qb] *= alpha;
+          if (!(jt == 0 && kb == 0)) {          // O^T(., qb) *= alpha: only QK^T MFMAs are in flight in X
+            sfor<64>([&](auto R) {
+              constexpr int reg = A_O + 16 * (2 * (R.value / 16) + qb) + R.value % 16;
+              agpr_write<reg>(__float_as_uint(agpr_read<reg>() * alpha));
+            });
+            asm volatile("s_nop 1");
+          }
+        }
+        negm[qb] = (mrow[qb] == -INFINITY) ? 0.f : -mrow[qb];
+        ls0[qb] = 0.f; ls1[qb] = 0.f; pe0[qb] = 0.f; pe1[qb] = 0.f;
+      };
+      auto pair = [&](auto QB, auto PI) {       // starts pair PI (fma, exp), finishes pair PI - 1 (row sums, packing)
+        constexpr int qb = QB.value, pi = PI.value, k = 2 * pi;
+        float t0, t1, l0 = ls0[qb], l1 = ls1[qb], e0 = pe0[qb], e1 = pe1[qb];
+        uint32_t pw;
+        asm volatile(
+            "v_fma_f32 %5, %7, %9, %10\n\tv_fma_f32 %6, %8, %9, %10\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %4\n\t"
+            "v_cvt_pk_bf16_f32 %0, %3, %4\n\t" A64_EXP " %3, %5\n\t" A64_EXP " %4, %6"
+            : "=&v"(pw), "+v"(l0), "+v"(l1), "+v"(e0), "+v"(e1), "=&v"(t0), "=&v"(t1)
+            : "v"(Sc[qb][k]), "v"(Sc[qb][k + 1]), "v"(cs), "v"(negm[qb]));
+        ls0[qb] = l0; ls1[qb] = l1; pe0[qb] = e0; pe1[qb] = e1;
+        if constexpr (pi > 0) Pw[qb][(pi - 1) >> 2][(pi - 1) & 3] = pw;
+      };
+      auto fin = [&](auto QB) {                 // finishes pair 7
+        constexpr int qb = QB.value;
+        float l0 = ls0[qb], l1 = ls1[qb];
+        const float e0 = pe0[qb], e1 = pe1[qb];
+        uint32_t pw;
+        asm volatile("v_add_f32 %1, %1, %3\n\tv_add_f32 %2, %2, %4\n\tv_cvt_pk_bf16_f32 %0, %3, %4" : "=&v"(pw), "+v"(l0), "+v"(l1) : "v"(e0), "v"(e1));
+        Pw[qb][1][3] = pw;
+        lrow[qb] += l0 + l1;
+      };
+      using Q0 = std::integral_constant<int, 0>;
+      using Q1 = std::integral_constant<int, 1>;
+      // fillers of gap g (after the MFMA of gap g): X = 0..15, Y = 16..31
+      auto filler = [&](auto G) {
+        constexpr int g = G.value;
+        if constexpr (g == 0) { if (need_mask) { mask_cur(0); mask_cur(1); } max_a(Q0{}); }
+        else if constexpr (g == 1) max_b(Q0{});
+        else if constexpr (g == 2) max_a(Q1{});
+        else if constexpr (g == 3) max_b(Q1{});
+        else if constexpr (g == 4) vote(Q0{});
+        else if constexpr (g == 5) vote(Q1{});
+        else if constexpr (g >= 6 && g <= 21) {
+          constexpr int k = g - 6;                                    // pairs (0,0) (1,0) (0,1) (1,1) ... (1,7)
+          if constexpr ((k & 1) == 0) pair(Q0{}, std::integral_constant<int, k / 2>{});
+          else pair(Q1{}, std::integral_constant<int, k / 2>{});
+        }
+        else if constexpr (g == 22) fin(Q0{});
+        else if constexpr (g == 23) fin(Q1{});
+        else if constexpr (g >= 24 && g <= 27) stage_piece(jt + 3, b_dma, 4 * kb + (g - 24));
+        else if constexpr (g >= 29 && g < 29 + PFK) kreq_next(std::integral_constant<int, g - 29>{});      // across the sub-tile (and tile) seam
+      };
+      // ---- X: QK^T of the next sub-tile (K fragment ks -> both query blocks), fragments requested PFK ahead
+      sfor<8>([&](auto KS) {
+        constexpr int ks = KS.value;
+        kreq(std::integral_constant<int, ks + PFK>{});
+        if constexpr (has_next) mfma_vb<A_Q + 4 * ks, ks == 0>(Sn[0], kf[ks % RK]);
+        filler(std::integral_constant<int, 2 * ks>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (has_next) mfma_vb<A_Q + 4 * (8 + ks), ks == 0>(Sn[1], kf[ks % RK]);
+        if constexpr (ks >= 5) vreq(std::integral_constant<int, ks - 5>{});      // the first V^T fragments of Y, three gaps ahead
+        filler(std::integral_constant<int, 2 * ks + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      A64_T(1 + 2 * kb);
+      // ---- Y: PV of the current sub-tile (V^T fragment (u, db) -> both query blocks)
+      sfor<8>([&](auto N) {
+        constexpr int n = N.value, u = n >> 2, db = n & 3;
+        vreq(std::integral_constant<int, n + PFV>{});
+        mfma_pv<A_O + 16 * (2 * db + 0)>(vf[n % RV], Pw[0][u]);
+        filler(std::integral_constant<int, 16 + 2 * n>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pv<A_O + 16 * (2 * db + 1)>(vf[n % RV], Pw[1][u]);
+        filler(std::integral_constant<int, 17 + 2 * n>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      A64_T(2 + 2 * kb);
+    };
+    subtile(std::integral_constant<int, 0>{}, std::true_type{}, Sa, Sb);
+    if (jt + 1 < ntiles) subtile(std::integral_constant<int, 1>{}, std::true_type{}, Sb, Sa);
+    else subtile(std::integral_constant<int, 1>{}, std::false_type{}, Sb, Sa);
+    { const int t_ = b_cur; b_cur = b_nxt; b_nxt = b_nn; b_nn = b_dma; b_dma = t_; }
+  }
+#if defined(QFX_A64_TIMING)
+  if (lane == 0 && blockIdx.x < 16) {
+    float* dbg = a.lse2 + ((int64_t)a.B * a.H) * a.S_pad + (blockIdx.x * 4 + w) * 8;
+    for (int i = 0; i < 6; ++i) dbg[i] = (float)tph[i];
+    dbg[6] = (float)ntiles;
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (!live) return;
+
+  // ---- epilogue: O = O^T / l -> bf16 -> staging slab [64 rows][272 B] of this wave -> 16-row fragments of the qfx_attn.hip layout
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last PV MFMAs have written the accumulators
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the K requests for the tile past the last one
+  char* stg = smem + w * (64 * STG_LD);
+  float lse_out[2];
+  sfor<2>([&](auto QB) {
+    constexpr int qb = QB.value;
+    float l = lrow[qb];
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    lse_out[qb] = mrow[qb] + log2f(l);
+    sfor<4>([&](auto DB) {
+      sfor<4>([&](auto C) {
+        constexpr int reg = A_O + 16 * (2 * DB.value + qb) + 4 * C.value;
+        const float o0 = agpr_read<reg>() * inv, o1 = agpr_read<reg + 1>() * inv, o2 = agpr_read<reg + 2>() * inv, o3 = agpr_read<reg + 3>() * inv;
+        const u32x2 u = {pack2bf(o0, o1), pack2bf(o2, o3)};
+        *(u32x2*)(stg + (32 * qb + lj) * STG_LD + (32 * DB.value + 8 * C.value + 4 * hi) * 2) = u;
+      });
+    });
+    const int q = q0 + 32 * qb + lj;
+    if (q < S && hi == 0) a.lse2[((int64_t)b * a.H + h) * a.S_pad + q] = lse_out[qb];
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab is private to the wave: no block barrier
+  const int g = lane >> 4, li = lane & 15;
+  const bool wide = rows_16b(a.O, a.ldo);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    if (q0 + 16 * f >= S) break;                           // wave-uniform
+    u32x2 u[DH / 16];
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d) u[d] = *(const u32x2*)(stg + (16 * f + li) * STG_LD + (16 * d + 4 * g) * 2);
+    const int q = q0 + 16 * f + li;
+    const int qc = q < S ? q : S - 1;
+    store_frag<DH>(a.O + ((int64_t)b * S + qc) * a.ldo + h * DH, u, g, q < S, wide);
+    head_lora_frag<DH>(a.hl[0], h, a.T, q0 + 16 * f, (int64_t)b * S + qc, q < S, u, g, li);
+  }
+}
+
+// =============================================================================================================================
 // dQ with 64-query waves (round 5).  Per 64-key tile and wave: S^T = K Q^T and dP^T = V dO^T (2 x 32 MFMAs), dS = P (dP - dsum) on the VALU,
 // dQ^T += K^T dS (32 MFMAs) -- 96 MFMAs against ~290 VALU instructions: 3 per MFMA where the forward has 4.5, so unlike the forward this
 // loop can be bound by the matrix pipe.  Accumulator half: a[0:127] = dQ^T (4 d-blocks x 2 query blocks), a[128:191] = Q fragments,
@@ -463,10 +799,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const qfx_attn_args 
 //   D  k-steps 2,3                  16 MFMAs | 8 K^T fragments, pairs 12..15 before k-step 3, the LDS-DMA pieces of tile jt + 3
 // Both tiles use ONE swizzle that serves ds_read_b128 (rows of a 16-lane group on one chunk) and the transpose read (4 rows x 4 chunks
 // per half wave): chunk' = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)).
-template <int BREG, bool FIRST> __device__ __forceinline__ void mfma_vb(f32x16& s, const bf16x8& af) {      // D (VGPR) (+)= A (VGPR) x B (AGPR)
-  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(af), "i"(BREG), "i"(BREG + 3));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(af), "i"(BREG), "i"(BREG + 3));
-}
 
 constexpr int A_DQ = 0, A_QF = 128, A_DO = 192;
 
@@ -495,8 +827,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const qfx_attn_ar
     const int row = 16 * w + 4 * ii + rr;
     int s = jt * 64 + row; s = s < S ? s : S - 1;
     const unsigned sc = (unsigned)((c ^ swz64(row)) * 8);
-    if (i < 4) glds16(Kb + (row_off(s, a.ldk) + sc), dK + (16 * w + 4 * ii) * 256);
-    else glds16(Vb + (row_off(s, a.ldv) + sc), dK + TB + (16 * w + 4 * ii) * 256);
+    if (i < 4) glds16a(Kb + (row_off(s, a.ldk) + sc), dK + (16 * w + 4 * ii) * 256);
+    else glds16a(Vb + (row_off(s, a.ldv) + sc), dK + TB + (16 * w + 4 * ii) * 256);
   };
   auto stage = [&](int jt, int buf) {
 #pragma unroll
@@ -784,6 +1116,12 @@ namespace qfxi {
 int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream) {
   dim3 grid(((a->S + 255) / 256) * a->H * a->B);
   hipLaunchKernelGGL(attn_fwd64_kernel, grid, dim3(256), 0, stream, *a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? QFX_OK : -(1000 + (int)e);
+}
+int launch_attn_fwd64p(const qfx_attn_args* a, hipStream_t stream) {
+  dim3 grid(((a->S + 255) / 256) * a->H * a->B);
+  hipLaunchKernelGGL(attn_fwd64p_kernel, grid, dim3(256), 0, stream, *a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? QFX_OK : -(1000 + (int)e);
 }

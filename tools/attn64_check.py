@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
 from qflux_amd import ops, _lib as L
 ap = argparse.ArgumentParser(); ap.add_argument("--S", default="2432,8576,333:2:2,200:2:3,64:1:1,1000:4:1"); ap.add_argument("--hl", type=int, default=16)
-ap.add_argument("--mask", type=int, default=0); ap.add_argument("--time", type=int, default=1)
+ap.add_argument("--mask", type=int, default=0); ap.add_argument("--time", type=int, default=1); ap.add_argument("--new", default="1", help="QFX_ATTN_FWD64 value of the new kernel: 1 = sub-tile pipeline, 1s = skewed query blocks")
 args = ap.parse_args()
 BF, DEV = torch.bfloat16, "cuda:0"
 out = {}
@@ -24,7 +24,7 @@ for spec in args.S.split(","):
         kmask = torch.zeros(Bn, S, device=DEV); kmask[:, S - S // 5:] = -1e4 if args.mask == 1 else float("-inf")
     res = {}
     for mode in ("0", "1"):
-        os.environ["QFX_ATTN_FWD64"] = mode
+        os.environ["QFX_ATTN_FWD64"] = mode if mode == "0" else args.new
         O = torch.zeros(Bn, S, D, dtype=BF, device=DEV); lse2 = torch.zeros(Bn, H, S_pad, device=DEV)
         part = torch.zeros(H, Bn * S, R, device=DEV)
         a = ops.attn_args(Bn, S, S_pad, H, dh, 1 / math.sqrt(dh), Q=qkv[:, :, :D], K=qkv[:, :, D:2 * D], V=qkv[:, :, 2 * D:], ldq=ld, ldk=ld, ldv=ld,

@@ -5,7 +5,7 @@ import ctypes as C, math, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "qwen-image-finetune_amd"))
 from qflux_amd import _lib as L
-var = C.CDLL(os.path.join(ROOT, "tools", "_ab", "libqfx_a64t.so"))
+var = C.CDLL(os.path.join(ROOT, "tools", "_ab", os.environ.get("A64T_LIB", "libqfx_a64t.so")))
 var.qfx_attn_fwd.argtypes = [C.POINTER(L.AttnArgs), C.c_void_p]; var.qfx_attn_fwd.restype = C.c_int
 var.qfx_attn_bwd_dq.argtypes = [C.POINTER(L.AttnArgs), C.c_void_p]; var.qfx_attn_bwd_dq.restype = C.c_int
 os.environ["QFX_ATTN_FWD64"] = "1"; os.environ["QFX_ATTN_DQ64"] = "1"
