@@ -174,8 +174,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         oacc[d][1] = MFMA(vfr, pb[1][t], oacc[d][1]);
       }
   };
-  stage_rows_n<DH, NW>(smem, Kb, a.ldk, 0, S, w, lane);
-  stage_rows_n<DH, NW>(smem + TB, Vb, a.ldv, 0, S, w, lane);
+  stage_rows_n<DH, NW, true>(smem, Kb, a.ldk, 0, S, w, lane);
+  stage_rows_n<DH, NW, true>(smem + TB, Vb, a.ldv, 0, S, w, lane);
   __syncthreads();
 #if defined(QFX_ATTN_TIMING)
   uint64_t tq = 0, tp = 0, tb = 0;
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     const char* sV = sK + TB;
     if (jt + 1 < ntiles) {
       char* nK = smem + ((jt + 1) & 1) * 2 * TB;
-      stage_rows_n<DH, NW>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
-      stage_rows_n<DH, NW>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
+      stage_rows_n<DH, NW, true>(nK, Kb, a.ldk, (jt + 1) * 64, S, w, lane);
+      stage_rows_n<DH, NW, true>(nK + TB, Vb, a.ldv, (jt + 1) * 64, S, w, lane);
     }
 #if defined(QFX_ATTN_TIMING)
     const uint64_t t0 = __builtin_readcyclecounter();
@@ -492,8 +492,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
       glds16(Qb + (row_off(sr, a.ldq) + (unsigned)sc8), dQ_ + (w * RPW + i * RPI) * (DH * 2));
       glds16(dOb + (row_off(sr, a.lddo) + (unsigned)sc8), dQ_ + TB + (w * RPW + i * RPI) * (DH * 2));
     }
-    if (w == 0) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(lseb + i0 + ln), (QFX_AS3 void*)(sStat + buf * 512), 4, 0, 0);
-    if (w == 1) __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)(dsb + i0 + ln), (QFX_AS3 void*)(sStat + buf * 512 + 256), 4, 0, 0);
+    if (w == 0) glds4(lseb + i0 + ln, sStat + buf * 512);
+    if (w == 1) glds4(dsb + i0 + ln, sStat + buf * 512 + 256);
   };
 #pragma unroll
   for (int i = 0; i < 4; ++i) stage_rows_n<DH, NW>(sV + i * TB, Vb, a.ldv, kb + 64 * i, S, w, lane);

@@ -109,16 +109,6 @@ template <class F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, st
 }
 template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// LDS-DMA piece issued from an asm statement (cdna_hip_programming.md 5.7: M0 is written in the statement that reads it).  hipcc does not
-// know these writes to LDS exist.  With the builtin it does, cannot tell which ring stage a ds_read touches, and puts an
-// s_waitcnt vmcnt(0) in front of fragment reads -- the whole asynchronous ring then waits for its youngest pieces inside the tile loop
-// (found in round 5: X phases of 1200 instead of ~800 cycles).  Completion is tracked by hand: vmcnt(8) / vmcnt(0) at the tile seams.
-__device__ __forceinline__ void glds16a(const bf16_t* g, char* lds) {
-  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(l) : "memory");
-}
-
 // chunk' = chunk ^ swz64(row): one 16-byte-chunk swizzle of a [rows][256 B] LDS tile that serves ds_read_b128 fragments (the rows of a
 // 16-lane read group on one chunk) AND the transpose read of the 32x32x16 layout (4 rows x 4 chunks per half wave)
 __device__ __forceinline__ int swz64(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }

@@ -10,8 +10,37 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;   // operand type of the transpose-read builtin
 
-__device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
+// One LDS-DMA piece (1 KiB per wave instruction).  Issued from an ASM statement (cdna_hip_programming.md 5.7: M0 is written in the statement
+// that reads it): hipcc does not know these writes to LDS exist.  With the builtin it does, cannot tell which ring stage a ds_read
+// touches, and guards fragment reads with s_waitcnt vmcnt(...) / turns its counted lgkmcnt waits into lgkmcnt(0) -- the asynchronous
+// tile ring then waits for its youngest pieces inside the tile loop (found in round 5 on the 64-query kernels).  Every kernel tracks
+// completion by hand: s_waitcnt vmcnt(N) + barrier at the tile seams.  -DQFX_ATTN_BUILTIN_DMA = the builtin of rounds 1-4 (A/B lever).
+__device__ __forceinline__ void glds16a(const bf16_t* g, char* lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+}
+__device__ __forceinline__ void glds4a(const float* g, char* lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+}
+__device__ __forceinline__ void glds16b(const bf16_t* g, char* lds) {   // the builtin: hipcc counts it (and guards every LDS read with it)
   __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)g, (QFX_AS3 void*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
+#if defined(QFX_ATTN_BUILTIN_DMA)
+  glds16b(g, lds);
+#else
+  glds16a(g, lds);
+#endif
+}
+__device__ __forceinline__ void glds4(const float* g, char* lds) {
+#if defined(QFX_ATTN_BUILTIN_DMA)
+  __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)g, (QFX_AS3 void*)lds, 4, 0, 0);
+#else
+  glds4a(g, lds);
+#endif
 }
 
 template <int DH> __device__ __forceinline__ int swz_row(int row) {
@@ -60,7 +89,9 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 
 
 // 64 rows x DH tile staged by NW waves (rows s0..s0+63 clamped to S-1) -> LDS [64][DH], swizzled.
-template <int DH, int NW>
+// BUILTIN = true: the compiler-tracked form (the 32-query forward kernel, two waves per SIMD, measures 4% faster with it: its waits
+// sit where the tile has landed anyway and the asm form's M0 save/restore costs issue slots; profiles/r05_attn_lds_dma.json).
+template <int DH, int NW, bool BUILTIN = false>
 __device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int64_t ld, int s0, int S, int w, int lane) {
   constexpr int CPR = DH / 8, RPI = 64 / CPR, RPW = 64 / NW, NI = RPW / RPI;
   static_assert(NI >= 1, "too many waves for this tile");
@@ -70,7 +101,9 @@ __device__ __forceinline__ void stage_rows_n(char* lds, const bf16_t* base, int6
     const int row = w * RPW + i * RPI + rr;
     int s = s0 + row; s = s < S ? s : S - 1;
     const int sc = c ^ swz_row<DH>(row);
-    glds16(base + (row_off(s, ld) + (unsigned)(sc * 8)), lds + (w * RPW + i * RPI) * (DH * 2));
+    const bf16_t* g = base + (row_off(s, ld) + (unsigned)(sc * 8));
+    if constexpr (BUILTIN) glds16b(g, lds + (w * RPW + i * RPI) * (DH * 2));
+    else glds16(g, lds + (w * RPW + i * RPI) * (DH * 2));
   }
 }
 
