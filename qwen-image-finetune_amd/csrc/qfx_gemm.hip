@@ -243,6 +243,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 #ifndef QFX_GEMM_PF_DIST
 #define QFX_GEMM_PF_DIST 0      // K tiles an L2 prefetch runs ahead of the K loop (0 = off), see the compute waves
 #endif
+#ifndef QFX_GEMM_KSTAGGER
+#define QFX_GEMM_KSTAGGER 0     // K tiles between the starting points of neighbouring tiles' K loops (0 = every tile starts at k = 0), see the loader waves
+#endif
 constexpr int NLD = QFX_GEMM_NLD;                 // loader waves
 constexpr int WS_THREADS = 512 + 64 * NLD;
 constexpr int STG_BYTES = 2048;                   // per compute wave: 16 rows x 64 bf16 staging for the epilogue
@@ -356,11 +359,25 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     int im0 = 0, in0 = 0, iM = 1, iN = 1;          // issue cursor's tile (rows are recomputed at the LoRA-segment switch)
     const bf16_t* iA2 = nullptr; const bf16_t* iB2 = nullptr;
     int ilda2 = 0, ildb2 = 0;
+    int ikt0 = 0;                                   // K tile the base segment starts at (QFX_GEMM_KSTAGGER), wraps around
     auto setp = [&](int bid) {
       int gi;
+#if QFX_GEMM_KSTAGGER > 0
+      int tin_, tgsz_;
+      tile_coord<BMT, TN>(ga, nwg, bid, gi, im0, in0, &tin_, &tgsz_);
+#else
       tile_coord<BMT, TN>(ga, nwg, bid, gi, im0, in0);
+#endif
       KArgs& p = ga.g[gi];
       int1 = p.K1 / BKT; intt = int1 + p.K2 / BKT;
+#if QFX_GEMM_KSTAGGER > 0
+      // The ~32 tiles an XCD runs at a time share A panels 4 ways and B panels 8 ways and walk K in lockstep: every operand line is a
+      // compulsory L2 miss that ALL its sharers wait for together.  Starting the base segment QFX_GEMM_KSTAGGER K tiles apart by tile
+      // parity (fp32 sums are re-ordered, nothing else changes) lets half the sharers find the line already resident.  Measured
+      // (profiles/r05_gemm_kstagger.json): 1-2 % SLOWER at 2 / 4 / 8 K tiles on every launch class -- lockstep sharers merge their
+      // misses, the stream is bandwidth- not latency-bound.  A/B lever only (default 0: this code is not compiled).
+      if constexpr (!FP8) { ikt0 = ((((tin_ % tgsz_) & 1) + 2 * ((tin_ / tgsz_) & 1)) * QFX_GEMM_KSTAGGER) % int1; }
+#endif
       iA2 = p.A2; iB2 = p.B2; ilda2 = p.lda2; ildb2 = p.ldb2; iM = p.M; iN = p.N;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -389,7 +406,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
       char* sA = smem + ist * STAGE_BYTES;
       char* sB = sA + BMT * BKT * 2;
+#if QFX_GEMM_KSTAGGER > 0
+      int kt_ = it < int1 ? it + ikt0 : it - int1;
+      if (it < int1 && kt_ >= int1) kt_ -= int1;
+      const int koff = kt_ * BKT;
+#else
       const int koff = (it < int1 ? it : it - int1) * BKT;
+#endif
 #if defined(QFX_GEMM_ABL_HALF_DMA)   // ablation (results are garbage): every other DMA piece -- is the K loop bound by the L2 -> LDS stream?
 #pragma unroll
       for (int i = 0; i < NA; i += 2) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
