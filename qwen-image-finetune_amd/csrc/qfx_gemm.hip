@@ -391,6 +391,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     };
     bool more = true;
+#if defined(QFX_GEMM_ABL_DMA_TO_VGPR)
+    u32x4 abl_sink = {0u, 0u, 0u, 0u};
+#endif
     auto issue = [&]() {
       if (it == int1) {  // first K tile of the LoRA segment (A2 rows are never remapped)
 #pragma unroll
@@ -418,6 +421,18 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       for (int i = 0; i < NA; i += 2) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
 #pragma unroll
       for (int i = 0; i < NB; i += 2) glds16(pb[i] + koff, sB + (lw + i * NLD) * 1024);
+#elif defined(QFX_GEMM_ABL_DMA_TO_VGPR)   // ablation (garbage results): the same requests as plain 16-byte loads into a register nobody reads -- is the
+                                         // stream bound on the L2 -> vector-memory path, or on the LDS side of the LDS-DMA?  (_B: only the weight half)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+#if defined(QFX_GEMM_ABL_DMA_TO_VGPR_B)
+        glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
+#else
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(abl_sink) : "v"(pa[i] + koff) : "memory");
+#endif
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(abl_sink) : "v"(pb[i] + koff) : "memory");
 #else
 #pragma unroll
       for (int i = 0; i < NA; ++i) glds16(pa[i] + koff, sA + (lw + i * NLD) * 1024);
@@ -455,6 +470,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         if (more) { issue(); ++ahead; }   // into the stage every compute wave left before this barrier
       }
     }
+#if defined(QFX_GEMM_ABL_DMA_TO_VGPR)
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(abl_sink) : "memory");
+#endif
     return;
   }
 

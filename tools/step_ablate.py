@@ -64,7 +64,17 @@ def main():
     print("calls per step:", counts)
     names = args.variants.split(",")
 
+    env_keys = set()
+
     def install(v):
+        # a variant of the form KEY=VAL[+KEY=VAL...] runs the full programs under those environment levers (read per launch by the library)
+        for k in env_keys:
+            os.environ.pop(k, None)
+        if "=" in v:
+            for kv in v.split("+"):
+                k, _, val = kv.partition("=")
+                os.environ[k] = val
+                env_keys.add(k)
         drop = VARIANTS.get(v, ())
         for k, prog in (("fwd", plan.fwd), ("bwd", plan.bwd)):
             calls = []
