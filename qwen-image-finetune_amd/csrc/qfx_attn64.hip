@@ -1049,6 +1049,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const qfx_attn_ar
   char* stg = smem + w * (64 * 512);
   const int g = lane >> 4, li = lane & 15;
   const bool wide = rows_16b(a.dQ, a.lddq);
+  // operands of the fused QK-norm + RoPE backward: those of fragment 0 are requested BEFORE the accumulators are staged, those of
+  // fragment f + 1 before fragment f is worked on (qfx_attn_common.h: nrb_load)
+  NrbOps<DH> nops[2];
+  auto nrb_req = [&](int f4, NrbOps<DH>& o) {
+    int qc = q0 + 16 * f4 + li; qc = qc < S ? qc : S - 1;
+    nrb_load<DH>(o, a.qk_saved + ((int64_t)b * S + qc) * a.ld_saved + h * DH + 4 * g,
+                 a.rope + (int64_t)b * a.rope_bstride + ((int64_t)qc * (DH / 2) + 2 * g) * 2, (qc < a.T ? a.wq_txt : a.wq_img) + 4 * g);
+  };
+  if (a.qk_saved) nrb_req(0, nops[0]);
   sfor<2>([&](auto QB) {
     sfor<4>([&](auto DB) {
       sfor<4>([&](auto C) {
@@ -1060,36 +1069,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const qfx_attn_ar
     });
   });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int f4 = 0; f4 < 4; ++f4) {
+  sfor<4>([&](auto F4) {
+    constexpr int f4 = F4.value;
     const int qf0 = q0 + 16 * f4;
-    if (qf0 >= S) break;                                // wave-uniform
-    f32x4 dq[DH / 16][2];
+    if (qf0 >= S) return;                               // wave-uniform
+    f32x4 dq[DH / 16];
     const int row = 16 * f4 + li;
 #pragma unroll
-    for (int d = 0; d < DH / 16; ++d) {
-      dq[d][0] = *(const f32x4*)(stg + row * 512 + (((4 * d + g) ^ (row & 7)) << 4));
-      dq[d][1] = dq[d][0];
-    }
+    for (int d = 0; d < DH / 16; ++d) dq[d] = *(const f32x4*)(stg + row * 512 + (((4 * d + g) ^ (row & 7)) << 4));
     const int q = qf0 + li;
     const int qc = q < S ? q : S - 1;
     bf16_t* op = a.dQ + ((int64_t)b * S + qc) * a.lddq + h * DH;
     u32x2 u[DH / 16];
     if (a.qk_saved) {
-      norm_rope_bwd_row<DH>(dq, 0, a.scale, a.qk_saved + ((int64_t)b * S + qc) * a.ld_saved + h * DH + 4 * g,
-                            a.rope + (int64_t)b * a.rope_bstride + ((int64_t)qc * (DH / 2) + 2 * g) * 2,
-                            (qc < a.T ? a.wq_txt : a.wq_img) + 4 * g, a.norm_eps, a.norm_flags, u);
+      if constexpr (f4 + 1 < 4) { if (qf0 + 16 < S) nrb_req(f4 + 1, nops[(f4 + 1) & 1]); }
+      norm_rope_bwd_ops<DH>(dq, a.scale, nops[f4 & 1], a.norm_eps, a.norm_flags, u);
       store_frag<DH>(op, u, g, q < S, wide);
       head_lora_frag<DH>(a.hl[1], h, a.T, qf0, (int64_t)b * S + qc, q < S, u, g, li);
     } else {
 #pragma unroll
       for (int d = 0; d < DH / 16; ++d) {
-        u[d][0] = pack2bf(dq[d][0][0] * a.scale, dq[d][0][1] * a.scale);
-        u[d][1] = pack2bf(dq[d][0][2] * a.scale, dq[d][0][3] * a.scale);
+        u[d][0] = pack2bf(dq[d][0] * a.scale, dq[d][1] * a.scale);
+        u[d][1] = pack2bf(dq[d][2] * a.scale, dq[d][3] * a.scale);
       }
       store_frag<DH>(op, u, g, q < S, wide);
     }
-  }
+  });
 #if defined(QFX_A64_TIMING)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && blockIdx.x < 16) {

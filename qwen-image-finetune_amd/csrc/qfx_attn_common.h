@@ -307,5 +307,66 @@ __device__ __forceinline__ void norm_rope_bwd_row(const f32x4 (&acc)[DH / 16][2]
   NRB_FENCE(4);
 }
 
+// The same backward with its operands taken in two steps (round 5, one-wave-per-SIMD kernels): left to itself hipcc requests the RoPE and
+// weight pieces of a row two at a time between the arithmetic that uses them -- eight dependent memory round trips per 16-row fragment,
+// ~6000 cycles each fragment with nothing else on the SIMD to cover them (dQ epilogue 31 k cycles against 7 k without the fusion,
+// tools/attn64_timing.py).  nrb_load() requests all 24 pieces of a fragment at once (a scheduling barrier keeps the requests together
+// and ahead of what follows); the caller requests fragment f + 1 before it works on fragment f.
+template <int DH> struct NrbOps { u32x2 x[DH / 16]; f32x4 cs[DH / 16]; u32x2 w[DH / 16]; };
+template <int DH>
+__device__ __forceinline__ void nrb_load(NrbOps<DH>& o, const bf16_t* xrow, const float* rrow, const bf16_t* wrow) {
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d) o.x[d] = *(const u32x2*)(xrow + d * 16);
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d) o.cs[d] = *(const f32x4*)(rrow + d * 16);
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d) o.w[d] = *(const u32x2*)(wrow + d * 16);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int DH>
+__device__ __forceinline__ void norm_rope_bwd_ops(const f32x4 (&acc)[DH / 16], float out_scale, const NrbOps<DH>& o, float eps, int flags,
+                                                  u32x2 (&out)[DH / 16]) {
+  constexpr int DF = DH / 16;
+  float xh[DF][4], dn[DF][4];
+  float ss = 0.f;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    xh[d][0] = __uint_as_float(o.x[d][0] << 16); xh[d][1] = __uint_as_float(o.x[d][0] & 0xffff0000u);
+    xh[d][2] = __uint_as_float(o.x[d][1] << 16); xh[d][3] = __uint_as_float(o.x[d][1] & 0xffff0000u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss += xh[d][r] * xh[d][r];
+  }
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float rstd = rsqrtf(ss / (float)DH + eps);
+  float dot = 0.f;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    const f32x4 cs = o.cs[d];
+    const float w0 = __uint_as_float(o.w[d][0] << 16), w1 = __uint_as_float(o.w[d][0] & 0xffff0000u);
+    const float w2 = __uint_as_float(o.w[d][1] << 16), w3 = __uint_as_float(o.w[d][1] & 0xffff0000u);
+    float e0 = rbf(acc[d][0] * out_scale), e1 = rbf(acc[d][1] * out_scale);
+    float e2 = rbf(acc[d][2] * out_scale), e3 = rbf(acc[d][3] * out_scale);
+    NRB_OPQ4(0, e0, e1, e2, e3);                                   // see norm_rope_bwd_row: these products stay scalar
+    const float d0 = rbf(e0 * cs[0] + e1 * cs[1]), d1 = rbf(-e0 * cs[1] + e1 * cs[0]);     // dy * conj(f)
+    const float d2 = rbf(e2 * cs[2] + e3 * cs[3]), d3 = rbf(-e2 * cs[3] + e3 * cs[2]);
+    dn[d][0] = (flags & 1) ? d0 * w0 : rbf(d0 * w0);
+    dn[d][1] = (flags & 1) ? d1 * w1 : rbf(d1 * w1);
+    dn[d][2] = (flags & 1) ? d2 * w2 : rbf(d2 * w2);
+    dn[d][3] = (flags & 1) ? d3 * w3 : rbf(d3 * w3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xh[d][r] *= rstd; dot += dn[d][r] * xh[d][r]; }
+  }
+  dot += __shfl_xor(dot, 16);
+  dot += __shfl_xor(dot, 32);
+  dot /= (float)DH;
+#pragma unroll
+  for (int d = 0; d < DF; ++d) {
+    out[d][0] = pack2bf_scalar((dn[d][0] - xh[d][0] * dot) * rstd, (dn[d][1] - xh[d][1] * dot) * rstd);
+    out[d][1] = pack2bf_scalar((dn[d][2] - xh[d][2] * dot) * rstd, (dn[d][3] - xh[d][3] * dot) * rstd);
+  }
+}
+
 }  // namespace
 

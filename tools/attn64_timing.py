@@ -34,9 +34,18 @@ for S in (2432, 8576):
     a.dO, a.lddo, a.dsum = dO.data_ptr(), D, dsum.data_ptr()
     a.dQ, a.dK, a.dV = dqkv.data_ptr(), dqkv.data_ptr() + 2 * D, dqkv.data_ptr() + 4 * D
     a.lddq = a.lddk = a.lddv = 3 * D
-    for _ in range(3): assert var.qfx_attn_bwd_dq(C.byref(a), st) == 0
-    torch.cuda.synchronize()
-    d = dsum[Bn * H * S_pad:].view(16, 4, 8).cpu()
-    live = d[:, :2]
-    print(f"S={S} dQ64: cycles per tile and wave: " + "  ".join(f"{n} {live[:, :, i].mean().item() / nt:.0f}" for i, n in enumerate(names[:5])) + f"   loop total {live[:, :, :5].sum(-1).mean().item() / nt:.0f}"
-          f"   per wave: prologue {live[:, :, 7].mean().item():.0f}  loop {live[:, :, :5].sum(-1).mean().item():.0f}  epilogue {live[:, :, 5].mean().item():.0f} cycles")
+    for fused in (0, 1):
+      if fused:      # the fused QK-norm + RoPE backward of the step's launches (epilogue cost)
+        sqk = torch.randn(Bn, S, 2 * D, device=DEV).to(BF)
+        ang = torch.rand(S, dh // 2, device=DEV) * 6.28
+        rope = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+        ws = [(1 + 0.1 * torch.randn(dh, device=DEV)).to(BF) for _ in range(4)]
+        a.qk_saved, a.ld_saved, a.rope, a.rope_bstride = sqk.data_ptr(), 2 * D, rope.data_ptr(), 0
+        a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = (t.data_ptr() for t in ws)
+        a.T, a.norm_flags, a.norm_eps = 384, 0, 1e-6
+      for _ in range(3): assert var.qfx_attn_bwd_dq(C.byref(a), st) == 0
+      torch.cuda.synchronize()
+      d = dsum[Bn * H * S_pad:].view(16, 4, 8).cpu()
+      live = d[:, :2]
+      print(f"S={S} dQ64 fused_qknorm={fused}: cycles per tile and wave: " + "  ".join(f"{n} {live[:, :, i].mean().item() / nt:.0f}" for i, n in enumerate(names[:5])) + f"   loop total {live[:, :, :5].sum(-1).mean().item() / nt:.0f}"
+            f"   per wave: prologue {live[:, :, 7].mean().item():.0f}  loop {live[:, :, :5].sum(-1).mean().item():.0f}  epilogue {live[:, :, 5].mean().item():.0f} cycles")
