@@ -18,6 +18,8 @@
 #include "qfx_common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 
@@ -293,6 +295,13 @@ struct GroupedArgs {
   int64_t ldcq[QFX_MAX_GROUPS];
   int cq_rows[QFX_MAX_GROUPS];
   int cq_only[QFX_MAX_GROUPS];
+  // same-XCD split-K (gemm256_kernel<..., SPLIT = true>): tile_start counts WORK ITEMS (two per tile: item 2t = the upper K half, the
+  // producer of an fp32 partial tile; item 2t + 1 = the lower half + LoRA segment + epilogue); ws = partial tiles
+  // [tile][compute wave][mi][ni][lane] x 4 floats, wflag = one word per (tile, compute wave), kh_bias = K tiles the consumer's half is
+  // shorter by (it also runs the LoRA segment, the exchange and the epilogue)
+  float* ws;
+  unsigned* wflag;
+  int kh_bias;
 };
 
 // The argument block is read straight from the kernarg segment (constant address space, scalar loads): indexing the
@@ -301,15 +310,21 @@ struct GroupedArgs {
 typedef const QFX_AS4 GroupedArgs KGroupedArgs;
 typedef const QFX_AS4 qfx_gemm_args KArgs;
 
-template <int BMT, int TN>
-__device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0, int* pin = nullptr, int* pgsz = nullptr) {
+template <int BMT, int TN, bool SPLIT = false>
+__device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, int& gi, int& m0, int& n0, int* pin = nullptr, int* pgsz = nullptr,
+                                           int* phalf = nullptr, int* pgt = nullptr) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   gi = 0;
 #pragma unroll
   for (int i = 1; i < QFX_MAX_GROUPS; ++i)
     if (i < ga.n && swz >= ga.tile_start[i]) gi = i;
-  const int lt = swz - ga.tile_start[gi];
+  int lt = swz - ga.tile_start[gi];
+  if constexpr (SPLIT) {          // two work items per tile, neighbours in the XCD's contiguous range (nwg % 16 == 0: never across XCDs)
+    if (phalf) *phalf = 1 - (lt & 1);
+    if (pgt) *pgt = swz >> 1;
+    lt >>= 1;
+  }
   // supertile order: consecutive tile ids walk 8 M-tiles before the next N-tile, so the ~32 tiles an XCD runs at
   // a time form an 8(M) x 4(N) patch that shares A rows and B rows in that XCD's L2.
   const int M = ga.g[gi].M, N = ga.g[gi].N;
@@ -326,10 +341,11 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
 
 typedef __attribute__((ext_vector_type(8))) int v8i32;
 
-template <int EPI, int BMT, int TN, bool FP8 = false>
+template <int EPI, int BMT, int TN, bool FP8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArgs ga_by_value) {
   static_assert(!(FP8 && !(BMT == 256 && TN == 128)), "the MX-FP8 instantiation uses the 256x128 tile (the streaming loops have no registers for 8-VGPR operands)");
   using TC = TileCfg<BMT, TN>;
+  static_assert(!SPLIT || (TC::WIDE && TC::BKT == 64 && !FP8), "split-K runs on the 256x256 bf16 tile");
   constexpr int STAGE_BYTES = TC::STAGE, NSTAGE = TC::NST, MI = TC::MI, NI = TC::NI, NG = TC::NG, NGRP = TC::NGRP;
   constexpr int BKT = TC::BKT;     // K depth of a ring stage (64; 32 on the wide tile)
   static_assert(!(FP8 && BKT != 64), "the MX-FP8 operands need 64-element (128-byte) stage rows");
@@ -359,17 +375,23 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     int im0 = 0, in0 = 0, iM = 1, iN = 1;          // issue cursor's tile (rows are recomputed at the LoRA-segment switch)
     const bf16_t* iA2 = nullptr; const bf16_t* iB2 = nullptr;
     int ilda2 = 0, ildb2 = 0;
-    int ikt0 = 0;                                   // K tile the base segment starts at (QFX_GEMM_KSTAGGER), wraps around
+    int ikt0 = 0;                                   // K tile the base segment starts at (split-K: the work item's half; QFX_GEMM_KSTAGGER: wraps around)
     auto setp = [&](int bid) {
       int gi;
+      int ihalf = 0;
 #if QFX_GEMM_KSTAGGER > 0
       int tin_, tgsz_;
-      tile_coord<BMT, TN>(ga, nwg, bid, gi, im0, in0, &tin_, &tgsz_);
+      tile_coord<BMT, TN, SPLIT>(ga, nwg, bid, gi, im0, in0, &tin_, &tgsz_, &ihalf);
 #else
-      tile_coord<BMT, TN>(ga, nwg, bid, gi, im0, in0);
+      tile_coord<BMT, TN, SPLIT>(ga, nwg, bid, gi, im0, in0, nullptr, nullptr, &ihalf);
 #endif
       KArgs& p = ga.g[gi];
       int1 = p.K1 / BKT; intt = int1 + p.K2 / BKT;
+      if constexpr (SPLIT) {                        // consumer: K tiles [0, kh) + the LoRA segment; producer: [kh, K1 / BKT)
+        const int kh = int1 / 2 - ga.kh_bias;
+        if (ihalf) { ikt0 = kh; int1 -= kh; intt = int1; }
+        else { ikt0 = 0; int1 = kh; intt = kh + p.K2 / BKT; }
+      }
 #if QFX_GEMM_KSTAGGER > 0
       // The ~32 tiles an XCD runs at a time share A panels 4 ways and B panels 8 ways and walk K in lockstep: every operand line is a
       // compulsory L2 miss that ALL its sharers wait for together.  Starting the base segment QFX_GEMM_KSTAGGER K tiles apart by tile
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       if (it < int1 && kt_ >= int1) kt_ -= int1;
       const int koff = kt_ * BKT;
 #else
-      const int koff = (it < int1 ? it : it - int1) * BKT;
+      const int koff = (it < int1 ? it + (SPLIT ? ikt0 : 0) : it - int1) * BKT;
 #endif
 #if defined(QFX_GEMM_ABL_HALF_DMA)   // ablation (results are garbage): every other DMA piece -- is the K loop bound by the L2 -> LDS stream?
 #pragma unroll
@@ -452,9 +474,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     for (int k = 2; k < NSTAGE; ++k)                 // an NSTAGE ring holds NSTAGE - 1 stages ahead
       if (more) { issue(); ++ahead; }
     for (int wbid = blockIdx.x; wbid < nwg; wbid += gridDim.x) {
-      int gi, m0, n0;
-      tile_coord<BMT, TN>(ga, nwg, wbid, gi, m0, n0);
-      const int ntw = ga.g[gi].K1 / BKT + ga.g[gi].K2 / BKT;
+      int gi, m0, n0, whalf = 0;
+      tile_coord<BMT, TN, SPLIT>(ga, nwg, wbid, gi, m0, n0, nullptr, nullptr, &whalf);
+      int ntw = ga.g[gi].K1 / BKT + ga.g[gi].K2 / BKT;
+      if constexpr (SPLIT) {
+        const int n1 = ga.g[gi].K1 / BKT, kh = n1 / 2 - ga.kh_bias;
+        ntw = whalf ? n1 - kh : kh + ga.g[gi].K2 / BKT;
+      }
       for (int t = 0; t < ntw; ++t) {
         // the oldest K stage in flight must have landed; the ones issued after it (PPS pieces each) may still be in flight
 #if defined(QFX_GEMM_ABL_HALF_DMA)
@@ -486,8 +512,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   // load's destination written when the statement ends and would hand the register to something else while the data is in flight
   unsigned pf_sink = 0;
   for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
-    int gi, m0, n0, tin, tgsz;
-    tile_coord<BMT, TN>(ga, nwg, bid, gi, m0, n0, &tin, &tgsz);
+    int gi, m0, n0, tin, tgsz, half = 0, gtile = 0;
+    tile_coord<BMT, TN, SPLIT>(ga, nwg, bid, gi, m0, n0, &tin, &tgsz, &half, &gtile);
     KArgs& p = ga.g[gi];
     // Lane-derived values are re-derived per tile -- here for the K loop, once more for the epilogue -- from a lane id the optimiser
     // cannot see through (v_mbcnt in an asm volatile: neither hoisted nor spilled).  Kept in registers across the whole persistent
@@ -501,7 +527,12 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     const int swl = (li >> 1) & 7;
     const int offA0 = (wr * WROWS + li) * (BK * 2) + ((g ^ swl) << 4);
     const int offB0 = BMT * BK * 2 + (wc * WCOLS + li) * (BK * 2) + ((g ^ swl) << 4);
-    const int nt1 = p.K1 / BKT, nt2 = p.K2 / BKT, nt = nt1 + nt2;
+    int nt1 = p.K1 / BKT, nt2 = p.K2 / BKT;
+    if constexpr (SPLIT) {
+      const int kh = nt1 / 2 - ga.kh_bias;
+      if (half) { nt1 -= kh; nt2 = 0; } else nt1 = kh;
+    }
+    const int nt = nt1 + nt2;
     // 64-byte stage rows (32-deep stages of the wide tile): chunk g of row li sits at g ^ (-(li >> 2) & 3), fragments are 1 KiB apart
     const int sw32 = (0 - (li >> 2)) & 3;
     const int offA32 = (wr * WROWS + li) * 64 + ((g ^ sw32) << 4);
@@ -564,6 +595,45 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       }
     };
     const bool mid_round = nt2 > 0 && !p.seg2_plain;
+    // ---- same-XCD split-K hand-off (SPLIT): compute wave w of the producer item hands its fp32 accumulators to compute wave w of the
+    // consumer item through the XCD's L2.  Producer: plain stores, s_waitcnt vmcnt(0) (acknowledged by the L2), then the flag.  Consumer:
+    // polls the flag (sc0 sc1: past the L1), invalidates the L1 (the words may sit there from an earlier launch), reads the partial tile,
+    // adds, clears the flag for the next launch on this stream.  Both items of a tile run in the same round of one grid (<= 256 items,
+    // producer first), so the consumer never waits for a block that has not started; the poll gives up after ~2 s instead of hanging.
+    auto publish = [&]() {
+      float* dst = ga.ws + ((int64_t)gtile * 8 + w) * (MI * NI * 256) + l0 * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *(f32x4*)(dst + (mi * NI + ni) * 256) = acc[mi][ni];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (l0 == 0) {
+        const unsigned one = 1u;
+        asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(ga.wflag + gtile * 8 + w), "v"(one) : "memory");
+      }
+    };
+    auto fixup = [&]() {
+      unsigned* fl = ga.wflag + gtile * 8 + w;
+      for (int spin = 0; spin < (1 << 21); ++spin) {
+        unsigned v;
+        asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(fl) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) != 0u) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      asm volatile("buffer_inv sc1" ::: "memory");      // words of the workspace may sit in this CU's L1 from an earlier launch
+      const float* src = ga.ws + ((int64_t)gtile * 8 + w) * (MI * NI * 256) + l0 * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {       // two fragment rows (8 loads) at a time: all 32 at once would not fit beside the accumulators
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += *(const f32x4*)(src + (mi * NI + ni) * 256);
+        if (mi & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("" ::: "memory");
+      if (l0 == 0) {
+        const unsigned zero = 0u;
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(fl), "v"(zero) : "memory");
+      }
+    };
 #if defined(QFX_GEMM_ABL_NO_COMPUTE)   // ablation (garbage results): the compute waves keep the barrier protocol only -- how long does the operand stream alone take?
     const bool wave_dead = true;
 #else
@@ -731,33 +801,57 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
       }
     } else {
-      for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* st = smem + buf * STAGE_BYTES;
-        pf(t + QFX_GEMM_PF_DIST);
-        if (wave_dead) { buf ^= 1; continue; }   // see the narrow-tile loop
+      // SPLIT: the base segment and the LoRA segment run as two passes of this loop with the hand-off between them, so that its
+      // temporaries are not live inside the K loop (inside it they cost 450 bytes of scratch per lane)
+      auto kpass = [&](int t0, int t1) __attribute__((always_inline)) {
+        for (int t = t0; t < t1; ++t) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          const char* st = smem + buf * STAGE_BYTES;
+          pf(t + QFX_GEMM_PF_DIST);
+          if (wave_dead) { buf ^= 1; continue; }   // see the narrow-tile loop
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const char* pA = st + (offA0 ^ (kk << 6));
-          const char* pB = st + (offB0 ^ (kk << 6));
-          bf16x8 b[NI];
+          for (int kk = 0; kk < 2; ++kk) {
+            const char* pA = st + (offA0 ^ (kk << 6));
+            const char* pB = st + (offB0 ^ (kk << 6));
+            bf16x8 b[NI];
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8*)(pB + ni * (16 * BK * 2));
-          bf16x8 fa0 = *(const bf16x8*)(pA), fa1 = *(const bf16x8*)(pA + 16 * BK * 2), fa2;
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8*)(pB + ni * (16 * BK * 2));
+            bf16x8 fa0 = *(const bf16x8*)(pA), fa1 = *(const bf16x8*)(pA + 16 * BK * 2), fa2;
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) {
-            if (mi + 2 < MI) fa2 = *(const bf16x8*)(pA + (mi + 2) * (16 * BK * 2));
+            for (int mi = 0; mi < MI; ++mi) {
+              if (mi + 2 < MI) fa2 = *(const bf16x8*)(pA + (mi + 2) * (16 * BK * 2));
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], fa0, acc[mi][ni], 0, 0, 0);
-            fa0 = fa1; fa1 = fa2;
-            __builtin_amdgcn_sched_barrier(0);
+              for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], fa0, acc[mi][ni], 0, 0, 0);
+              fa0 = fa1; fa1 = fa2;
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
+          if constexpr (!SPLIT) { if (mid_round && t == nt1 - 1) round_base(); }
+          buf ^= 1;
         }
-        if (mid_round && t == nt1 - 1) round_base();
-        buf ^= 1;
+      };
+      if constexpr (SPLIT) {
+        kpass(0, nt1);
+        if (half == 0) {
+#if !defined(QFX_SPLIT_ABL_NOFIX)                 // ablation (garbage results): no hand-off on the consumer side
+          if (!wave_dead) fixup();                 // the whole base sum, before it is rounded
+#endif
+          if (mid_round && !wave_dead) round_base();
+          kpass(nt1, nt);
+        }
+      } else {
+        kpass(0, nt);
+      }
+    }
+    if constexpr (SPLIT) {
+      if (half) {                    // producer item: the partial tile leaves through the L2, no epilogue
+#if !defined(QFX_SPLIT_ABL_NOPUB)                 // ablation: the producer keeps its partial tile to itself
+        if (!wave_dead) publish();
+#endif
+        continue;
       }
     }
 
@@ -959,11 +1053,23 @@ GeoTable g_geo_tab = {{
 }};
 std::mutex g_geo_mu;
 std::once_flag g_geo_once;
+// split-K policy (read once from the environment in geo_init): QFX_GEMM_SPLITK = 0 / 1, QFX_GEMM_SPLITK_MINK = smallest base K taken,
+// QFX_GEMM_SPLITK_BIAS = K tiles the consumer's half is shorter by
+bool g_split_on = false;
+int g_split_min_k = 9216;
+int g_split_bias = 3;
 
 // `tiles`: "legacy" | "all" | comma list of exact BMTxTN names; `eff`: three comma-separated factors.  All-or-nothing: a value
 // that does not parse leaves the table untouched and returns QFX_EINVAL.  Caller holds g_geo_mu.
 int geo_set_locked(const char* tiles, const char* eff) {
   GeoTable t = g_geo_tab;
+  if (tiles && !strncmp(tiles, "splitk", 6)) {      // "splitk=0|1", "splitk_mink=<K>", "splitk_bias=<K tiles>": the split-K policy (A/B lever, tests)
+    int v = 0;
+    if (sscanf(tiles, "splitk=%d", &v) == 1 && (v == 0 || v == 1)) { g_split_on = v != 0; return QFX_OK; }
+    if (sscanf(tiles, "splitk_mink=%d", &v) == 1 && v >= 2048) { g_split_min_k = v; return QFX_OK; }
+    if (sscanf(tiles, "splitk_bias=%d", &v) == 1 && v >= 0 && v <= 16) { g_split_bias = v; return QFX_OK; }
+    return QFX_EINVAL;
+  }
   if (tiles && *tiles) {
     const std::string v(tiles);
     if (v == "legacy") { for (int i = 0; i < NGEO; ++i) t.g[i].on = i < 2; }
@@ -1007,6 +1113,9 @@ void geo_init() {
       fprintf(stderr, "libqfx: QFX_GEMM_TILES=\"%s\" not understood (legacy | all | comma list of 256x128,256x256,160x192): ignored\n", tiles);
     if (geo_set_locked(nullptr, eff) != QFX_OK)
       fprintf(stderr, "libqfx: QFX_GEMM_EFF=\"%s\" not understood (three factors in (0.1, 10)): ignored\n", eff);
+    if (const char* e = getenv("QFX_GEMM_SPLITK")) g_split_on = e[0] != '0';
+    if (const char* e = getenv("QFX_GEMM_SPLITK_MINK")) { const int v = atoi(e); if (v >= 2048) g_split_min_k = v; }
+    if (const char* e = getenv("QFX_GEMM_SPLITK_BIAS")) { const int v = atoi(e); if (v >= 0 && v <= 16) g_split_bias = v; }
   });
 }
 
@@ -1014,6 +1123,31 @@ GeoTable geo_snapshot() {
   geo_init();
   std::lock_guard<std::mutex> lk(g_geo_mu);
   return g_geo_tab;
+}
+
+// ---- same-XCD split-K workspace: one per stream (launches on a stream are ordered, so a workspace is never shared by two live
+// grids), grown on demand, kept for the life of the process
+struct SplitWs { float* ws = nullptr; unsigned* flag = nullptr; size_t tiles = 0; };
+std::mutex g_ws_mu;
+std::map<hipStream_t, SplitWs> g_ws;
+bool split_ws(hipStream_t s, size_t tiles, float** ws, unsigned** flag) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  SplitWs& w = g_ws[s];
+  if (w.tiles < tiles) {
+    // (an old, smaller workspace may still be read by a grid in flight on this stream: it is left allocated, not freed)
+    float* nw = nullptr; unsigned* nf = nullptr;
+    if (hipMalloc((void**)&nw, tiles * 256 * 256 * sizeof(float)) != hipSuccess) return false;
+    if (hipMalloc((void**)&nf, tiles * 8 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(nw); return false; }
+    if (hipMemsetAsync(nf, 0, tiles * 8 * sizeof(unsigned), s) != hipSuccess) { (void)hipFree(nw); (void)hipFree(nf); return false; }
+    w.ws = nw; w.flag = nf; w.tiles = tiles;
+  }
+  *ws = w.ws; *flag = w.flag;
+  return true;
+}
+
+template <int E>
+void launch_split(int grid, hipStream_t s, const GroupedArgs& ga) {
+  hipLaunchKernelGGL((gemm256_kernel<E, 256, 256, false, true>), dim3(grid), dim3(WS_THREADS), 0, s, ga);
 }
 
 template <int E, bool FP8>
@@ -1030,12 +1164,14 @@ void launch_geo(int gi, int grid, hipStream_t s, const GroupedArgs& ga) {
 }
 
 template <bool FP8>
-int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo, int epi, hipStream_t s) {
+int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo, int epi, hipStream_t s, bool split = false, float* ws = nullptr,
+                   unsigned* wflag = nullptr) {
   const int bmt = g_geo_tab.g[geo].bmt, tn = g_geo_tab.g[geo].tn;      // tile shapes are compile-time constants of the table: never tuned
+  const int per_tile = split ? 2 : 1;          // work items per tile
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
     ga.tile_start[i] = tiles;
-    tiles += ((probs[i]->M + bmt - 1) / bmt) * ((probs[i]->N + tn - 1) / tn);
+    tiles += per_tile * ((probs[i]->M + bmt - 1) / bmt) * ((probs[i]->N + tn - 1) / tn);
   }
   for (int i = n; i <= QFX_MAX_GROUPS; ++i) ga.tile_start[i] = tiles;
   ga.n = n;
@@ -1044,6 +1180,20 @@ int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo
   int grid = (((tiles + rounds - 1) / rounds) + 7) & ~7;
   if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
   if (grid > tiles) grid = tiles;
+  ga.ws = nullptr; ga.wflag = nullptr; ga.kh_bias = 0;
+  if constexpr (!FP8) {
+    if (split) {
+      ga.ws = ws; ga.wflag = wflag; ga.kh_bias = g_split_bias;
+      switch (epi) {                     // one round: every item has its own CU, the two items of a tile are neighbours in one XCD
+        case QFX_EPI_NONE: launch_split<QFX_EPI_NONE>(tiles, s, ga); break;
+        case QFX_EPI_GELU: launch_split<QFX_EPI_GELU>(tiles, s, ga); break;
+        case QFX_EPI_GATE_RES: launch_split<QFX_EPI_GATE_RES>(tiles, s, ga); break;
+        default: launch_split<QFX_EPI_DGELU>(tiles, s, ga); break;
+      }
+      QFX_CHECK_LAUNCH();
+      return QFX_OK;
+    }
+  }
   switch (epi) {
     case QFX_EPI_NONE: launch_geo<QFX_EPI_NONE, FP8>(geo, grid, s, ga); break;
     case QFX_EPI_GELU: launch_geo<QFX_EPI_GELU, FP8>(geo, grid, s, ga); break;
@@ -1092,6 +1242,23 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
     if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
   }
   if (best < 0) best = 0;
+  // Same-XCD 2-way split-K on 256x256 tiles: the narrow launches (N = 3072 at B = 1) are confined to the 160x192 tile because 120
+  // tiles of 256x256 fill under half the chip; split along K they are 240 work items -- one round -- and move a third fewer operand
+  // bytes per flop (profiles/r05_gemm_splitk.json).  Taken when every problem has whole 256-column tiles and a base K of >= 9216, the
+  // items fill one round in pairs that never straddle an XCD (items % 16 == 0), and the round is at least 85 % full.
+  if (g_split_on && n256) {
+    long t256 = 0;
+    bool deep = true;
+    for (int i = 0; i < n; ++i) {
+      t256 += (long)((groups[i].M + 255) / 256) * (groups[i].N / 256);
+      deep = deep && groups[i].K1 >= g_split_min_k;
+    }
+    const long items = 2 * t256;
+    float* ws = nullptr;
+    unsigned* wflag = nullptr;
+    if (deep && items <= QFX_NUM_CU && items % 16 == 0 && items * 100 >= QFX_NUM_CU * 85 && split_ws((hipStream_t)stream, (size_t)t256, &ws, &wflag))
+      return launch_grouped<false>(ga, probs, n, 1, groups[0].epi, (hipStream_t)stream, true, ws, wflag);
+  }
   return launch_grouped<false>(ga, probs, n, best, groups[0].epi, (hipStream_t)stream);
 }
 

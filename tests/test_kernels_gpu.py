@@ -207,6 +207,72 @@ def test_gemm_wide_tile_all_epilogues():
         check(f"gemm_wide_grouped_{i}", it[2], rf, 1e-2)
 
 
+def test_gemm_same_xcd_split_k_lever():
+    """Round 5 lever (default off, profiles/r05_gemm_splitk.json): 256x256 tiles as two work items per tile on CUs of one XCD, fp32 partial
+    tiles handed over through the L2.  Forced on for the step's deep-K launch shape (image + text group, 240 work items): the LoRA
+    K extension with the bf16 mid-rounding after BOTH halves, gate + residual, ragged M; against the fp32 reference, against the
+    unsplit launch, and twice for bit-reproducibility.  A shape outside the policy (K < 9216) must not change."""
+    import ctypes as C
+    from qflux_amd import _lib as L
+    ops = _ops()
+    lib = L.lib
+    N, K, K2 = 3072, 9216, 192
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch(epi):
+        gs, keep, outs, refs = [], [], [], []
+        for i, Mi in enumerate((2040, 384)):
+            ai, bi, bs = randn(Mi, K, seed=140 + i).to(BF), randn(N, K, seed=150 + i, scale=0.05).to(BF), randn(N, seed=160 + i).to(BF)
+            ad, bd, sd = ai.to(DEV), bi.to(DEV), bs.to(DEV)
+            o = torch.zeros(Mi, N, dtype=BF, device=DEV)
+            g = L.GemmArgs()
+            g.A1, g.B1, g.lda1, g.ldb1, g.K1 = ad.data_ptr(), bd.data_ptr(), K, K, K
+            g.M, g.N, g.bias, g.C, g.ldc, g.rows_per_batch, g.epi = Mi, N, sd.data_ptr(), o.data_ptr(), N, Mi, epi
+            base = rb(ai.float() @ bi.float().t() + bs.float())
+            if epi == 0:        # + LoRA K extension: the base sum of BOTH K halves is rounded to bf16 before the extension is added
+                a2, b2 = randn(Mi, K2, seed=170 + i).to(BF), randn(N, K2, seed=180 + i, scale=0.05).to(BF)
+                a2d, b2d = a2.to(DEV), b2.to(DEV)
+                g.A2, g.B2, g.lda2, g.ldb2, g.K2 = a2d.data_ptr(), b2d.data_ptr(), K2, K2, K2
+                keep += [a2d, b2d]
+                refs.append(rb(base + a2.float() @ b2.float().t()))
+            else:               # gate * y + residual
+                gate, aux = randn(1, N, seed=190).to(BF), randn(Mi, N, seed=191 + i).to(BF)
+                gd, xd = gate.to(DEV), aux.to(DEV)
+                g.gate, g.gate_bstride, g.aux, g.ldaux = gd.data_ptr(), N, xd.data_ptr(), N
+                keep += [gd, xd]
+                refs.append(rb(aux.float() + rb(gate.float() * base)))
+            keep += [ad, bd, sd]; gs.append(g); outs.append(o)
+        arr = (L.GemmArgs * len(gs))(*gs)
+        assert lib.qfx_gemm_grouped(arr, len(gs), st) == 0
+        torch.cuda.synchronize()
+        first = [o.clone() for o in outs]
+        assert lib.qfx_gemm_grouped(arr, len(gs), st) == 0
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(first, outs)), "launch not bit-reproducible"
+        return first, refs
+
+    try:
+        got = {}
+        for mode in (b"splitk=0", b"splitk=1"):
+            assert lib.qfx_gemm_tune(mode, None) == 0
+            got[mode] = []
+            for epi in (0, 2):
+                outs, refs = launch(epi)
+                for k, (o, rf) in enumerate(zip(outs, refs)):
+                    check(f"gemm_{mode.decode()}_epi{epi}_{k}", o, rf, 1e-2)
+                got[mode] += outs
+        for x, y in zip(got[b"splitk=0"], got[b"splitk=1"]):
+            assert ((x.float() - y.float()).abs().max() / x.float().abs().max()).item() < 1e-2
+        a, b = randn(2432, 3072, seed=7).to(BF).to(DEV), randn(3072, 3072, seed=8, scale=0.05).to(BF).to(DEV)
+        assert lib.qfx_gemm_tune(b"splitk=0", None) == 0
+        r0 = ops.gemm(a, b)
+        assert lib.qfx_gemm_tune(b"splitk=1", None) == 0
+        assert torch.equal(r0, ops.gemm(a, b))
+    finally:
+        assert lib.qfx_gemm_tune(b"splitk=0", None) == 0
+    assert lib.qfx_gemm_tune(b"splitk=2", None) == -1 and lib.qfx_gemm_tune(b"splitk_bias=99", None) == -1
+
+
 GEOMETRIES = ("256x128", "256x256", "160x192")
 
 
