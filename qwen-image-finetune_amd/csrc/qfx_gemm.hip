@@ -601,38 +601,39 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     // adds, clears the flag for the next launch on this stream.  Both items of a tile run in the same round of one grid (<= 256 items,
     // producer first), so the consumer never waits for a block that has not started; the poll gives up after ~2 s instead of hanging.
     auto publish = [&]() {
-      float* dst = ga.ws + ((int64_t)gtile * 8 + w) * (MI * NI * 256) + l0 * 4;
+      int lp;      // a lane id of its own: computed from l0 the addresses below are hoisted above the K passes and cost accumulator spills there
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lp));
+      float* dst = ga.ws + ((int64_t)gtile * 8 + w) * (MI * NI * 256) + lp * 4;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) *(f32x4*)(dst + (mi * NI + ni) * 256) = acc[mi][ni];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (l0 == 0) {
-        const unsigned one = 1u;
-        asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(ga.wflag + gtile * 8 + w), "v"(one) : "memory");
-      }
+      // every lane writes the same word (no divergent branch around an asm statement: the allocator spills around those)
+      const unsigned one = 1u;
+      asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(ga.wflag + gtile * 8 + w), "v"(one) : "memory");
     };
     auto fixup = [&]() {
       unsigned* fl = ga.wflag + gtile * 8 + w;
-      for (int spin = 0; spin < (1 << 21); ++spin) {
+      for (int spin = 0; spin < (1 << 21); ++spin) {      // scalar poll past the scalar cache: no vector registers in this loop
         unsigned v;
-        asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(fl) : "memory");
-        if (__builtin_amdgcn_readfirstlane(v) != 0u) break;
+        asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(fl) : "memory");
+        if (v != 0u) break;
         __builtin_amdgcn_s_sleep(8);
       }
       asm volatile("buffer_inv sc1" ::: "memory");      // words of the workspace may sit in this CU's L1 from an earlier launch
-      const float* src = ga.ws + ((int64_t)gtile * 8 + w) * (MI * NI * 256) + l0 * 4;
+      int lp;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lp));
+      const float* src = ga.ws + ((int64_t)gtile * 8 + w) * (MI * NI * 256) + lp * 4;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {       // two fragment rows (8 loads) at a time: all 32 at once would not fit beside the accumulators
+      for (int mi = 0; mi < MI; ++mi) {       // one fragment row (4 loads) at a time: more do not fit beside the accumulators
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += *(const f32x4*)(src + (mi * NI + ni) * 256);
-        if (mi & 1) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("" ::: "memory");
-      if (l0 == 0) {
-        const unsigned zero = 0u;
-        asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(fl), "v"(zero) : "memory");
-      }
+      const unsigned zero = 0u;
+      asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(fl), "v"(zero) : "memory");
     };
 #if defined(QFX_GEMM_ABL_NO_COMPUTE)   // ablation (garbage results): the compute waves keep the barrier protocol only -- how long does the operand stream alone take?
     const bool wave_dead = true;
