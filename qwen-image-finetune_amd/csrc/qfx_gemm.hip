@@ -1056,7 +1056,11 @@ std::mutex g_geo_mu;
 std::once_flag g_geo_once;
 // split-K policy (read once from the environment in geo_init): QFX_GEMM_SPLITK = 0 / 1, QFX_GEMM_SPLITK_MINK = smallest base K taken,
 // QFX_GEMM_SPLITK_BIAS = K tiles the consumer's half is shorter by
+#if defined(QFX_GEMM_SPLITK_DEFAULT_ON)      // A/B builds (tools/build_variants.py)
+bool g_split_on = true;
+#else
 bool g_split_on = false;
+#endif
 int g_split_min_k = 9216;
 int g_split_bias = 3;
 
