@@ -483,7 +483,13 @@ int qfx_debug_where(uint32_t* out, int32_t n_blocks, void* stream);
  * tiles: NULL / "" = keep, "all", "legacy" (the two 256-row tiles), or a comma list of names; eff: NULL = keep, or three
  * comma-separated per-flop efficiencies relative to 256x128 in the order above.  Process-wide; the defaults come from the
  * environment (QFX_GEMM_TILES / QFX_GEMM_EFF) at the first launch.  Results do not depend on the geometry (same K order per
- * output element); only speed does.  Returns QFX_EINVAL for an unparsable argument. ---- */
+ * output element); only speed does.  Returns QFX_EINVAL for an unparsable argument.
+ * Round 5: `tiles` also takes ONE policy token of the same-XCD split-K lever instead of a geometry list -- "splitk=0|1" (default 0),
+ * "splitk_mink=<smallest base K taken, >= 2048>", "splitk_bias=<0..16 K tiles>" (environment: QFX_GEMM_SPLITK, _MINK, _BIAS).  With the
+ * lever on, a launch whose problems all have N % 256 == 0 and K1 >= mink and whose 256x256 tiles make 218..256 work items in pairs
+ * runs as two work items per tile (fp32 partial tiles through a per-stream workspace the library allocates on first use; never while the
+ * stream is capturing a graph).  The fp32 summation order changes (results stay within the bf16 tolerance of the tests, run-to-run
+ * bit-identical); measured slower than the unsplit launch on MI355X (profiles/r05_gemm_splitk.json): an A/B lever, not a default. ---- */
 int qfx_gemm_tune(const char* tiles, const char* eff);
 
 /* ---- debug: lane mapping of ds_read_b64_tr_b16 (64 lanes x 4 bf16 in, same out) ---- */

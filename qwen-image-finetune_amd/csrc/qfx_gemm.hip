@@ -1136,6 +1136,8 @@ struct SplitWs { float* ws = nullptr; unsigned* flag = nullptr; size_t tiles = 0
 std::mutex g_ws_mu;
 std::map<hipStream_t, SplitWs> g_ws;
 bool split_ws(hipStream_t s, size_t tiles, float** ws, unsigned** flag) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;   // no allocation inside a graph capture: unsplit
   std::lock_guard<std::mutex> lk(g_ws_mu);
   SplitWs& w = g_ws[s];
   if (w.tiles < tiles) {
