@@ -228,6 +228,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NP <= 6 ? 3
   }
 }
 
+#if defined(QFX_LN_BWD_PIPE)
+// A/B build (profiles/r05_ln_pipeline.json): the same backward on a PERSISTENT grid (one 4-wave block per CU), every wave
+// walking its rows with a two-row software pipeline -- the three HBM streams of row i+1 are requested before the reductions and stores of
+// row i.  Same arithmetic, same row -> wave mapping within a 4-row block; the MX-FP8 side output is not supported here.
+template <int NP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void ln_mod_bwd_pipe_kernel(const LnBwdBatch bt, int nblk) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // the argument block is read from the kernarg segment (scalar loads): pointers into the by-value parameter would copy it to scratch
+  typedef const __attribute__((address_space(4))) qfx_ln_bwd_args KA;
+  typedef const __attribute__((address_space(4))) LnBwdBatch KB;
+  KB& kb = *(KB*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)bt;
+  struct Row { KA* q; int row; bool live; };
+  auto decode = [&](int blk) {
+    int row = blk * 4 + wv, pi = 0;
+#pragma unroll
+    for (int i = 0; i + 1 < QFX_MAX_LN_BATCH; ++i)
+      if (pi == i && i + 1 < kb.n && row >= kb.a[i].rows) { row -= kb.a[i].rows; pi = i + 1; }
+    KA* q = &kb.a[pi];
+    return Row{q, row, row < q->rows};
+  };
+  auto lo = [](unsigned u) { return __uint_as_float(u << 16); };
+  auto hi = [](unsigned u) { return __uint_as_float(u & 0xffff0000u); };
+  auto request = [&](const Row& r, u32x4 (&xr)[NP], u32x4 (&dyr)[NP], u32x4 (&drr)[NP]) {
+    if (!r.live) return;
+    const int64_t ro = (int64_t)r.row * r.q->D;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < r.q->D) {
+        xr[p] = *(const u32x4*)(r.q->x + ro + col);
+        dyr[p] = *(const u32x4*)(r.q->dy + ro + col);
+        if (r.q->dres) drr[p] = *(const u32x4*)(r.q->dres + ro + col);
+      }
+    }
+  };
+  auto finish = [&](const Row& r, const u32x4 (&xr)[NP], const u32x4 (&dyr)[NP], const u32x4 (&drr)[NP]) {
+    if (!r.live) return;
+    KA& q = *r.q;
+    const int D = q.D, b = r.row / q.rows_per_batch;
+    const int64_t ro = (int64_t)r.row * D;
+    if (q.row_mask != nullptr && q.row_mask[r.row] == 0.f) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int col = (p * 64 + lane) * 8;
+        if (col < D) { *(u32x4*)(q.dx + ro + col) = z; if (q.dyg) *(u32x4*)(q.dyg + ro + col) = z; }
+      }
+      return;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if ((p * 64 + lane) * 8 < D) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += lo(xr[p][i]) + hi(xr[p][i]);
+      }
+    const float mean = wave_sum(s) / (float)D;
+    float qq = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if ((p * 64 + lane) * 8 < D) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d0 = lo(xr[p][i]) - mean, d1 = hi(xr[p][i]) - mean; qq += d0 * d0 + d1 * d1; }
+      }
+    const float rstd = rsqrtf(wave_sum(qq) / (float)D + q.eps);
+    u32x4 gp[NP];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < D) {
+        const u32x4 sc = *(const u32x4*)(q.scale + (int64_t)b * q.mod_bstride + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float g0 = rbf(lo(dyr[p][i]) * rbf(1.0f + lo(sc[i])));
+          const float g1 = rbf(hi(dyr[p][i]) * rbf(1.0f + hi(sc[i])));
+          gp[p][i] = pack2bf(g0, g1);
+          c1 += g0 + g1;
+          c2 += g0 * ((lo(xr[p][i]) - mean) * rstd) + g1 * ((hi(xr[p][i]) - mean) * rstd);
+        }
+      }
+    }
+    c1 = wave_sum(c1) / (float)D;
+    c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int col = (p * 64 + lane) * 8;
+      if (col < D) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = (lo(xr[p][i]) - mean) * rstd, x1 = (hi(xr[p][i]) - mean) * rstd;
+          const float d0 = rbf((lo(gp[p][i]) - c1 - x0 * c2) * rstd), d1 = rbf((hi(gp[p][i]) - c1 - x1 * c2) * rstd);
+          o[2 * i] = q.dres ? rbf(lo(drr[p][i]) + d0) : d0;
+          o[2 * i + 1] = q.dres ? rbf(hi(drr[p][i]) + d1) : d1;
+        }
+        st8(q.dx + ro + col, o);
+        if (q.dyg) {
+          float gt[8], og[8];
+          ld8(q.gate + (int64_t)b * q.gate_bstride + col, gt);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) og[i] = gt[i] * o[i];
+          st8(q.dyg + ro + col, og);
+        }
+      }
+    }
+  };
+  int blk = blockIdx.x;
+  if (blk >= nblk) return;
+  u32x4 xa[NP], da[NP], ra[NP], xb[NP], db[NP], rb_[NP];
+  Row cur = decode(blk);
+  request(cur, xa, da, ra);
+  for (;;) {
+    const int nb = blk + gridDim.x;
+    const bool more = nb < nblk;
+    Row nxt = cur;
+    if (more) { nxt = decode(nb); request(nxt, xb, db, rb_); }
+    __builtin_amdgcn_sched_barrier(0);
+    finish(cur, xa, da, ra);
+    if (!more) break;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { xa[p] = xb[p]; da[p] = db[p]; ra[p] = rb_[p]; }
+    cur = nxt; blk = nb;
+  }
+}
+#endif
+
 // ---------------------------------------------------------------- gradients of the modulation vectors (shift, scale, gate)
 // grid = (row chunks of 32 per sample, B); block = 4 waves; a wave owns 8 consecutive rows (one row at a time in registers, as in
 // the LayerNorm kernels), accumulates its column sums in registers, the four waves combine in LDS and the block issues ONE fp32
@@ -1013,6 +1141,17 @@ extern "C" int qfx_ln_modulate_bwd_batch(const qfx_ln_bwd_args* list, int32_t n,
   bt.n = n;
   int dmax = 0;
   for (int i = 0; i < n; ++i) dmax = list[i].D > dmax ? list[i].D : dmax;
+#if defined(QFX_LN_BWD_PIPE)
+  bool plain = dmax <= 3072;
+  for (int i = 0; i < n; ++i) plain = plain && list[i].dygq == nullptr;
+  if (plain) {
+    const int nblk = rows / 4;
+    const int grid = nblk < QFX_LN_BWD_PIPE ? nblk : QFX_LN_BWD_PIPE;      // QFX_LN_BWD_PIPE = persistent blocks (256 = one per CU)
+    hipLaunchKernelGGL(ln_mod_bwd_pipe_kernel<6>, dim3(grid), dim3(256), 0, (hipStream_t)stream, bt, nblk);
+    QFX_CHECK_LAUNCH();
+    return QFX_OK;
+  }
+#endif
   if (dmax <= 3072) hipLaunchKernelGGL(ln_mod_bwd_kernel<6>, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
   else hipLaunchKernelGGL(ln_mod_bwd_kernel<MAXP>, dim3(rows / 4), dim3(256), 0, (hipStream_t)stream, bt);
   QFX_CHECK_LAUNCH();
