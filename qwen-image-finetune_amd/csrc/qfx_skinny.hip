@@ -334,7 +334,10 @@ __global__ __launch_bounds__(512) void ln_down_kernel(const LnDownBatch batch_by
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4v;
 constexpr int GX_ROWB = 288;  // padded LDS row stride (bytes) of the [32 tokens][128 cols] tile
 
-constexpr int GRAD_CH = 512;   // tokens per block: 4x fewer device-scope fp32 atomics per output element than 128 (the atomics
+#ifndef QFX_GRAD_CH
+#define QFX_GRAD_CH 512
+#endif
+constexpr int GRAD_CH = QFX_GRAD_CH;   // tokens per block: 4x fewer device-scope fp32 atomics per output element than 128 (the atomics
                                // of the M/CH partial sums, not the 15 MB stream, bounded the 128-token version)
 template <int NF>
 __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by_value) {
