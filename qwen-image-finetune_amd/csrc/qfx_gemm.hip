@@ -329,7 +329,10 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
   // a time form an 8(M) x 4(N) patch that shares A rows and B rows in that XCD's L2.
   const int M = ga.g[gi].M, N = ga.g[gi].N;
   const int tiles_m = (M + BMT - 1) / BMT, tiles_n = (N + TN - 1) / TN;
-  constexpr int GM = 8;
+#ifndef QFX_GEMM_GM
+#define QFX_GEMM_GM 8      // M-tiles a supertile walks before the next N-tile: the XCD patch is GM x (32 / GM) tiles (A/B build lever)
+#endif
+  constexpr int GM = QFX_GEMM_GM;
   const int per = GM * tiles_n, sg = lt / per, first = sg * GM;
   const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
   const int in = lt - sg * per;
