@@ -302,6 +302,7 @@ struct GroupedArgs {
   float* ws;
   unsigned* wflag;
   int kh_bias;
+  int gm;            // supertile height in M-tiles (tile_coord)
 };
 
 // The argument block is read straight from the kernarg segment (constant address space, scalar loads): indexing the
@@ -329,10 +330,14 @@ __device__ __forceinline__ void tile_coord(KGroupedArgs& ga, int nwg, int bid, i
   // a time form an 8(M) x 4(N) patch that shares A rows and B rows in that XCD's L2.
   const int M = ga.g[gi].M, N = ga.g[gi].N;
   const int tiles_m = (M + BMT - 1) / BMT, tiles_n = (N + TN - 1) / TN;
-#ifndef QFX_GEMM_GM
-#define QFX_GEMM_GM 8      // M-tiles a supertile walks before the next N-tile: the XCD patch is GM x (32 / GM) tiles (A/B build lever)
-#endif
+  // M-tiles a supertile walks before the next N-tile: the XCD patch is GM x (32 / GM) tiles.  8 x 4 moves the fewest operand rows per
+  // XCD; the six-problem q/k/v launch (13 + 3 M-tiles per stream, K = 3072) measures 3 % faster on 4 x 8 (profiles/r05_gemm_stream_path.json),
+  // every other class 0.3-1 % slower: chosen per launch (qfx_gemm_grouped), -DQFX_GEMM_GM forces one value (A/B builds).
+#if defined(QFX_GEMM_GM)
   constexpr int GM = QFX_GEMM_GM;
+#else
+  const int GM = ga.gm;
+#endif
   const int per = GM * tiles_n, sg = lt / per, first = sg * GM;
   const int gsz = (tiles_m - first) < GM ? (tiles_m - first) : GM;
   const int in = lt - sg * per;
@@ -1191,6 +1196,7 @@ int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo
   if (grid > QFX_NUM_CU) grid = QFX_NUM_CU;
   if (grid > tiles) grid = tiles;
   ga.ws = nullptr; ga.wflag = nullptr; ga.kh_bias = 0;
+  ga.gm = (n >= 6 && !split) ? 4 : 8;
   if constexpr (!FP8) {
     if (split) {
       ga.ws = ws; ga.wflag = wflag; ga.kh_bias = g_split_bias;
