@@ -216,8 +216,8 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
 
 
 def assert_step_bit_reproducible(plan, run_step, gflat, zero_grad, what=""):
-    """Two identical fused steps, each started from a ZEROED arena: every arena tensor must come out bit-identical (check-sums over
-    the raw bytes).  Only the flat LoRA gradient and the scalar loss are exempt from the bit test -- the weight-gradient launches add
+    """Two identical fused steps, each started from a ZEROED arena: every arena tensor must come out bit-identical (position-weighted
+    check-sums over all raw bytes).  Only the flat LoRA gradient and the scalar loss are exempt from the bit test -- the weight-gradient launches add
     with fp32 atomics (order-dependent in the last bit): 1e-5 / 1e-6.  `run_step()` -> loss tensor; `gflat` the flat gradient buffer."""
     tens, seen = [], set()
 
@@ -235,13 +235,29 @@ def assert_step_bit_reproducible(plan, run_step, gflat, zero_grad, what=""):
                 flat(f"{prefix}[{i}]", v)
     flat("A", plan.A)
 
+    def checksum(t):
+        """Position-weighted check-sum over EVERY raw byte (int64 words times odd position weights, wrapping; the size % 8 tail bytes
+        weighted separately): a permutation of words or a change in the trailing bytes changes it, unlike a plain sum."""
+        raw = (t if t.is_contiguous() else t.contiguous()).view(torch.uint8).view(-1)
+        n8 = raw.numel() // 8
+        acc = 0
+        CH = 1 << 24
+        words = raw[: n8 * 8].view(torch.int64)
+        for c0 in range(0, n8, CH):
+            wv = words[c0:c0 + CH]
+            pos = torch.arange(c0, c0 + wv.numel(), device=wv.device, dtype=torch.int64)
+            acc = (acc + int((wv * (pos * 0x9E3779B1 + 1)).sum().item())) & 0xFFFFFFFFFFFFFFFF
+        tail = raw[n8 * 8:]
+        if tail.numel():
+            acc = (acc + int((tail.to(torch.int64) * torch.arange(1, tail.numel() + 1, device=tail.device)).sum().item()) * 0x10001) & 0xFFFFFFFFFFFFFFFF
+        return acc
+
     def one():
         for _, t in tens:
             t.zero_()
         loss = run_step().item()
         torch.cuda.synchronize()
-        sums = [int((t if t.is_contiguous() else t.contiguous()).view(torch.uint8).view(-1)[: t.numel() * t.element_size() // 8 * 8].view(torch.int64).sum().item())
-                for _, t in tens]
+        sums = [checksum(t) for _, t in tens]
         g = gflat.clone()
         zero_grad()
         return loss, sums, g

@@ -83,5 +83,5 @@ del step, dit; gc.collect(); torch.cuda.empty_cache()
 dit = model(targets="all-linear")
 step = QwenLoraTrainStep(dit, lr=1e-4)
 dt, loss = timeit(step, embeddings(1, 32, 384))
-emit({"case": "cfg#2 shape, target_modules='all-linear' (every Linear adapted, conditioning head through cond_torch)", "ms_per_step": round(dt * 1e3, 1),
+emit({"case": "cfg#2 shape, target_modules='all-linear' (every Linear adapted, conditioning head through cond_hip.py)", "ms_per_step": round(dt * 1e3, 1),
       "images_per_s": round(1 / dt, 2), "loss": round(loss, 4), "lora_params_M": round(sum(p.numel() for p in dit.lora_parameters()) / 1e6, 1)})
