@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--no-fp8", action="store_true", help="skip the secondary MX-FP8 trunk measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary drop-in (autograd + torch optimizer) measurement")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the secondary disk-cache + PCIe inclusive measurement")
+    ap.add_argument("--sustained-steps", type=int, default=150, help="steps of the secondary sustained-throughput line (0 = skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args.gpus))
@@ -427,6 +428,56 @@ def main():
                                   "note": "dit(...)[0] -> MSE -> loss.backward() -> clip_grad_norm_ -> torch.optim.AdamW.step() -> zero_grad(), "
                                           "the reference's loop body (base_trainer.py:508-561) on the drop-in module; `value` above is the fused step"}
         del opt
+        step.zero_grad()
+    if world == 1 and B == 1 and args.sustained_steps > 0:
+        # secondary line: SUSTAINED throughput (`value` is a 20-40 step burst).  >= 150 back-to-back steps with no host
+        # synchronisation inside the loop; per-step GPU time from one HIP event per step on the launch stream (durations between
+        # consecutive events), wall clock around the whole run, package power / shader clock sampled by rocm-smi meanwhile.
+        import gc
+        import subprocess
+        import threading
+        ns = args.sustained_steps
+        smp, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                try:
+                    o = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+                    c = json.loads(o).get("card0", {})
+                    pw = [float(v) for k_, v in c.items() if "power" in k_.lower() and "(w)" in k_.lower()]
+                    ck = [float(str(v).strip("()").lower().replace("mhz", "")) for k_, v in c.items() if "sclk" in k_.lower() and "mhz" in str(v).lower()]
+                    smp.append((pw[0] if pw else None, ck[0] if ck else None))
+                except Exception:  # noqa: BLE001
+                    pass
+                stop.wait(0.5)
+        th = threading.Thread(target=poll, daemon=True)
+        for _ in range(5):
+            step.train_step(emb)
+        gc.collect()
+        gc.freeze()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(ns + 1)]
+        torch.cuda.synchronize()
+        th.start()
+        t1 = time.perf_counter()
+        evs[0].record()
+        for i in range(ns):
+            step.train_step(emb)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        stop.set(); th.join(6)
+        gc.unfreeze()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(ns))
+        pws = [a for a, _ in smp if a is not None]
+        cks = [b for _, b in smp if b is not None]
+        out["sustained"] = {"value": round(ns / dts, 4), "unit": "images/s", "steps": ns, "ms_per_step_wall": round(dts / ns * 1e3, 3),
+                            "ms_median": round(per[ns // 2], 3), "ms_p95": round(per[int(ns * 0.95)], 3), "ms_max": round(per[-1], 3),
+                            "ms_min": round(per[0], 3), "p95_over_median": round(per[int(ns * 0.95)] / per[ns // 2], 4),
+                            "vs_burst": round((dts / ns * 1e3) / ms_per_step, 4),
+                            "power_w_mean": round(sum(pws) / len(pws), 1) if pws else None, "power_w_max": max(pws) if pws else None,
+                            "sclk_mhz_mean": round(sum(cks) / len(cks), 1) if cks else None, "sclk_mhz_min": min(cks) if cks else None,
+                            "samples": len(smp),
+                            "note": "same resident batch as `value`, no host sync in the loop; per-step times = gaps between per-step HIP events"}
         step.zero_grad()
     if world == 1 and B == 1 and not args.no_hostfed:
         # secondary line: the step fed the way a training job feeds it -- the reference's on-disk embedding cache (fp16 .pt files,

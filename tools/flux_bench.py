@@ -14,6 +14,7 @@ ap.add_argument("--double", type=int, default=19); ap.add_argument("--single", t
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--res", type=int, default=512); ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--quant", default="", help='MX-FP8 trunk mode: "mxfp8" | "mxfp8-fb"')
+ap.add_argument("--multires", default="", help='cfg #5: ragged batch of buckets, e.g. "20x20,40x40" (token grids; one control of the same size each)')
 ap.add_argument("--targets", default="", help='"all-linear", or the regex of configs/face_seg_flux_kontext_fp16.yaml:11 with "regex"')
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -39,14 +40,60 @@ ctl = prepare_latent_image_ids(side, side); ctl[:, 0] = 1
 emb = dict(image_latents=torch.randn(B, S_t, 64).half().to(dev), control_latents=torch.randn(B, S_t, 64).half().to(dev),
            prompt_embeds=(torch.randn(B, T, 4096)).half().to(dev), pooled_prompt_embeds=torch.randn(B, 768).half().to(dev),
            text_ids=torch.zeros(T, 3), control_ids=ctl, latent_hw=(side, side))
-for _ in range(a.warmup): step.train_step(emb)
+def run():
+    if not a.multires:
+        return step.train_step(emb)
+    loss = step.forward_backward_multires(samples, txt)
+    step.optimizer_step(grad_scale=step.allreduce_grads())
+    step.zero_grad()
+    return loss
+
+
+pad = None
+if a.multires:      # the ragged two-bucket batch of tests/test_fullsize_cfgs_gpu.py (flux_kontext_trainer.py:579-796)
+    g = torch.Generator().manual_seed(53)
+    grids = [tuple(int(v) for v in s_.split("x")) for s_ in a.multires.split(",")]
+    samples = []
+    for (h, w) in grids:
+        samples.append(dict(image_latents=torch.randn(h * w, 64, generator=g).half().to(dev), control_latents=torch.randn(h * w, 64, generator=g).half().to(dev),
+                            hw=(h, w), control_hw=[(h, w)]))
+    B = len(grids)
+    txt = dict(text_ids=torch.zeros(T, 3), pooled_prompt_embeds=torch.randn(B, 768, generator=g).half().to(dev),
+               prompt_embeds=torch.randn(B, T, 4096, generator=g).half().to(dev))
+    toks = [2 * h * w for h, w in grids]
+    pad = 1.0 - sum(toks) / (len(toks) * max(toks))
+for _ in range(a.warmup): run()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(a.steps): loss = step.train_step(emb)
+for _ in range(a.steps): loss = run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-S = T + 2 * S_t; D = 3072
-f_lin = 2 * (a.double * S * 12 * D * D + a.single * S * (3 * D * D + 4 * D * D + 5 * D * D))
-f_attn = 2 * (a.double + a.single) * 2 * S * S * D
-tf = (2 * f_lin + 3.5 * f_attn) * B / 1e12
-print(json.dumps({"model": f"FLUX-Kontext-sized DiT {a.double}+{a.single} blocks", "targets": a.targets or "default", "trunk": a.quant or "bf16", "images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 2),
-                  "step_tflop_algorithmic": round(tf, 1), "tflops": round(tf / dt, 1), "loss": float(loss.item()),
+D = 3072
+if a.multires:
+    Ss = [T + n for n in toks]
+    f_lin = sum(2 * (a.double * S * 12 * D * D + a.single * S * (3 * D * D + 4 * D * D + 5 * D * D)) for S in Ss)
+    f_attn = sum(2 * (a.double + a.single) * 2 * S * S * D for S in Ss)
+    tf = (2 * f_lin + 3.5 * f_attn) / 1e12
+else:
+    S = T + 2 * S_t
+    f_lin = 2 * (a.double * S * 12 * D * D + a.single * S * (3 * D * D + 4 * D * D + 5 * D * D))
+    f_attn = 2 * (a.double + a.single) * 2 * S * S * D
+    tf = (2 * f_lin + 3.5 * f_attn) * B / 1e12
+# GEMM share of the replayed programs (HIP events around every GEMM launch of one extra step)
+from qflux_amd import _lib as L
+sys.path.insert(0, ROOT)
+gemm_frac = None
+try:
+    import bench as _b
+    plan = [p_ for k_, p_ in dit._plans.items() if (("multires" in str(k_)) == bool(a.multires))][-1]
+    fns = (L.lib.qfx_gemm_bf16, L.lib.qfx_gemm_grouped)
+    ev = _b.run_profiled(plan.fwd, fns, {}) + _b.run_profiled(plan.bwd, fns, {})
+    torch.cuda.synchronize()
+    gms = sum(x.elapsed_time(y) for x, y in ev)
+    gf = _b.gemm_flops_of(plan.fwd)[0] + _b.gemm_flops_of(plan.bwd)[0]
+    gemm_frac = {"gemm_ms": round(gms, 2), "gemm_share_of_step": round(gms / (dt * 1e3), 3), "gemm_frac_of_peak": round(gf / (gms * 1e-3) / 1e12 / 2500.0, 4)}
+except Exception as e:  # noqa: BLE001
+    gemm_frac = {"error": repr(e)[:200]}
+print(json.dumps({"model": f"FLUX-Kontext-sized DiT {a.double}+{a.single} blocks", "targets": a.targets or "default", "trunk": a.quant or "bf16",
+                  "batch": B, "multires": a.multires or None, "padded_token_fraction": None if pad is None else round(pad, 4),
+                  "images_per_s": round(B / dt, 3), "ms_per_step": round(dt * 1e3, 2),
+                  "step_tflop_algorithmic": round(tf, 1), "tflops": round(tf / dt, 1), "loss": float(loss.item()), "gemm": gemm_frac,
                   "mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))

@@ -31,8 +31,9 @@ def load_variant(name):
         return L.lib
     lib = C.CDLL(os.path.join(ROOT, "tools", "_ab", f"libqfx_{name}.so"))
     for sym, (res, args) in L.SYMBOLS.items():
-        fn = getattr(lib, sym)
-        fn.restype, fn.argtypes = res, args
+        fn = getattr(lib, sym, None)      # a library built from an older revision lacks the newer entry points
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
     return lib
 
 
