@@ -103,8 +103,14 @@ def test_reference_loop_under_accelerate_matches_oracle_plain_loop():
     assert hip.lora_store.is_consistent(DEV)          # optimizer.zero_grad(set_to_none) was survived (views re-attached)
     rel = [abs(a - b) / abs(b) for a, b in zip(lh, lo)]
     got = {n: p.detach().float().cpu() for n, p in hip.named_parameters() if "lora" in n}
-    drift = max(relmax(got[n], p) for n, p in oracle.named_parameters() if "lora" in n)
-    moved = max(float((got[n] - start[n]).abs().max()) for n in got)
-    print("accelerate loop: loss rel", rel, "adapter drift after", micro_steps // k, "optimizer steps:", drift)
-    assert max(rel) < QWEN_BARS[0] * 4, rel            # later micro-steps see adapters trained on bf16-noisy gradients
-    assert drift < 5e-2 and moved > 0, (drift, moved)
+    # Adam's first steps move every element by ~lr * sign(g): an element whose gradient is bf16 noise around zero may go the other way in
+    # the two runs (2 * lr apart after one step), so the adapters are compared as UPDATE VECTORS (cosine over all elements), not by max |d|
+    ref = {n: p.detach().float().cpu() for n, p in oracle.named_parameters() if "lora" in n}
+    du_h = torch.cat([(got[n] - start[n]).flatten() for n in got])
+    du_o = torch.cat([(ref[n] - start[n]).flatten() for n in got])
+    cos = float(torch.dot(du_h, du_o) / (du_h.norm() * du_o.norm() + 1e-30))
+    drift = max(relmax(got[n], ref[n]) for n in got)
+    moved = float(du_h.abs().max())
+    print("accelerate loop: loss rel", rel, "update cosine after", micro_steps // k, "optimizer steps:", cos, "max rel drift", drift)
+    assert max(rel) < QWEN_BARS[0] * 4, rel            # later micro-steps see adapters that already took an optimizer step
+    assert cos > 0.9 and moved > 0, (cos, moved)
