@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define QFX_ABI_VERSION 6
+#define QFX_ABI_VERSION 7
 
 #define QFX_OK 0
 #define QFX_EINVAL (-1)   /* bad shape / alignment / null pointer */
@@ -402,12 +402,30 @@ typedef struct qfx_attn_args {
   /* ABI 6 (zero = off): hl[0] X = O in qfx_attn_fwd; hl[1] X = d(pre-norm q) in qfx_attn_bwd_dq; hl[2] X = d(pre-norm k), hl[3] X = dV
    * in qfx_attn_bwd_dkv (the backward slots need qk_saved != NULL). */
   qfx_head_lora hl[4];
+  /* ABI 7: workspace of the ONE-PASS backward qfx_attn_bwd_fused (sizes from qfx_attn_bwd_fused_workspace; ignored by every other entry
+   * point): dq_acc = fp32 dQ tiles accumulated across the key blocks of a head, dq_turn = per-(batch, head, query tile) turn counters,
+   * ZERO before the first launch (every launch leaves them zero again). */
+  float* dq_acc; int32_t* dq_turn;
 } qfx_attn_args;
 
 int qfx_attn_fwd(const qfx_attn_args* a, void* stream);       /* needs Q,K,V -> O,lse2 */
 int qfx_attn_bwd_prep(const qfx_attn_args* a, void* stream);  /* dsum = rowsum(dO*O); optional: qfx_attn_bwd_dq computes and writes it too */
 int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream);    /* needs Q,K,V,O,dO,lse2 -> dQ and dsum (= rowsum(dO*O), consumed by qfx_attn_bwd_dkv: launch dq first) */
 int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream);   /* needs Q,K,V,dO,lse2,dsum -> dK,dV */
+/* ABI 7: the whole backward of the joint SDPA (transformer_qwenimage.py:329-337 under autograd) in ONE pass over the score tiles
+ * (csrc/qfx_attn_bwd1.hip): needs Q,K,V,O,dO,lse2 and the workspace dq_acc / dq_turn -> dQ,dK,dV (and dsum); every optional block of
+ * qfx_attn_args (key_mask, qk_saved..., hl[1..3]) means what it means for qfx_attn_bwd_dq + qfx_attn_bwd_dkv, results agree with that
+ * pair to fp32 summation order (dQ is summed over 256-key blocks in a fixed order: bit-reproducible).  dh = 128 only; the launch is a
+ * persistent grid of whole heads (<= 256 blocks) whose blocks wait for each other: it must not share the device with another kernel
+ * that never terminates.  qfx_attn_bwd_fused_workspace: bytes the two workspaces need for this shape; returns QFX_EUNSUPPORTED (sizes 0)
+ * where the one-pass form does not exist (dh != 128, S < 64) -- the caller then launches the two-pass pair. */
+int qfx_attn_bwd_fused(const qfx_attn_args* a, void* stream);
+int qfx_attn_bwd_fused_workspace(const qfx_attn_args* a, int64_t* acc_bytes, int64_t* turn_bytes);
+/* ABI 7: kernel-selection policy of the attention entry points (process-wide, read from the environment QFX_ATTN_FWD64 /
+ * QFX_ATTN_DQ64 / QFX_ATTN_FWD_WAVES once, at the first launch; this call overrides it): comma list of key=value with
+ * fwd64 = 0 | 1 | 1p | auto (32-query kernels | 64-query kernel | its pipelined form | by shape), dq64 = 0 | 1 | auto, fwd_waves = 0 | 4 | 8.
+ * NULL / "" = keep.  Returns QFX_EINVAL (nothing changed) on an unknown key or value. */
+int qfx_attn_tune(const char* spec);
 
 /* ---- flow-matching MSE criterion (src/qflux/losses/mse_loss.py:66-83 with weighting=1;
  * caller math of src/qflux/trainer/qwen_image_edit_trainer.py:839-847) --------------------------

@@ -13,10 +13,16 @@
 // lse2 is the log2-domain logsumexp of (scale * q.k + mask): P = exp2(scale*log2e * s + mask*log2e - lse2).
 #include "qfx_attn_common.h"
 
-namespace qfxi {      // qfx_attn64.hip
+#include <atomic>
+#include <cstring>
+#include <mutex>
+
+namespace qfxi {      // qfx_attn64.hip, qfx_attn_bwd1.hip
 int launch_attn_fwd64(const qfx_attn_args* a, hipStream_t stream);
 int launch_attn_fwd64p(const qfx_attn_args* a, hipStream_t stream);
 int launch_attn_bwd_dq64(const qfx_attn_args* a, hipStream_t stream);
+int launch_attn_bwd1(const qfx_attn_args* a, hipStream_t stream);
+int attn_bwd1_grid(const qfx_attn_args* a, int* nkb_out);
 }
 
 namespace {
@@ -317,6 +323,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_dq_kernel(c
     dsm[f] = part;
     if (g == 0 && q0 + f * 16 + li < S) a.dsum[((int64_t)b * a.H + h) * a.S_pad + q] = part;
   }
+#if !defined(QFX_ATTN_NO_CLAIM)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {      // round 6: claim the prologue's loads before the tile loop (see attn_bwd_dkv_kernel)
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) { asm volatile("" : "+v"(qf[f][kk])); asm volatile("" : "+v"(dof[f][kk])); }
+    asm volatile("" : "+v"(lse[f]), "+v"(dsm[f]));
+  }
+#endif
   f32x4 dq[DF][2];
 #pragma unroll
   for (int d = 0; d < DF; ++d) { dq[d][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq[d][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -514,6 +528,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
     for (int kk = 0; kk < KC; ++kk) kf[f][kk] = *(const bf16x8*)(kp + kk * 32);
     mk[f] = (a.key_mask && keyok[f]) ? a.key_mask[(int64_t)b * S + k] * LOG2E : 0.f;
   }
+  // Round 6: claim the prologue's register loads BEFORE the tile loop.  hipcc does not see the hand-placed s_waitcnt vmcnt(0) at the top
+  // of the loop; left pending in its model, the K fragment loads got counted waits (vmcnt(10) ... vmcnt(3)) at their first use INSIDE
+  // the loop, every iteration, right behind the 4-5 LDS-DMA pieces of the next tile -- vmcnt(3) then waits for the oldest of those.
+#if !defined(QFX_ATTN_NO_CLAIM)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) asm volatile("" : "+v"(kf[f][kk]));
+    asm volatile("" : "+v"(mk[f]));
+  }
+#endif
   f32x4 dk[DF][2], dv[DF][2];
 #pragma unroll
   for (int d = 0; d < DF; ++d)
@@ -658,12 +683,36 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkv_kernel(const qfx_attn_arg
 // unit of work (S = 8576: 837 vs 776 TF/s), so the 8-wave / one-block-per-CU form is chosen only where it fills the last round of
 // the 256 CUs clearly better (S = 2432: 240 blocks = 94 % vs 456 blocks on 512 half-CU slots = 89 %: 669 -> 710 TF/s).  The dQ
 // kernel measured slower with 8 waves in both cases and always uses 4.
+// Kernel-selection policy: read from the environment ONCE (first launch), changed through qfx_attn_tune (getenv per launch
+// is neither cheap nor safe against a host thread that edits the environment while another one launches).
+struct AttnPolicy {
+  std::atomic<int> fwd64{-1};       // -1 by shape, 0 = 32-query kernels, 1 = 64-query kernel, 2 = its pipelined form
+  std::atomic<int> dq64{-1};        // -1 by shape, 0 / 1
+  std::atomic<int> fwd_waves{0};    // 0 by shape, 4 / 8
+};
+AttnPolicy g_pol;
+std::once_flag g_pol_once;
+int parse_fwd64(const char* v) { return !strcmp(v, "auto") ? -1 : !strcmp(v, "0") ? 0 : !strcmp(v, "1") ? 1 : !strcmp(v, "1p") ? 2 : -2; }
+int parse_dq64(const char* v) { return !strcmp(v, "auto") ? -1 : !strcmp(v, "0") ? 0 : !strcmp(v, "1") ? 1 : -2; }
+void policy_from_env() {
+  std::call_once(g_pol_once, [] {
+    if (const char* e = getenv("QFX_ATTN_FWD64")) { const int v = parse_fwd64(e); if (v != -2) g_pol.fwd64 = v; }
+    if (const char* e = getenv("QFX_ATTN_DQ64")) { const int v = parse_dq64(e); if (v != -2) g_pol.dq64 = v; }
+    if (const char* e = getenv("QFX_ATTN_FWD_WAVES")) { const int v = atoi(e); if (v == 4 || v == 8) g_pol.fwd_waves = v; }
+  });
+}
+
+// Waves per block of the forward kernel.  Two independent 4-wave blocks per CU hide each other's barriers and are faster per
+// unit of work (S = 8576: 837 vs 776 TF/s), so the 8-wave / one-block-per-CU form is chosen only where it fills the last round of
+// the 256 CUs clearly better (S = 2432: 240 blocks = 94 % vs 456 blocks on 512 half-CU slots = 89 %: 669 -> 710 TF/s).  The dQ
+// kernel measured slower with 8 waves in both cases and always uses 4.
 int pick_waves(const qfx_attn_args* a) {
-  static const int forced = [] { const char* e = getenv("QFX_ATTN_FWD_WAVES"); return e ? atoi(e) : 0; }();   // A/B lever: 4 or 8
+  const int forced = g_pol.fwd_waves.load();   // A/B lever: 4 or 8
   if (forced == 4 || forced == 8) return forced;
   const long hb = (long)a->H * a->B;
   const long b4 = (long)((a->S + 127) / 128) * hb, b8 = (long)((a->S + 255) / 256) * hb;
-  const double e4 = (double)b4 / (double)(((b4 + 511) / 512) * 512), e8 = (double)b8 / (double)(((b8 + 255) / 256) * 256);
+  constexpr long NCU = QFX_NUM_CU_TOTAL;
+  const double e4 = (double)b4 / (double)(((b4 + 2 * NCU - 1) / (2 * NCU)) * 2 * NCU), e8 = (double)b8 / (double)(((b8 + NCU - 1) / NCU) * NCU);
   return e8 > 1.04 * e4 ? 8 : 4;
 }
 
@@ -673,20 +722,24 @@ int pick_waves(const qfx_attn_args* a) {
 // profiles/r05_attn_fwd64.json.
 // Whole-round test shared by the 64-query kernels: their 256-query blocks run one per CU.
 bool fills_rounds64(const qfx_attn_args* a) {
+  constexpr long NCU = QFX_NUM_CU_TOTAL;
   const long hb = (long)a->H * a->B;
   const long b64 = (long)((a->S + 255) / 256) * hb, b4 = (long)((a->S + 127) / 128) * hb;
-  const double e64 = (double)b64 / (double)(((b64 + 255) / 256) * 256);
-  const double e4 = (double)b4 / (double)(((b4 + 511) / 512) * 512);
+  const double e64 = (double)b64 / (double)(((b64 + NCU - 1) / NCU) * NCU);
+  const double e4 = (double)b4 / (double)(((b4 + 2 * NCU - 1) / (2 * NCU)) * 2 * NCU);
   const double eo = e64 > e4 ? e64 : e4;      // the 32-query kernels: 8 waves x 256 queries quantise like the 64-query blocks, 4 x 128 like b4
   return e64 > 0.82 && e64 >= eo - 0.02;
 }
-bool pick_fwd64(const qfx_attn_args* a) {
-  const char* e = getenv("QFX_ATTN_FWD64");
-  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-  return fills_rounds64(a);
+int pick_fwd64(const qfx_attn_args* a) {      // 0 = 32-query kernels, 1 = 64-query, 2 = pipelined 64-query
+  const int f = g_pol.fwd64.load();
+  if (f >= 0) return f;
+  return fills_rounds64(a) ? 1 : 0;
 }
 // dQ on 64-query waves (qfx_attn64.hip): 118 vs 136 us at S = 2432, 1312 vs 1326 us at S = 8576 (profiles/r05_attn_dq64.json); same policy
-bool pick_dq64(const qfx_attn_args* a) { return fills_rounds64(a); }
+bool pick_dq64(const qfx_attn_args* a) {
+  const int f = g_pol.dq64.load();
+  return f >= 0 ? f == 1 : fills_rounds64(a);
+}
 
 int check_common(const qfx_attn_args* a) {
   if (!a || a->B <= 0 || a->S <= 0 || a->H <= 0 || (a->S_pad % 64) || a->S_pad < a->S) return QFX_EINVAL;
@@ -722,15 +775,15 @@ extern "C" int qfx_attn_fwd(const qfx_attn_args* a, void* stream) {
   if (!a->Q || !a->K || !a->V || !a->O || !a->lse2 || (a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 4)) return QFX_EINVAL;
   if ((rc = check_head_lora(a, 0, 0))) return rc;
   // dh = 128: 64-query waves, one per SIMD, on the 32x32x16 MFMA with hand-allocated accumulator registers (qfx_attn64.hip, round 5)
-  // where its 256-query blocks fill whole rounds of the 256 CUs (pick_fwd64).  QFX_ATTN_FWD64 = 0 / 1 forces the 32-query kernels /
-  // the 64-query kernel (A/B lever and tests; read per launch so that one process can compare both).
-  if (a->dh == 128 && pick_fwd64(a)) {
-    // two 64-query forms exist: query blocks skewed by half a tile (default; 84.5 us at S = 2432) and a continuous pipeline over 32-key
-    // sub-tiles ("1p"; 88.0 us: a lone wave issues one instruction per ~6.4 cycles whatever their placement, and the pipeline needs ~30
-    // more of them per tile -- profiles/r05_attn_fwd64.json)
-    const char* e = getenv("QFX_ATTN_FWD64");
-    const bool piped = e && e[0] == '1' && e[1] == 'p';
-    return piped ? qfxi::launch_attn_fwd64p(a, (hipStream_t)stream) : qfxi::launch_attn_fwd64(a, (hipStream_t)stream);
+  // where its 256-query blocks fill whole rounds of the 256 CUs (pick_fwd64; forced either way through qfx_attn_tune / QFX_ATTN_FWD64).
+  // Two 64-query forms exist: query blocks skewed by half a tile (default; 84.5 us at S = 2432) and a continuous pipeline over 32-key
+  // sub-tiles ("1p"; 88.0 us: a lone wave issues one instruction per ~6.4 cycles whatever their placement, and the pipeline needs ~30
+  // more of them per tile -- profiles/r05_attn_fwd64.json)
+  policy_from_env();
+  if (a->dh == 128) {
+    const int f64 = pick_fwd64(a);
+    if (f64 == 2) return qfxi::launch_attn_fwd64p(a, (hipStream_t)stream);
+    if (f64 == 1) return qfxi::launch_attn_fwd64(a, (hipStream_t)stream);
   }
   const int nw = pick_waves(a);
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
@@ -765,11 +818,9 @@ extern "C" int qfx_attn_bwd_dq(const qfx_attn_args* a, void* stream) {
   if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ) return QFX_EINVAL;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4)) return QFX_EINVAL;
   if ((rc = check_head_lora(a, 1, 1))) return rc;
-  {   // dh = 128: the 64-query kernel of qfx_attn64.hip; QFX_ATTN_DQ64 = 0 / 1 forces the 32-query / 64-query kernel, default: pick_dq64
-    const char* e = getenv("QFX_ATTN_DQ64");
-    const bool forced = e && (e[0] == '0' || e[0] == '1');
-    if (a->dh == 128 && (forced ? e[0] == '1' : pick_dq64(a))) return qfxi::launch_attn_bwd_dq64(a, (hipStream_t)stream);
-  }
+  policy_from_env();
+  // dh = 128: the 64-query kernel of qfx_attn64.hip where its blocks fill whole rounds (forced either way: qfx_attn_tune / QFX_ATTN_DQ64)
+  if (a->dh == 128 && pick_dq64(a)) return qfxi::launch_attn_bwd_dq64(a, (hipStream_t)stream);
   const int nw = 4;   /* see pick_waves */
   dim3 grid(((a->S + 32 * nw - 1) / (32 * nw)) * a->H * a->B);
   if (a->dh == 128) {
@@ -794,5 +845,51 @@ extern "C" int qfx_attn_bwd_dkv(const qfx_attn_args* a, void* stream) {
   if (a->dh == 128) hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(512), 0, (hipStream_t)stream, *a);
   QFX_CHECK_LAUNCH();
+  return QFX_OK;
+}
+
+extern "C" int qfx_attn_bwd_fused_workspace(const qfx_attn_args* a, int64_t* acc_bytes, int64_t* turn_bytes) {
+  if (acc_bytes) *acc_bytes = 0;
+  if (turn_bytes) *turn_bytes = 0;
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (qfxi::attn_bwd1_grid(a, nullptr) <= 0) return QFX_EUNSUPPORTED;
+  const int64_t tiles = (int64_t)a->B * a->H * ((a->S + 63) / 64);
+  if (acc_bytes) *acc_bytes = tiles * 64 * 128 * 4;
+  if (turn_bytes) *turn_bytes = tiles * 4;
+  return QFX_OK;
+}
+
+extern "C" int qfx_attn_bwd_fused(const qfx_attn_args* a, void* stream) {
+  int rc = check_common(a);
+  if (rc) return rc;
+  if (a->dh != 128) return QFX_EUNSUPPORTED;
+  if (a->qk_saved && (!a->rope || !a->wq_txt || !a->wq_img || !a->wk_txt || !a->wk_img || (a->ld_saved % 4) || a->T < 0)) return QFX_EINVAL;
+  if (!a->Q || !a->K || !a->V || !a->O || !a->dO || !a->lse2 || !a->dsum || !a->dQ || !a->dK || !a->dV || !a->dq_acc || !a->dq_turn) return QFX_EINVAL;
+  if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8) || (a->lddo % 8) || (a->lddq % 4) || (a->lddk % 4) || (a->lddv % 4)) return QFX_EINVAL;
+  if (((uintptr_t)a->dq_acc % 16) || ((uintptr_t)a->dq_turn % 4)) return QFX_EINVAL;
+  if ((rc = check_head_lora(a, 1, 3))) return rc;
+  if ((rc = qfx_attn_bwd_prep(a, stream))) return rc;      // dsum = rowsum(dO * O): every key block needs it for every query tile
+  return qfxi::launch_attn_bwd1(a, (hipStream_t)stream);
+}
+
+extern "C" int qfx_attn_tune(const char* spec) {
+  policy_from_env();
+  if (!spec || !*spec) return QFX_OK;
+  int f64 = g_pol.fwd64.load(), d64 = g_pol.dq64.load(), fw = g_pol.fwd_waves.load();
+  char buf[256];
+  strncpy(buf, spec, sizeof(buf) - 1);
+  buf[sizeof(buf) - 1] = 0;
+  for (char* tok = strtok(buf, ","); tok; tok = strtok(nullptr, ",")) {
+    char* eq = strchr(tok, '=');
+    if (!eq) return QFX_EINVAL;
+    *eq = 0;
+    const char* v = eq + 1;
+    if (!strcmp(tok, "fwd64")) { f64 = parse_fwd64(v); if (f64 == -2) return QFX_EINVAL; }
+    else if (!strcmp(tok, "dq64")) { d64 = parse_dq64(v); if (d64 == -2) return QFX_EINVAL; }
+    else if (!strcmp(tok, "fwd_waves")) { fw = atoi(v); if (fw != 0 && fw != 4 && fw != 8) return QFX_EINVAL; }
+    else return QFX_EINVAL;
+  }
+  g_pol.fwd64 = f64; g_pol.dq64 = d64; g_pol.fwd_waves = fw;      // parsed completely before anything changes
   return QFX_OK;
 }

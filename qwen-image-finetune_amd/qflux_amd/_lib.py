@@ -150,10 +150,12 @@ class AttnArgs(C.Structure):
         ("wq_txt", C.c_void_p), ("wk_txt", C.c_void_p), ("wq_img", C.c_void_p), ("wk_img", C.c_void_p),
         ("T", C.c_int32), ("norm_flags", C.c_int32), ("norm_eps", C.c_float),
         ("hl", HeadLora * 4),
+        ("dq_acc", C.c_void_p), ("dq_turn", C.c_void_p),
     ]
 
 
-ABI_VERSION = 6        # QFX_ABI_VERSION
+ABI_VERSION = 7        # QFX_ABI_VERSION
+QFX_OK, QFX_EINVAL, QFX_EUNSUPPORTED = 0, -1, -2
 MAX_BATCH = 8          # QFX_MAX_BATCH
 MAX_LN_BATCH = 4       # QFX_MAX_LN_BATCH
 EPI_NONE, EPI_GELU, EPI_GATE_RES, EPI_DGELU = 0, 1, 2, 3
@@ -195,6 +197,9 @@ SYMBOLS = {
     "qfx_attn_bwd_prep": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "qfx_attn_bwd_dq": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "qfx_attn_bwd_dkv": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "qfx_attn_bwd_fused": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "qfx_attn_bwd_fused_workspace": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "qfx_attn_tune": (C.c_int, [C.c_char_p]),
     "qfx_mse_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _vp]),
     "qfx_mse_token_weighted_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f, _f, _vp]),
     "qfx_flowmatch_prepare": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import ops
 from ..plan_cache import PlanCache, ladder
 from ..modules import LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm
 from .transformer_qwenimage import (BF, F32, QfxAttention, QfxFeedForward, QwenImageTransformer2DModel, _AdaLNOut, _Cfg, _LinW,
@@ -666,8 +667,7 @@ class _FluxPlan(_QwenPlan):
         self._gemm(p, A1=A["dyg_j"], lda1=D, B1=wo.WT[D:], K1=D, M=M, N=4 * D, C_=A["A2"], ldc=ldA2, epi=L.EPI_DGELU, aux=bb["h"],
                    ldaux=4 * D, **kwm)
         q2 = bb["qkv"].view(M, 3 * D)
-        p.c(lib.qfx_attn_bwd_dq, C.byref(a))
-        p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
+        ops.emit_attn_backward(p, a, A)      # two-pass pair, or the one-pass kernel (QFX_ATTN_BWD)
         if not a.qk_saved:
             nq, nk = w["norms"]
             p.c(lib.qfx_qk_norm_rope_bwd, _ptr(A["dqkv"]), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq), _ptr(nk), _ptr(nq), _ptr(nk),

@@ -22,6 +22,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import ops
 from ..dp import DataParallelMixin
 from ..plan_cache import PlanCache, ladder
 from ..modules import (LoraConfig, LoraStore, QfxLinear, QfxLoraLinear, QfxRMSNorm, init_lora_, match_target)
@@ -1633,8 +1634,7 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             # ---- attention backward
             q2 = bb["qkv"].view(B * S, 3 * D)
-            p.c(lib.qfx_attn_bwd_dq, C.byref(a))
-            p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
+            ops.emit_attn_backward(p, a, A)      # two-pass pair, or the one-pass kernel (QFX_ATTN_BWD)
             if not a.qk_saved:      # (else: the backward of the QK norm + RoPE runs in the epilogues of the two kernels above)
                 nq_t, nk_t, nq_i, nk_i = w["norms"]
                 p.c(lib.qfx_qk_norm_rope_bwd, _ptr(dqkv), _ptr(bb["sqk"]), _ptr(self.rope), _ptr(nq_t), _ptr(nk_t), _ptr(nq_i),

@@ -227,6 +227,45 @@ def attn_call(name, a):
     L.check(getattr(lib, name)(C.byref(a), stream_ptr()), name)
 
 
+def emit_attn_backward(p, a, A):
+    """Emit the attention backward of one block into launch program `p`: the two-pass pair qfx_attn_bwd_dq + qfx_attn_bwd_dkv, or the
+    one-pass qfx_attn_bwd_fused (csrc/qfx_attn_bwd1.hip) with its workspace kept once per plan in the arena `A`.  QFX_ATTN_BWD =
+    2pass | 1pass | auto; auto (default) = whichever measured faster for the shape: the two-pass pair everywhere as of round 6
+    (profiles/r06_attn_onepass.json: the ordered fp32 dQ accumulation across key blocks costs what the saved recompute returns)."""
+    import os
+    mode = os.environ.get("QFX_ATTN_BWD", "auto")
+    if mode == "1pass":
+        if "dq_ws" not in A:
+            A["dq_ws"] = attn_bwd_fused_workspace(a)
+        ws = A["dq_ws"]
+        if ws is not None:
+            a.dq_acc, a.dq_turn = ws[0].data_ptr(), ws[1].data_ptr()
+            p.c(lib.qfx_attn_bwd_fused, C.byref(a))
+            return "1pass"
+    p.c(lib.qfx_attn_bwd_dq, C.byref(a))
+    p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
+    return "2pass"
+
+
+def attn_tune(spec: str):
+    """Kernel-selection policy of the attention entry points (qfx_attn_tune): "fwd64=0|1|1p|auto,dq64=0|1|auto,fwd_waves=0|4|8"."""
+    L.check(lib.qfx_attn_tune(spec.encode() if spec else None), "qfx_attn_tune")
+
+
+def attn_bwd_fused_workspace(a, device=None):
+    """Allocates (once per shape, by the caller) the workspace of qfx_attn_bwd_fused for the shape in `a` and points a.dq_acc / a.dq_turn
+    at it.  Returns (acc fp32 tensor, turn int32 tensor) -- keep them alive -- or None where the one-pass backward does not exist."""
+    nb_acc, nb_turn = C.c_int64(0), C.c_int64(0)
+    rc = lib.qfx_attn_bwd_fused_workspace(C.byref(a), C.byref(nb_acc), C.byref(nb_turn))
+    if rc != 0 or nb_acc.value == 0:
+        return None
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    acc = torch.empty(nb_acc.value // 4, dtype=torch.float32, device=device)
+    turn = torch.zeros(nb_turn.value // 4, dtype=torch.int32, device=device)      # zero before the first launch; launches leave it zero
+    a.dq_acc, a.dq_turn = acc.data_ptr(), turn.data_ptr()
+    return acc, turn
+
+
 def mse_loss_fwd_bwd(pred, target, S_t, gscale=1.0, want_grad=True):
     B, S_all, Cc = pred.shape
     loss = torch.zeros((), dtype=torch.float32, device=pred.device)

@@ -23,3 +23,12 @@ def pytest_sessionstart(session):
     import __graft_entry__ as g
     if os.path.exists(g.LIB) and g._stale():
         g.build()
+
+
+@pytest.fixture(autouse=True)
+def _reset_attn_policy():
+    """Tests switch the attention kernel-selection policy through qfx_attn_tune (process-wide): back to "by shape" after every test."""
+    yield
+    mod = sys.modules.get("qflux_amd.ops")
+    if mod is not None:
+        mod.attn_tune("fwd64=auto,dq64=auto,fwd_waves=0")

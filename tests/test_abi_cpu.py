@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.qfx_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib.qfx_abi_version() == _lib.ABI_VERSION == 7
     assert _lib.lib.qfx_build_arch() == b"gfx950"
 
 

@@ -861,23 +861,27 @@ def test_attention_kernels_are_bit_reproducible(S):
                 for i, (x, y) in enumerate(zip(cur, ref)):
                     assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), f"{fn.__name__}: output {i} differs between two launches on identical inputs"
 
-    import os
     for mode in ("0", "1", "1p"):       # the 32-query and both 64-query forwards
-        os.environ["QFX_ATTN_FWD64"] = mode
+        ops.attn_tune("fwd64=" + mode)
         try:
             run(L.lib.qfx_attn_fwd, [O, lse2, parts[0]])
         finally:
-            os.environ.pop("QFX_ATTN_FWD64", None)
+            ops.attn_tune("fwd64=auto")
     a.qk_saved, a.ld_saved, a.rope, a.rope_bstride = sqk.data_ptr(), 2 * D, rope.data_ptr(), 0
     a.wq_txt, a.wk_txt, a.wq_img, a.wk_img = (t.data_ptr() for t in ws)
     a.norm_flags, a.norm_eps = 0, 1e-6
     for mode in ("0", "1"):       # the 32-query and the 64-query dQ kernel
-        os.environ["QFX_ATTN_DQ64"] = mode
+        ops.attn_tune("dq64=" + mode)
         try:
             run(L.lib.qfx_attn_bwd_dq, [dqkv, dsum, parts[1]])
         finally:
-            os.environ.pop("QFX_ATTN_DQ64", None)
+            ops.attn_tune("dq64=auto")
     run(L.lib.qfx_attn_bwd_dkv, [dqkv, parts[2], parts[3]])
+    # round 6: the one-pass backward (dQ accumulated across key blocks in a fixed order) -- every output, and the turn counters back at zero
+    ws_ = ops.attn_bwd_fused_workspace(a)
+    assert ws_ is not None
+    run(L.lib.qfx_attn_bwd_fused, [dqkv, dsum, parts[1], parts[2], parts[3]])
+    assert int(ws_[1].abs().max()) == 0
 
 
 @pytest.mark.parametrize("S,H,Bn,mask,R", [(2432, 24, 1, 0, 16), (333, 2, 2, 0, 16), (333, 2, 2, 1, 0), (200, 3, 2, 2, 32), (64, 1, 1, 0, 0), (1000, 4, 1, 0, 16),
@@ -908,7 +912,7 @@ def test_attention_fwd64_matches_sdpa_and_the_32_query_kernel(S, H, Bn, mask, R,
         wpk = [L.head_fragment_image(wts[0], wts[1], dh), L.head_fragment_image(wts[2], wts[3], dh)]
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("QFX_ATTN_FWD64", mode if mode == "0" else form)
+        ops.attn_tune("fwd64=" + (mode if mode == "0" else form))      # reset after the test by conftest's _reset_attn_policy
         O = torch.zeros(Bn, S, D, dtype=torch.bfloat16, device=DEV)
         lse2 = torch.zeros(Bn, H, S_pad, device=DEV)
         part = torch.zeros(H, Bn * S, max(R, 1), device=DEV)
@@ -975,7 +979,7 @@ def test_attention_dq64_matches_autograd_and_the_32_query_kernel(S, H, Bn, mask,
     res = {}
     for fused in (0, 1):
         for mode in ("0", "1"):
-            monkeypatch.setenv("QFX_ATTN_DQ64", mode)
+            ops.attn_tune("dq64=" + mode)      # reset after the test by conftest's _reset_attn_policy
             O = torch.zeros(Bn, S, D, dtype=torch.bfloat16, device=DEV)
             lse2 = torch.zeros(Bn, H, S_pad, device=DEV)
             dsum = torch.zeros(Bn, H, S_pad, device=DEV)

@@ -11,8 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "qwen-image-finetune_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_ab")
-SOURCES = ["qfx_gemm.hip", "qfx_gemm_fp8.hip", "qfx_skinny.hip", "qfx_elem.hip", "qfx_attn.hip", "qfx_attn64.hip", "qfx_cond.hip"]
-EXTRA_FLAGS = {"qfx_attn64.hip": ["-fno-slp-vectorize"]}
+SOURCES = ["qfx_gemm.hip", "qfx_gemm_fp8.hip", "qfx_skinny.hip", "qfx_elem.hip", "qfx_attn.hip", "qfx_attn64.hip", "qfx_attn_bwd1.hip", "qfx_cond.hip"]
+EXTRA_FLAGS = {"qfx_attn64.hip": ["-fno-slp-vectorize"], "qfx_attn_bwd1.hip": ["-fno-slp-vectorize"]}
 
 
 def main():
