@@ -166,10 +166,16 @@ typedef struct qfx_lora_grad_args {
   float* G; float* G1; float* G2; int64_t g_sr; int64_t g_sc;
   int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off;
   float out_scale;                       /* lora_alpha/r for dB, 1 for dA */
+  /* ABI 7 (optional; NULL = the round-1..5 behaviour: the partial sums of the token chunks meet in G by fp32 atomics, order-dependent
+   * in the last bit).  ws: fp32 scratch of qfx_lora_grad_ws_floats(M, K, R) elements, ws_count: int32[(K + 127) / 128], ZERO before the
+   * first launch (every launch leaves it zero).  With both set the chunk partials go to ws and the LAST block to arrive at a 128-column
+   * strip adds them up in chunk order and updates G with plain stores: same inputs -> same bits. */
+  float* ws; int32_t* ws_count;
 } qfx_lora_grad_args;
 
 int qfx_lora_grad(const qfx_lora_grad_args* args, void* stream);
 int qfx_lora_grad_batch(const qfx_lora_grad_args* list, int32_t n, void* stream);   /* same R for all; see qfx_lora_down_batch */
+int64_t qfx_lora_grad_ws_floats(int32_t M, int32_t K, int32_t R);   /* fp32 elements of qfx_lora_grad_args.ws for one problem (0: a single token chunk, no scratch needed) */
 
 /* ---- LoRA operand packing (after every optimizer step) ---------------------------------------
  * From fp32 A[r,K], B[N,r] and scale s = lora_alpha/r build (Rp = r rounded up to 16):

@@ -429,6 +429,47 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
     for (int j = 0; j < 4; ++j) { st[j][0] = stn[j][0]; st[j][1] = stn[j][1]; }
   }
   // D[i = rank 4g+r][j = col li]
+  const int nchunk = (p.M + CH - 1) / CH;
+  if (p.ws != nullptr && nchunk > 1) {
+    // ---- deterministic form (ABI 7): partial tile -> scratch; the LAST block of this 128-column strip adds the chunks in chunk order.
+    // Hand-off as cdna_hip_programming.md section 5 (split-K reducer): plain slab stores, every wave drains them, ONE agent-scope release
+    // by lane 0, relaxed ticket; the last arriver acquires once and reads plain.
+    const int chunk = (int)blockIdx.y - kb.start[pi];
+    const int nstrip = (p.K + 127) / 128;      // the scratch is sized per problem (qfx_lora_grad_ws_floats), not per launch grid
+    float* slab = p.ws + ((int64_t)chunk * nstrip + blockIdx.x) * (NF * 2048) + tid * 4;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) *(f32x4*)(slab + (nf * 2 + cf) * 1024) = acc[nf][cf];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = (int*)&sX[0][0];
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ROCm 7.2 may drop the wait behind buffer_wbl2: restated where it cannot)
+      const int t = __hip_atomic_fetch_add(p.ws_count + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == nchunk - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.ws_count + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) acc[nf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunk; ++c) {      // chunk order: the sum does not depend on who arrived when
+      const float* src = p.ws + ((int64_t)c * nstrip + blockIdx.x) * (NF * 2048) + tid * 4;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) acc[nf][cf] += *(const f32x4*)(src + (nf * 2 + cf) * 1024);
+    }
+  }
+  const bool plain = p.ws != nullptr;      // one writer per element and launch: no atomic needed (a single chunk included)
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -440,7 +481,10 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf) {
         const int k = k0 + w * 32 + cf * 16 + li;
-        if (k < p.K) unsafeAtomicAdd(G + (int64_t)jj * p.g_sr + (int64_t)k * p.g_sc, acc[nf][cf][r] * p.out_scale);
+        if (k >= p.K) continue;
+        float* gp = G + (int64_t)jj * p.g_sr + (int64_t)k * p.g_sc;
+        if (plain) *gp += acc[nf][cf][r] * p.out_scale;
+        else unsafeAtomicAdd(gp, acc[nf][cf][r] * p.out_scale);
       }
     }
 }
@@ -586,6 +630,7 @@ int check_grad(const qfx_lora_grad_args* a) {
   if (a->group_R <= 0 || (a->group_R % 16) || (a->R % a->group_R) || a->R / a->group_R > 3) return QFX_EINVAL;
   if (a->R / a->group_R > 1 && !a->G1) return QFX_EINVAL;
   if (a->R / a->group_R > 2 && !a->G2) return QFX_EINVAL;
+  if (a->ws && (!a->ws_count || ((uintptr_t)a->ws % 16) || ((uintptr_t)a->ws_count % 4))) return QFX_EINVAL;
   return QFX_OK;
 }
 }  // namespace
@@ -725,6 +770,12 @@ extern "C" int qfx_lora_grad_batch(const qfx_lora_grad_args* list, int32_t n, vo
   }
   QFX_CHECK_LAUNCH();
   return QFX_OK;
+}
+
+extern "C" int64_t qfx_lora_grad_ws_floats(int32_t M, int32_t K, int32_t R) {
+  if (M <= 0 || K <= 0 || R <= 0 || (R % 16)) return 0;
+  const int64_t chunks = (M + GRAD_CH - 1) / GRAD_CH;
+  return chunks > 1 ? chunks * ((K + 127) / 128) * (R / 16) * 2048 : 0;
 }
 
 extern "C" int qfx_lora_grad(const qfx_lora_grad_args* a, void* stream) {

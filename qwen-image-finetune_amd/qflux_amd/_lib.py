@@ -60,6 +60,7 @@ class LoraGradArgs(C.Structure):
         ("G", C.c_void_p), ("G1", C.c_void_p), ("G2", C.c_void_p), ("g_sr", C.c_int64), ("g_sc", C.c_int64),
         ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
         ("out_scale", C.c_float),
+        ("ws", C.c_void_p), ("ws_count", C.c_void_p),
     ]
 
 
@@ -172,6 +173,7 @@ SYMBOLS = {
     "qfx_lora_down_batch": (C.c_int, [C.POINTER(LoraDownArgs), C.c_int32, _vp]),
     "qfx_lora_grad": (C.c_int, [C.POINTER(LoraGradArgs), _vp]),
     "qfx_lora_grad_batch": (C.c_int, [C.POINTER(LoraGradArgs), C.c_int32, _vp]),
+    "qfx_lora_grad_ws_floats": (C.c_int64, [_i32, _i32, _i32]),
     "qfx_lora_pack": (C.c_int, [_vp, _i32, _i32, _vp]),
     "qfx_ln_modulate_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f, _vp]),
     "qfx_ln_modulate_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _f, _vp, _vp]),

@@ -1233,6 +1233,15 @@ class _QwenPlan:
         a.rows_per_batch = M if rpb is None else rpb
         a.x_batch_rows, a.x_row_off = x_map
         a.out_scale = out_scale
+        # ABI 7: chunk partials through a scratch of the problem's own, added up in chunk order by the last block to arrive -- the flat
+        # LoRA gradient is bit-reproducible (QFX_GRAD_DET=0: the fp32 atomics of rounds 1-5).  One scratch per problem of the plan: launches
+        # on the main and the side stream may overlap, 288 GB make sharing pointless (~10 MB per block).
+        if os.environ.get("QFX_GRAD_DET", "1") != "0":
+            nfl = int(lib.qfx_lora_grad_ws_floats(M, K, R))
+            ws = torch.empty(max(nfl, 4), dtype=F32, device=X.device)
+            cnt = torch.zeros((K + 127) // 128, dtype=torch.int32, device=X.device)
+            a.ws, a.ws_count = _ptr(ws), _ptr(cnt)
+            prog.keep.append((ws, cnt))
         if defer is not None:
             defer.append(a)
             return

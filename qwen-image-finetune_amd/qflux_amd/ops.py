@@ -92,7 +92,7 @@ def lora_down(x, w_hi, w_lo, *, U=None, ext=None, Ut=None, group_R=None, group_s
     L.check(lib.qfx_lora_down(C.byref(a), stream_ptr()), "qfx_lora_down")
 
 
-def lora_grad(Vt, X, G, g_sr, g_sc, *, M, r_valid=None, group_R=None, K=None, rows_per_batch=None, x_map=(0, 0), out_scale=1.0):
+def lora_grad(Vt, X, G, g_sr, g_sc, *, M, r_valid=None, group_R=None, K=None, rows_per_batch=None, x_map=(0, 0), out_scale=1.0, deterministic=True):
     """Vt = (Vt_hi, Vt_lo) bf16 [R, ld>=roundup(M,32)] ; G a tensor or a tuple of up to 3 tensors (fused targets)."""
     a = L.LoraGradArgs()
     Gs = G if isinstance(G, (tuple, list)) else (G,)
@@ -106,7 +106,13 @@ def lora_grad(Vt, X, G, g_sr, g_sc, *, M, r_valid=None, group_R=None, K=None, ro
     a.rows_per_batch = M if rows_per_batch is None else rows_per_batch
     a.x_batch_rows, a.x_row_off = x_map
     a.out_scale = out_scale
+    if deterministic:      # ABI 7: chunk partials through scratch, summed in chunk order (False: the fp32 atomics of rounds 1-5)
+        ws = torch.empty(max(int(lib.qfx_lora_grad_ws_floats(a.M, a.K, a.R)), 4), dtype=torch.float32, device=X.device)
+        cnt = torch.zeros((a.K + 127) // 128, dtype=torch.int32, device=X.device)
+        a.ws, a.ws_count = _p(ws), _p(cnt)
     L.check(lib.qfx_lora_grad(C.byref(a), stream_ptr()), "qfx_lora_grad")
+    if deterministic:
+        assert int(cnt.abs().max()) == 0      # (synchronises: this helper is for tests)
 
 
 def pack_descs_tensor(descs, device):

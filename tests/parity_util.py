@@ -217,8 +217,8 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
 
 def assert_step_bit_reproducible(plan, run_step, gflat, zero_grad, what=""):
     """Two identical fused steps, each started from a ZEROED arena: every arena tensor must come out bit-identical (position-weighted
-    check-sums over all raw bytes).  Only the flat LoRA gradient and the scalar loss are exempt from the bit test -- the weight-gradient launches add
-    with fp32 atomics (order-dependent in the last bit): 1e-5 / 1e-6.  `run_step()` -> loss tensor; `gflat` the flat gradient buffer."""
+    check-sums over all raw bytes).  The flat LoRA gradient is bit-identical as well since round 6 (chunk partials summed in chunk
+    order instead of fp32 atomics); the scalar loss (one fp32 atomic per block of the criterion) is held to 1e-6.  `run_step()` -> loss tensor; `gflat` the flat gradient buffer."""
     tens, seen = [], set()
 
     def flat(prefix, obj):
@@ -265,5 +265,6 @@ def assert_step_bit_reproducible(plan, run_step, gflat, zero_grad, what=""):
     l2, s2, g2 = one()
     bad = [tens[i][0] for i in range(len(tens)) if s1[i] != s2[i]]
     assert abs(l1 - l2) <= 1e-6 * abs(l1) and not bad, (what, l1, l2, bad[:6])
-    assert ((g1 - g2).abs().max() / g1.abs().max()).item() < 1e-5, what
+    # round 6: the weight-gradient launches add their token chunks in a fixed order (qfx_lora_grad_args.ws): the flat gradient is bit-identical too
+    assert torch.equal(g1.view(torch.int32), g2.view(torch.int32)), (what, ((g1 - g2).abs().max() / g1.abs().max()).item())
     return len(tens)

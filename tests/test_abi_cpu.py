@@ -17,7 +17,7 @@ def test_header_symbols_are_exported_and_bound():
         g.build()
     from qflux_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "qfx.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(qfx_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(qfx_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:

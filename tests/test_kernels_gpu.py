@@ -496,6 +496,28 @@ def test_lora_grad(M, K, R, r):
     check(f"lora_grad_Bt_{M}", Gt, 2.0 * ref.t(), 1e-4)
 
 
+def test_lora_grad_is_bit_reproducible_and_matches_the_atomic_form():
+    """ABI 7: with a scratch the token-chunk partials (5 chunks at M = 2432) are added in chunk order by the last block of each 128-column
+    strip -- six launches give identical bits (the fp32-atomic form of rounds 1-5 differs in the last bit from launch to launch), both
+    forms agree to fp32 rounding, and the strip counters are back at zero (ops.lora_grad asserts it)."""
+    ops = _ops()
+    M, K, R, r = 2432, 3072, 16, 16
+    Vt = [(randn(R, 2432, seed=71 + i) * 0.3).to(BF).to(DEV) for i in range(2)]
+    X = randn(M, K, seed=73).to(BF).to(DEV)
+    outs = []
+    for rep in range(6):
+        G = torch.zeros(r, K, device=DEV)
+        ops.lora_grad(Vt, X, G, K, 1, M=M, r_valid=r)
+        outs.append(G)
+    assert all(torch.equal(outs[0].view(torch.int32), g.view(torch.int32)) for g in outs[1:])
+    Ga = torch.zeros(r, K, device=DEV)
+    ops.lora_grad(Vt, X, Ga, K, 1, M=M, r_valid=r, deterministic=False)
+    assert ((Ga - outs[0]).abs().max() / Ga.abs().max()).item() < 1e-6
+    G2 = outs[0].clone()      # accumulation on top of an existing gradient (micro-batches)
+    ops.lora_grad(Vt, X, G2, K, 1, M=M, r_valid=r)
+    assert ((G2 - 2 * outs[0]).abs().max() / outs[0].abs().max()).item() < 1e-6
+
+
 def test_lora_grad_fused_three_targets_and_remap():
     ops = _ops()
     Bn, rpb, T, K, Rp, r = 2, 70, 10, 256, 16, 8

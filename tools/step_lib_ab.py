@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--out", default="")
+    ap.add_argument("--gflat-repro", action="store_true", help="per variant: two forward+backward passes on identical draws, is the flat LoRA gradient bit-identical?")
     args = ap.parse_args()
     from step_ab import load_variant
     from qflux_amd.models import QwenImageTransformer2DModel
@@ -66,6 +67,23 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps * 1e3, float(loss)
 
+    repro = {}
+    if args.gflat_repro:
+        gen = torch.Generator().manual_seed(3)
+        noise = torch.randn(emb["image_latents"].shape, generator=gen)
+        u = torch.rand(B, generator=gen)
+        for n in names:
+            install(libs[n])
+            gs = []
+            for _ in range(3):
+                step.zero_grad()
+                step.forward_backward(emb, noise=noise, u=u)
+                torch.cuda.synchronize()
+                gs.append(dit.lora_store.gflat.clone())
+            step.zero_grad()
+            repro[n] = {"bit_identical": bool(all(torch.equal(gs[0].view(torch.int32), g.view(torch.int32)) for g in gs[1:])),
+                        "max_rel_diff": float(max(((g - gs[0]).abs().max() / gs[0].abs().max()).item() for g in gs[1:]))}
+            print("gflat repro", n, repro[n])
     res = {n: [] for n in names}
     losses = {}
     for r in range(args.rounds + 1):
@@ -75,7 +93,7 @@ def main():
             losses.setdefault(n, loss)
             if r:
                 res[n].append(ms)       # round 0 warms every variant's code objects
-    out = {"unit": "ms per step", "steps": args.steps, "variants": {}}
+    out = {"unit": "ms per step", "steps": args.steps, "variants": {}, "gflat_repro": repro}
     for n in names:
         med = sorted(res[n])[len(res[n]) // 2]
         out["variants"][n] = {"median_ms": med, "all": res[n], "first_loss": losses[n]}
