@@ -347,7 +347,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd1_kernel(const qfx_attn_args a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the accumulated tile has landed (so has the next tile's Q | dO)
         const uint32_t lo_ = lQ + w * 4096 + ln_ * 16;
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi) qacc[fi >> 1][fi & 1] += *(const QFX_AS3 f32x4*)(lo_ + fi * 1024);
+        for (int fi = 0; fi < 4; ++fi) {
+          const f32x4 o = *(const QFX_AS3 f32x4*)(lo_ + fi * 1024);
+          // element by element, on purpose: a vector += lowers to v_pk_add_f32 reading the MFMA accumulator pairs in place -- the pattern
+          // behind the run-to-run differences of round 4 (profiles/r05_nondeterminism.md; tools/pk_mfma_scan.py keeps it out)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = qacc[fi >> 1][fi & 1][r];
+            asm volatile("" : "+v"(v));
+            qacc[fi >> 1][fi & 1][r] = v + o[r];
+          }
+        }
       }
 #pragma unroll
       for (int fi = 0; fi < ((BWD1_ABL & 2) ? 0 : 4); ++fi)

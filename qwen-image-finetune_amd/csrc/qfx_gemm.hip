@@ -623,12 +623,14 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
     };
     auto fixup = [&]() {
       unsigned* fl = ga.wflag + gtile * 8 + w;
+      bool got = false;
       for (int spin = 0; spin < (1 << 21); ++spin) {      // scalar poll past the scalar cache: no vector registers in this loop
         unsigned v;
         asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(fl) : "memory");
-        if (v != 0u) break;
+        if (v != 0u) { got = true; break; }
         __builtin_amdgcn_s_sleep(8);
       }
+      if (!got) __builtin_trap();      // a producer that never shows is a failed launch (HIP error on the stream), not a silently incomplete tile
       asm volatile("buffer_inv sc1" ::: "memory");      // words of the workspace may sit in this CU's L1 from an earlier launch
       int lp;
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lp));
@@ -1051,26 +1053,24 @@ int validate(const qfx_gemm_args* a) {
 // overrides the three efficiency factors (A/B experiments).  Both are read once per process.
 struct Geo { int bmt, tn; double area, eff; bool on; };
 constexpr int NGEO = 3;
-struct GeoTable { Geo g[NGEO]; };
+struct GeoTable { Geo g[NGEO]; bool split_on; int split_min_k, split_bias; };
 // Process-wide tuning state: guarded by a mutex, initialised exactly once from the environment, and every launch works on
 // its own SNAPSHOT of the table -- qfx_gemm_tune() from one thread can no longer tear the table under a launch from another
 // (side-stream / data-parallel hook threads launch GEMMs concurrently with the main thread).
+// The same-XCD split-K policy lives in the same table (it used to be three loose globals read without the lock):
+// QFX_GEMM_SPLITK = 0 / 1, QFX_GEMM_SPLITK_MINK = smallest base K taken, QFX_GEMM_SPLITK_BIAS = K tiles the consumer's half is shorter by.
+#if defined(QFX_GEMM_SPLITK_DEFAULT_ON)      // A/B builds (tools/build_variants.py)
+#define QFX_SPLIT_DEFAULT true
+#else
+#define QFX_SPLIT_DEFAULT false
+#endif
 GeoTable g_geo_tab = {{
     {256, 128, 1.0, 1.00, true},
     {256, 256, 2.0, 1.09, true},
     {160, 192, 0.9375, 0.965, true},      // round 4: 0.9375 of the work at ~0.965 of the per-flop speed (profiles/r04_gemm_tiles.json)
-}};
+}, QFX_SPLIT_DEFAULT, 9216, 3};
 std::mutex g_geo_mu;
 std::once_flag g_geo_once;
-// split-K policy (read once from the environment in geo_init): QFX_GEMM_SPLITK = 0 / 1, QFX_GEMM_SPLITK_MINK = smallest base K taken,
-// QFX_GEMM_SPLITK_BIAS = K tiles the consumer's half is shorter by
-#if defined(QFX_GEMM_SPLITK_DEFAULT_ON)      // A/B builds (tools/build_variants.py)
-bool g_split_on = true;
-#else
-bool g_split_on = false;
-#endif
-int g_split_min_k = 9216;
-int g_split_bias = 3;
 
 // `tiles`: "legacy" | "all" | comma list of exact BMTxTN names; `eff`: three comma-separated factors.  All-or-nothing: a value
 // that does not parse leaves the table untouched and returns QFX_EINVAL.  Caller holds g_geo_mu.
@@ -1078,10 +1078,11 @@ int geo_set_locked(const char* tiles, const char* eff) {
   GeoTable t = g_geo_tab;
   if (tiles && !strncmp(tiles, "splitk", 6)) {      // "splitk=0|1", "splitk_mink=<K>", "splitk_bias=<K tiles>": the split-K policy (A/B lever, tests)
     int v = 0;
-    if (sscanf(tiles, "splitk=%d", &v) == 1 && (v == 0 || v == 1)) { g_split_on = v != 0; return QFX_OK; }
-    if (sscanf(tiles, "splitk_mink=%d", &v) == 1 && v >= 2048) { g_split_min_k = v; return QFX_OK; }
-    if (sscanf(tiles, "splitk_bias=%d", &v) == 1 && v >= 0 && v <= 16) { g_split_bias = v; return QFX_OK; }
-    return QFX_EINVAL;
+    if (sscanf(tiles, "splitk=%d", &v) == 1 && (v == 0 || v == 1)) t.split_on = v != 0;
+    else if (sscanf(tiles, "splitk_mink=%d", &v) == 1 && v >= 2048) t.split_min_k = v;
+    else if (sscanf(tiles, "splitk_bias=%d", &v) == 1 && v >= 0 && v <= 16) t.split_bias = v;
+    else return QFX_EINVAL;
+    tiles = nullptr;      // (the efficiency factors of the same call are still parsed below; the table is committed once, at the end)
   }
   if (tiles && *tiles) {
     const std::string v(tiles);
@@ -1126,9 +1127,9 @@ void geo_init() {
       fprintf(stderr, "libqfx: QFX_GEMM_TILES=\"%s\" not understood (legacy | all | comma list of 256x128,256x256,160x192): ignored\n", tiles);
     if (geo_set_locked(nullptr, eff) != QFX_OK)
       fprintf(stderr, "libqfx: QFX_GEMM_EFF=\"%s\" not understood (three factors in (0.1, 10)): ignored\n", eff);
-    if (const char* e = getenv("QFX_GEMM_SPLITK")) g_split_on = e[0] != '0';
-    if (const char* e = getenv("QFX_GEMM_SPLITK_MINK")) { const int v = atoi(e); if (v >= 2048) g_split_min_k = v; }
-    if (const char* e = getenv("QFX_GEMM_SPLITK_BIAS")) { const int v = atoi(e); if (v >= 0 && v <= 16) g_split_bias = v; }
+    if (const char* e = getenv("QFX_GEMM_SPLITK")) g_geo_tab.split_on = e[0] != '0';
+    if (const char* e = getenv("QFX_GEMM_SPLITK_MINK")) { const int v = atoi(e); if (v >= 2048) g_geo_tab.split_min_k = v; }
+    if (const char* e = getenv("QFX_GEMM_SPLITK_BIAS")) { const int v = atoi(e); if (v >= 0 && v <= 16) g_geo_tab.split_bias = v; }
   });
 }
 
@@ -1142,12 +1143,14 @@ GeoTable geo_snapshot() {
 // grids), grown on demand, kept for the life of the process
 struct SplitWs { float* ws = nullptr; unsigned* flag = nullptr; size_t tiles = 0; };
 std::mutex g_ws_mu;
-std::map<hipStream_t, SplitWs> g_ws;
+std::map<std::pair<int, hipStream_t>, SplitWs> g_ws;      // (device, stream): the null stream of two devices must not share a workspace
 bool split_ws(hipStream_t s, size_t tiles, float** ws, unsigned** flag) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;   // no allocation inside a graph capture: unsplit
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  SplitWs& w = g_ws[s];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  SplitWs& w = g_ws[std::make_pair(dev, s)];
   if (w.tiles < tiles) {
     // (an old, smaller workspace may still be read by a grid in flight on this stream: it is left allocated, not freed)
     float* nw = nullptr; unsigned* nf = nullptr;
@@ -1156,6 +1159,8 @@ bool split_ws(hipStream_t s, size_t tiles, float** ws, unsigned** flag) {
     if (hipMemsetAsync(nf, 0, tiles * 8 * sizeof(unsigned), s) != hipSuccess) { (void)hipFree(nw); (void)hipFree(nf); return false; }
     w.ws = nw; w.flag = nf; w.tiles = tiles;
   }
+  // every split launch starts from cleared flags (a launch that died mid-way must not leave a stale 'ready' behind)
+  if (hipMemsetAsync(w.flag, 0, tiles * 8 * sizeof(unsigned), s) != hipSuccess) return false;
   *ws = w.ws; *flag = w.flag;
   return true;
 }
@@ -1180,8 +1185,9 @@ void launch_geo(int gi, int grid, hipStream_t s, const GroupedArgs& ga) {
 
 template <bool FP8>
 int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo, int epi, hipStream_t s, bool split = false, float* ws = nullptr,
-                   unsigned* wflag = nullptr) {
-  const int bmt = g_geo_tab.g[geo].bmt, tn = g_geo_tab.g[geo].tn;      // tile shapes are compile-time constants of the table: never tuned
+                   unsigned* wflag = nullptr, int split_bias = 0) {
+  constexpr int GEO_BMT[NGEO] = {256, 256, 160}, GEO_TN[NGEO] = {128, 256, 192};      // = the table's tile shapes (compile-time constants, never tuned)
+  const int bmt = GEO_BMT[geo], tn = GEO_TN[geo];
   const int per_tile = split ? 2 : 1;          // work items per tile
   int tiles = 0;
   for (int i = 0; i < n; ++i) {
@@ -1199,7 +1205,7 @@ int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo
   ga.gm = (n >= 6 && !split) ? 4 : 8;
   if constexpr (!FP8) {
     if (split) {
-      ga.ws = ws; ga.wflag = wflag; ga.kh_bias = g_split_bias;
+      ga.ws = ws; ga.wflag = wflag; ga.kh_bias = split_bias;
       switch (epi) {                     // one round: every item has its own CU, the two items of a tile are neighbours in one XCD
         case QFX_EPI_NONE: launch_split<QFX_EPI_NONE>(tiles, s, ga); break;
         case QFX_EPI_GELU: launch_split<QFX_EPI_GELU>(tiles, s, ga); break;
@@ -1225,8 +1231,7 @@ int launch_grouped(GroupedArgs& ga, const qfx_gemm_args* probs[], int n, int geo
 extern "C" int qfx_gemm_tune(const char* tiles, const char* eff) {
   geo_init();
   std::lock_guard<std::mutex> lk(g_geo_mu);
-  const int rc = geo_set_locked(tiles, nullptr);
-  return rc != QFX_OK ? rc : geo_set_locked(nullptr, eff);
+  return geo_set_locked(tiles, eff);      // both arguments are parsed into ONE temporary table, committed once (all or nothing)
 }
 
 extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* stream) {
@@ -1262,18 +1267,18 @@ extern "C" int qfx_gemm_grouped(const qfx_gemm_args* groups, int32_t n, void* st
   // tiles of 256x256 fill under half the chip; split along K they are 240 work items -- one round -- and move a third fewer operand
   // bytes per flop (profiles/r05_gemm_splitk.json).  Taken when every problem has whole 256-column tiles and a base K of >= 9216, the
   // items fill one round in pairs that never straddle an XCD (items % 16 == 0), and the round is at least 85 % full.
-  if (g_split_on && n256) {
+  if (geo.split_on && n256 && geo.g[1].on) {
     long t256 = 0;
     bool deep = true;
     for (int i = 0; i < n; ++i) {
       t256 += (long)((groups[i].M + 255) / 256) * (groups[i].N / 256);
-      deep = deep && groups[i].K1 >= g_split_min_k;
+      deep = deep && groups[i].K1 >= geo.split_min_k && groups[i].K1 / 64 / 2 - geo.split_bias >= 1;      // both halves keep at least one K tile
     }
     const long items = 2 * t256;
     float* ws = nullptr;
     unsigned* wflag = nullptr;
     if (deep && items <= QFX_NUM_CU && items % 16 == 0 && items * 100 >= QFX_NUM_CU * 85 && split_ws((hipStream_t)stream, (size_t)t256, &ws, &wflag))
-      return launch_grouped<false>(ga, probs, n, 1, groups[0].epi, (hipStream_t)stream, true, ws, wflag);
+      return launch_grouped<false>(ga, probs, n, 1, groups[0].epi, (hipStream_t)stream, true, ws, wflag, geo.split_bias);
   }
   return launch_grouped<false>(ga, probs, n, best, groups[0].epi, (hipStream_t)stream);
 }

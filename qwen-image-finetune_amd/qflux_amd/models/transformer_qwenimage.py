@@ -1326,7 +1326,39 @@ class _QwenPlan:
         else:
             p.c(lib.qfx_mod_gemv, _ptr(A["tproj"]), B, 256, _ptr(P["t1_Wp"]), _ptr(P["t1_bp"]), 1, D, 0, _ptr(A["t1"]))
             p.c(lib.qfx_mod_gemv, _ptr(A["t1"]), B, D, _ptr(P["t2_Wp"]), _ptr(P["t2_bp"]), 1, D, 1, _ptr(A["temb"]))
-            p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
+            # Round 6 lever (QFX_SIDE_MOD=1, default OFF): the modulation GEMVs of all blocks are ONE pass over 13.6 GB of frozen weights at
+            # HBM speed (2.2 ms of a 93 ms step with the matrix pipes idle).  With the lever only block 0's two matrices stay on the main
+            # stream, the rest go out on the side stream in three launches under the first blocks' GEMMs, each joined in front of the first
+            # block that reads its rows.  Measured (profiles/r06_step_side_mod.json): 95.35 vs 95.31 ms -- nothing.  The persistent GEMM
+            # blocks (12 waves x ~160 registers) leave no register file for a second kernel's waves on their CUs, so the side launches only
+            # run in the seams between GEMM launches: the same wall the side-stream gradient launches hit.
+            mod_joins = {}
+            if Lyr > 4 and os.environ.get("QFX_SIDE_MOD", "0") == "1":
+                side = ops.side_stream(model.device, 0)
+                p.side = side
+
+                def gemv(i0, i1, on_side):
+                    (p.c_side if on_side else p.c)(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]) + 8 * i0, _ptr(P["mod_b"]) + 8 * i0,
+                                                   i1 - i0, 6 * D, 1, A["mods"][i0].data_ptr())
+                gemv(0, 2, False)
+                ev_fork = torch.cuda.Event()
+                p.keep.append(ev_fork)
+
+                def fork(ev=ev_fork, side=side):
+                    ev.record(torch.cuda.current_stream())
+                    side.wait_event(ev)
+                p.py(fork)
+                for b0, b1 in ((1, 3), (3, 9), (9, Lyr)):
+                    if b0 >= Lyr:
+                        break
+                    b1 = min(b1, Lyr)
+                    gemv(2 * b0, 2 * b1, True)
+                    ev = torch.cuda.Event()
+                    p.keep.append(ev)
+                    p.py(lambda ev=ev, side=side: ev.record(side))
+                    mod_joins[b0] = ev
+            else:
+                p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]), _ptr(P["mod_b"]), 2 * Lyr, 6 * D, 1, _ptr(A["mods"]))
             p.c(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["norm_out_Wp"]), _ptr(P["norm_out_bp"]), 1, 2 * D, 1, _ptr(A["mod_out"]))
         kw = self._site_fwd(p, P["img_in"], A["site"]["img_in"], A["in_img"], cfg.in_channels, rows["img"])
         self._gemm(p, A1=A["in_img"], lda1=cfg.in_channels, B1=P["img_in"].W, K1=cfg.in_channels, M=rows["img"], N=D,
@@ -1337,6 +1369,8 @@ class _QwenPlan:
                    bias=P["txt_in"].b, row_mask=self.rm_txt0, **kw)
         self.attn_args = []
         for i in range(Lyr):
+            if not self.cond and i in mod_joins:      # this block's modulation rows come from the side stream
+                p.py(lambda ev=mod_joins[i]: torch.cuda.current_stream().wait_event(ev))
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
             self._emit_double_fwd(p, P["blocks"][i], A["blk"][i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   {s: (A["X"][s][i + 1], (0, 0)) for s in ("img", "txt")}, last=(i == Lyr - 1), norm_flags=0, par=i & 1)

@@ -14,8 +14,9 @@ for p in (ROOT, os.path.join(ROOT, "qwen-image-finetune_amd"), os.path.join(ROOT
 BF = torch.bfloat16
 # Step-parity bars of the tiny-model drivers (HIP path vs the bf16 oracle): 2x the maxima observed over the whole -m gpu suite of
 # round 4 (profiles/r04_parity_observed.json: Qwen, 23 runs: loss 1.8e-4, prediction 7.4e-3, worst gradient 1.44e-2 of the tensor
-# maximum; FLUX, 18 runs: 2.7e-3, 1.13e-2, 3.75e-2), never looser than the round-3 bars (2e-2, 2e-2, 4e-2) -- the FLUX gradient
-# bar therefore stays at 4e-2, 1.07x its observed maximum.
+# maximum; FLUX, 18 runs: 2.7e-3, 1.13e-2, 3.75e-2), never looser than the round-3 bars (2e-2, 2e-2, 4e-2).  The FLUX gradient bar (4e-2) is
+# where the tiny bf16 graph's OWN reduction-order noise sits (3.8e-2, profiles/r06_flux_bar_noise.json): run_flux_step_parity evaluates
+# the oracle a second time on the GPU and lets a tensor exceed the bar only up to twice that self-noise on the same tensor.
 QWEN_BARS = (4e-4, 1.5e-2, 3e-2)     # loss, prediction, gradient
 FLUX_BARS = (6e-3, 2e-2, 4e-2)
 LOSS_BAR, PRED_BAR, GRAD_BAR = FLUX_BARS      # (the looser set: for callers that do not say which model)
@@ -181,6 +182,19 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
     emb_o = dict(emb, control_latents=emb["control_latents"].to(BF))
     loss_o, pred_o = FO.flux_compute_loss(oracle, emb_o, noise, t, BF, return_pred=True)
     loss_o.float().backward()
+    # Round 6 (profiles/r06_flux_bar_noise.json): the tiny FLUX bf16 graph differs from ITSELF by up to 3.8e-2 of a
+    # gradient tensor's maximum when only the reduction order changes (torch CPU kernels vs rocBLAS on the GPU; 8 weight seeds) -- the
+    # 4e-2 gradient bar sits at the eager graph's own noise, and the HIP path's worst tensor (3.9e-2) is the oracle's own worst tensor.
+    # So the same oracle step is ALSO evaluated on the GPU and a tensor may exceed the bar only as far as twice the oracle's self-noise
+    # on that very tensor.
+    import copy
+    oracle_g = copy.deepcopy(oracle).to(device)
+    for p_ in oracle_g.parameters():
+        p_.grad = None
+    emb_g = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in emb_o.items()}
+    FO.flux_compute_loss(oracle_g, emb_g, noise.to(device), t.to(device), BF).float().backward()
+    self_noise = {n: relmax(p_.grad, dict(oracle.named_parameters())[n].grad) for n, p_ in oracle_g.named_parameters()
+                  if "lora" in n and p_.grad is not None and dict(oracle.named_parameters())[n].grad is not None}
     step = FluxKontextTrainStep(hip)
     res = {}
     if fused:
@@ -197,7 +211,7 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
     res["loss_oracle"], res["loss_hip"] = loss_o.item(), loss_h.item()
     res["loss_rel"] = abs(loss_h.item() - loss_o.item()) / abs(loss_o.item())
     og = {n: p.grad for n, p in oracle.named_parameters() if "lora" in n}
-    worst, worst_name, bad = 0.0, None, 0
+    worst, worst_name, bad, worst_norm = 0.0, None, 0, 0.0
     for n, p in hip.named_parameters():
         if "lora" in n:
             if og[n] is None:
@@ -207,9 +221,13 @@ def run_flux_step_parity(device="cuda:0", verbose=False, cfg=None, hw=(4, 6), T=
             bad += int((p.grad.abs().max().item() > 0) != (og[n].abs().max().item() > 0))
             if e > worst:
                 worst, worst_name = e, n
+            # normalised: 1.0 = the bar, or twice the eager graph's own noise on this tensor where that is larger
+            worst_norm = max(worst_norm, e / max(FLUX_BARS[2], 2.0 * self_noise.get(n, 0.0) / _grad_tol_factor(n)))
     res["grad_rel_worst"], res["grad_worst_name"], res["n_lora"] = worst, worst_name, len(og)
+    res["grad_rel_worst_over_allowed"] = worst_norm
+    res["oracle_self_noise_worst"] = max(self_noise.values()) if self_noise else 0.0
     _observe("flux_tiny_step", res)
-    res["ok"] = bool(res["loss_rel"] < FLUX_BARS[0] and res.get("pred_rel", 0.0) < FLUX_BARS[1] and worst < FLUX_BARS[2] and bad == 0)
+    res["ok"] = bool(res["loss_rel"] < FLUX_BARS[0] and res.get("pred_rel", 0.0) < FLUX_BARS[1] and worst_norm < 1.0 and bad == 0)
     if verbose:
         print(res)
     return res
