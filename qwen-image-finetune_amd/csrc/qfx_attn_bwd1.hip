@@ -38,6 +38,9 @@ constexpr int ACC_TILE = 64 * DH;               // floats of one dQ tile in the 
 #ifndef BWD1_ABL
 #define BWD1_ABL 0
 #endif
+#ifndef BWD1_STORE_AUX
+#define BWD1_STORE_AUX 16      // cache policy of the workspace stores: 16 = sc1 (agent scope: what the protocol needs); 0 / 1 / 2 = plain / sc0 / nt timing experiments
+#endif
 constexpr int SPIN_LIMIT = 1 << 20;      // ~1 s of polling: a turn that never comes is a trap, not a hang
 
 template <class F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd1_kernel(const qfx_attn_args a
       }
 #pragma unroll
       for (int fi = 0; fi < ((BWD1_ABL & 2) ? 0 : 4); ++fi)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qacc[fi >> 1][fi & 1]), accr, ln_ * 16, aoff + fi * 1024, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qacc[fi >> 1][fi & 1]), accr, ln_ * 16, aoff + fi * 1024, BWD1_STORE_AUX);
       prev_ti = ti;
       prev_next = rank == nkb - 1 ? 0 : rank + 1;      // the last key block leaves the counter at zero for the next launch
       // next tile (rotation) and its first arriver
