@@ -214,6 +214,51 @@ def pmc_traffic(kernel="gemm256_kernel"):
         return None, None
 
 
+def live_pmc_traffic(kernel="gemm256_kernel", budget_s=200):
+    """HBM-side traffic of the dominant kernel measured IN THIS RUN (the committed summary is a constant the driver
+    never observes): two rocprofv3 counter passes (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2: separate passes; --pmc with --kernel-trace
+    only -- MI355X_MICROARCH.md) over a 2-step run of this same command as child processes, folded by tools/pmc_to_json.py's rules
+    (FETCH_SIZE x 2 on gfx950, KB per dispatch).  Returns (bytes per launch, source dict) or (None, None) when rocprofv3 is missing,
+    refuses, or the passes do not fit the time budget -- the caller then falls back to the committed summary."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_to_json
+    except Exception:  # noqa: BLE001
+        return None, None
+    tmp = tempfile.mkdtemp(prefix="qfx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    inner = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-batch2", "--no-fp8",
+             "--no-dropin", "--no-hostfed", "--sustained-steps", "0", "--no-live-traffic"]
+    t0 = time.perf_counter()
+    try:
+        acc = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 30:
+                return None, None
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + inner,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+            if r.returncode != 0:
+                return None, None
+            acc[ctr] = pmc_to_json.read_pass(d, ctr).get(kernel)
+        if not acc["FETCH_SIZE"] or not acc["WRITE_SIZE"]:
+            return None, None
+        (fn, fkb), (wn, wkb) = acc["FETCH_SIZE"], acc["WRITE_SIZE"]
+        traffic = int(round(fkb / fn * 1024 * 2)) + int(round(wkb / wn * 1024))
+        return traffic, {"measured_in_this_run": True, "passes": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace over 2 steps of this command",
+                         "launches_counted": int(fn), "seconds": round(time.perf_counter() - t0, 1)}
+    except Exception:  # noqa: BLE001  (timeout, unreadable output ...: the committed summary is the fallback)
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run (one process per GPU, RCCL) and
     relay rank 0's JSON line."""
@@ -243,6 +288,7 @@ def main():
     ap.add_argument("--no-fp8", action="store_true", help="skip the secondary MX-FP8 trunk measurement")
     ap.add_argument("--no-dropin", action="store_true", help="skip the secondary drop-in (autograd + torch optimizer) measurement")
     ap.add_argument("--no-hostfed", action="store_true", help="skip the secondary disk-cache + PCIe inclusive measurement")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC summary instead of two rocprofv3 passes of this run")
     ap.add_argument("--sustained-steps", type=int, default=150, help="steps of the secondary sustained-throughput line (0 = skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -564,6 +610,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline((cfgd.attention_head_dim, cfgd.num_attention_heads, Jd, S_t, T))
         except Exception as e:  # the baseline is a reported side number; never let it kill the bench line
             out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    if rank == 0 and world == 1 and traffic is not None and not args.no_live_traffic:
+        lt, lsrc = live_pmc_traffic()
+        if lt is not None:
+            out["roofline"]["traffic_committed_summary"] = {"bytes_per_launch": traffic, **(traffic_src or {})}
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = lt, lsrc
+            out["roofline"]["traffic_unit"] = "bytes per launch, L2 fabric side incl. Infinity-Cache hits (rocprofv3 PMC passes of this run)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

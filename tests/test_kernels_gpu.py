@@ -1094,6 +1094,14 @@ def _attention_case(dh, S, mask, Bn, H):
     check(f"attn_dq_{tag}", dqkv[:, :, :D], g[:, :, :D], 2e-2)
     check(f"attn_dk_{tag}", dqkv[:, :, D:2 * D], g[:, :, D:2 * D], 2e-2)
     check(f"attn_dv_{tag}", dqkv[:, :, 2 * D:], g[:, :, 2 * D:], 2e-2)
+    ws = ops.attn_bwd_fused_workspace(a)      # round 6: the one-pass backward on the same shape (dh = 128, S >= 64)
+    if ws is not None:
+        dqkv.zero_(); dsum.zero_()
+        ops.attn_call("qfx_attn_bwd_fused", a)
+        check(f"attn1_dq_{tag}", dqkv[:, :, :D], g[:, :, :D], 2e-2)
+        check(f"attn1_dk_{tag}", dqkv[:, :, D:2 * D], g[:, :, D:2 * D], 2e-2)
+        check(f"attn1_dv_{tag}", dqkv[:, :, 2 * D:], g[:, :, 2 * D:], 2e-2)
+        assert int(ws[1].abs().max()) == 0
 
 
 @pytest.mark.parametrize("seed", range(12))
