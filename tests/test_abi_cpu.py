@@ -51,6 +51,21 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.qfx_lora_head_reduce(C.byref(r), 1, None) == -1
     r.ld_ext, r.part_hstride = 48, 63 * 16                              # a head slab shorter than the rows read from it
     assert _lib.lib.qfx_lora_head_reduce(C.byref(r), 1, None) == -1
+    # ABI 7 (round 6): the attention policy entry parses completely before anything changes; the split-K lever's values go through the
+    # same all-or-nothing table as the tile names; the one-pass backward refuses what it cannot run, without a device
+    tune = _lib.lib.qfx_attn_tune
+    assert tune(b"fwd64=2") == -1 and tune(b"dq64=1p") == -1 and tune(b"fwd64=1,nope=3") == -1 and tune(b"fwd_waves=6") == -1
+    assert tune(b"fwd64=1p,dq64=0,fwd_waves=8") == 0 and tune(b"fwd64=auto,dq64=auto,fwd_waves=0") == 0 and tune(None) == 0 and tune(b"") == 0
+    assert t(b"splitk=2", None) == -1 and t(b"splitk_mink=100", None) == -1 and t(b"splitk_bias=3", b"1,1.09") == -1
+    assert t(b"splitk_bias=3", b"1,1.09,0.965") == 0 and t(b"splitk=0", None) == 0
+    ws = _lib.lib.qfx_lora_grad_ws_floats
+    assert ws(512, 3072, 16) == 0 and ws(2048, 3072, 16) == 4 * 24 * 2048 and ws(2432, 3072, 48) == 5 * 24 * 3 * 2048 and ws(2048, 3072, 17) == 0
+    a.B, a.S, a.S_pad, a.H, a.dh = 1, 2432, 2432, 24, 64
+    nb1, nb2 = C.c_int64(-1), C.c_int64(-1)
+    assert _lib.lib.qfx_attn_bwd_fused_workspace(C.byref(a), C.byref(nb1), C.byref(nb2)) == _lib.QFX_EUNSUPPORTED and (nb1.value, nb2.value) == (0, 0)
+    assert _lib.lib.qfx_attn_bwd_fused(C.byref(a), None) == _lib.QFX_EUNSUPPORTED
+    g2 = _lib.LoraGradArgs()
+    assert _lib.lib.qfx_lora_grad(C.byref(g2), None) == -1
 
 
 def test_map_mask_to_latent_host_helper_matches_reference_vectors():
