@@ -167,10 +167,10 @@ typedef struct qfx_lora_grad_args {
   int32_t rows_per_batch; int32_t x_batch_rows; int32_t x_row_off;
   float out_scale;                       /* lora_alpha/r for dB, 1 for dA */
   /* ABI 7 (optional; NULL = the round-1..5 behaviour: the partial sums of the token chunks meet in G by fp32 atomics, order-dependent
-   * in the last bit).  ws: fp32 scratch of qfx_lora_grad_ws_floats(M, K, R) elements, ws_count: int32[(K + 127) / 128], ZERO before the
+   * in the last bit).  ws: fp32 scratch of ws_floats >= qfx_lora_grad_ws_floats(M, K, R) elements, ws_count: int32[(K + 127) / 128], ZERO before the
    * first launch (every launch leaves it zero).  With both set the chunk partials go to ws and the LAST block to arrive at a 128-column
    * strip adds them up in chunk order and updates G with plain stores: same inputs -> same bits. */
-  float* ws; int32_t* ws_count;
+  float* ws; int32_t* ws_count; int64_t ws_floats;      /* ws_floats = elements allocated behind ws: launches that need more are refused (QFX_EINVAL) */
 } qfx_lora_grad_args;
 
 int qfx_lora_grad(const qfx_lora_grad_args* args, void* stream);

@@ -630,7 +630,7 @@ int check_grad(const qfx_lora_grad_args* a) {
   if (a->group_R <= 0 || (a->group_R % 16) || (a->R % a->group_R) || a->R / a->group_R > 3) return QFX_EINVAL;
   if (a->R / a->group_R > 1 && !a->G1) return QFX_EINVAL;
   if (a->R / a->group_R > 2 && !a->G2) return QFX_EINVAL;
-  if (a->ws && (!a->ws_count || ((uintptr_t)a->ws % 16) || ((uintptr_t)a->ws_count % 4))) return QFX_EINVAL;
+  if (a->ws && (!a->ws_count || ((uintptr_t)a->ws % 16) || ((uintptr_t)a->ws_count % 4) || a->ws_floats < qfx_lora_grad_ws_floats(a->M, a->K, a->R))) return QFX_EINVAL;
   return QFX_OK;
 }
 }  // namespace

@@ -60,7 +60,7 @@ class LoraGradArgs(C.Structure):
         ("G", C.c_void_p), ("G1", C.c_void_p), ("G2", C.c_void_p), ("g_sr", C.c_int64), ("g_sc", C.c_int64),
         ("rows_per_batch", C.c_int32), ("x_batch_rows", C.c_int32), ("x_row_off", C.c_int32),
         ("out_scale", C.c_float),
-        ("ws", C.c_void_p), ("ws_count", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_count", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

@@ -1240,7 +1240,7 @@ class _QwenPlan:
             nfl = int(lib.qfx_lora_grad_ws_floats(M, K, R))
             ws = torch.empty(max(nfl, 4), dtype=F32, device=X.device)
             cnt = torch.zeros((K + 127) // 128, dtype=torch.int32, device=X.device)
-            a.ws, a.ws_count = _ptr(ws), _ptr(cnt)
+            a.ws, a.ws_count, a.ws_floats = _ptr(ws), _ptr(cnt), ws.numel()
             prog.keep.append((ws, cnt))
         if defer is not None:
             defer.append(a)

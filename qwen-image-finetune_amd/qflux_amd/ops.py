@@ -109,7 +109,7 @@ def lora_grad(Vt, X, G, g_sr, g_sc, *, M, r_valid=None, group_R=None, K=None, ro
     if deterministic:      # ABI 7: chunk partials through scratch, summed in chunk order (False: the fp32 atomics of rounds 1-5)
         ws = torch.empty(max(int(lib.qfx_lora_grad_ws_floats(a.M, a.K, a.R)), 4), dtype=torch.float32, device=X.device)
         cnt = torch.zeros((a.K + 127) // 128, dtype=torch.int32, device=X.device)
-        a.ws, a.ws_count = _p(ws), _p(cnt)
+        a.ws, a.ws_count, a.ws_floats = _p(ws), _p(cnt), ws.numel()
     L.check(lib.qfx_lora_grad(C.byref(a), stream_ptr()), "qfx_lora_grad")
     if deterministic:
         assert int(cnt.abs().max()) == 0      # (synchronises: this helper is for tests)

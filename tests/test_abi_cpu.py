@@ -66,6 +66,10 @@ def test_argument_validation_without_gpu():
     assert _lib.lib.qfx_attn_bwd_fused(C.byref(a), None) == _lib.QFX_EUNSUPPORTED
     g2 = _lib.LoraGradArgs()
     assert _lib.lib.qfx_lora_grad(C.byref(g2), None) == -1
+    g2.Vt_hi, g2.Vt_lo, g2.ldvt, g2.R, g2.r_valid, g2.group_R = 0x1000, 0x2000, 2048, 16, 16, 16
+    g2.X, g2.ldx, g2.M, g2.K, g2.G, g2.g_sr, g2.g_sc, g2.rows_per_batch = 0x3000, 3072, 2048, 3072, 0x4000, 3072, 1, 2048
+    g2.ws, g2.ws_count, g2.ws_floats = 0x5000, 0x6000, 4 * 24 * 2048 - 1            # one float short of qfx_lora_grad_ws_floats(2048, 3072, 16)
+    assert _lib.lib.qfx_lora_grad(C.byref(g2), None) == -1
 
 
 def test_map_mask_to_latent_host_helper_matches_reference_vectors():
