@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 namespace {
 
@@ -30,6 +31,14 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
   __builtin_amdgcn_global_load_lds((const QFX_AS1 void*)g, (QFX_AS3 void*)lds, 16, 0, 0);
+}
+
+// LDS-DMA piece issued from an asm statement: invisible to hipcc's wait-count pass (with the builtin it guards EVERY later LDS read of
+// the wave with s_waitcnt vmcnt(0)); completion is tracked by hand-counted s_waitcnt vmcnt(N) (see the dGELU epilogue of gemm256_kernel)
+__device__ __forceinline__ void glds16_asm(const bf16_t* g, char* lds) {
+  const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(g), "s"(l) : "memory");
 }
 
 template <int EPI>
@@ -245,6 +254,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 #ifndef QFX_GEMM_PF_DIST
 #define QFX_GEMM_PF_DIST 0      // K tiles an L2 prefetch runs ahead of the K loop (0 = off), see the compute waves
 #endif
+#ifndef QFX_GEMM_AUX_DMA
+#define QFX_GEMM_AUX_DMA 1      // bit 0: d(GELU) epilogue, bit 1: gate + residual epilogue (measured SLOWER: profiles/r06_gemm_aux_landing.json) -- the aux rows of the next pass come in by LDS-DMA instead of a load inside the pass (0 = rounds 1-5)
+#endif
 #ifndef QFX_GEMM_KSTAGGER
 #define QFX_GEMM_KSTAGGER 0     // K tiles between the starting points of neighbouring tiles' K loops (0 = every tile starts at k = 0), see the loader waves
 #endif
@@ -277,6 +289,9 @@ template <int BMT, int TN> struct TileCfg {
   static constexpr int NGRP = NI / NG;
   static_assert(BMT % (WRN * 16) == 0 && TN % (WCN * 16) == 0 && NI % NG == 0, "tile / wave layout");
   static_assert(NST * STAGE + 8 * STG_BYTES <= 160 * 1024, "LDS budget");
+  // round 6: per compute wave, a landing buffer for the NEXT epilogue pass's aux rows (16 rows x 16 NG columns bf16), filled by LDS-DMA
+  static constexpr int AUXW = 512 * NG;
+  static constexpr bool AUX_FITS = NST * STAGE + 8 * STG_BYTES + 8 * AUXW <= 160 * 1024;
 };
 
 struct GroupedArgs {
@@ -358,7 +373,9 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
   constexpr int BKT = TC::BKT;     // K depth of a ring stage (64; 32 on the wide tile)
   static_assert(!(FP8 && BKT != 64), "the MX-FP8 operands need 64-element (128-byte) stage rows");
   constexpr int WCOLS = 16 * NI;   // columns per compute wave
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES];
+  // dGELU epilogue with its aux rows by LDS-DMA (round 6; see the epilogue)
+  constexpr bool AUXDMA = (QFX_GEMM_AUX_DMA != 0) && !FP8 && !SPLIT && TC::AUX_FITS && (EPI == QFX_EPI_DGELU || (EPI == QFX_EPI_GATE_RES && (QFX_GEMM_AUX_DMA & 2)));
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_BYTES + 8 * STG_BYTES + (AUXDMA ? 8 * TC::AUXW : 0)];
   KGroupedArgs& ga = *(KGroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // == ga_by_value (sole explicit argument)
 
   const int tid = threadIdx.x;
@@ -650,6 +667,39 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
 #else
     const bool wave_dead = m0 + wr * WROWS >= p.M;   // wave-uniform
 #endif
+    // ---- dGELU epilogue, aux rows by LDS-DMA (round 6).  The epilogue reads one aux row segment per lane and pass (16 per wave and
+    // 256 x 256 tile) -- first touches of a 60 MB tensor written a whole forward ago: HBM latency, 128 accumulators leave no registers to
+    // request them ahead (profiles/r04_gemm_aux_prefetch.json), the launch ran 180 us against 165 for the GELU epilogue that writes twice
+    // as much.  Now lane slot (j, lane) of pass p + 1 is requested one pass ahead by LDS-DMA into a landing buffer of the wave's own
+    // (slot-linear: every lane reads back what it asked for; no registers in flight), pass 0 before the K loop.  Completion by counted
+    // waits: the compute waves' only vector-memory operations are these requests and the epilogue's stores, ONE per lane slot, in a
+    // fixed order (asm statements with memory clobbers pin it) -- see the wait in the epilogue.  Taken where every store of the wave is
+    // issued (whole column range inside N, no row mask); everything else keeps the load inside the pass.
+    [[maybe_unused]] char* auxb = smem + NSTAGE * STAGE_BYTES + 8 * STG_BYTES + (AUXDMA ? w * TC::AUXW : 0);
+    bool use_dma = false;
+    // all rows of a wave on the landing-buffer side lie in ONE sample: the C / aux row of row m is m + a wave-uniform delta (no division
+    // per lane slot, nothing of the row map held in vector registers)
+    [[maybe_unused]] int row_delta = 0;
+    [[maybe_unused]] auto aux_issue = [&](int pass, int j, int lnx) {
+      constexpr int CHX = 2 * NG, SLOTSX = 16 * CHX;
+      const int slot = j * 64 + lnx;
+      if (SLOTSX < 128 && slot >= SLOTSX) return;              // (the 48-column groups: 32 live lanes in the second piece)
+      const int row = slot / CHX, ch = slot - row * CHX;
+      const int mi_ = pass / NGRP, gq_ = pass - mi_ * NGRP;
+      int m = m0 + wr * WROWS + mi_ * 16 + row; m = m < p.M ? m : p.M - 1;
+      const int n = n0 + wc * WCOLS + ch * 8 + gq_ * (16 * NG);
+      const int64_t arow = (int64_t)(m + (p.aux_unmapped ? 0 : row_delta));
+      glds16_asm(p.aux + arow * p.ldaux + n, auxb + j * 1024);
+    };
+    if constexpr (AUXDMA) {
+      const int r0 = m0 + wr * WROWS, r1 = (r0 + WROWS < p.M ? r0 + WROWS : p.M) - 1;
+      use_dma = !wave_dead && p.row_mask == nullptr && (p.M & 15) == 0 && n0 + wc * WCOLS + WCOLS <= p.N && r1 >= r0 &&
+                !(p.bias != nullptr && (nt2 == 0 || p.seg2_plain)) &&                           // (no bias left for the epilogue)
+                (p.c_batch_rows == 0 || r0 / p.rows_per_batch == r1 / p.rows_per_batch);        // wave-uniform
+      if (use_dma) row_delta = (int)(remap_row(r0, p.rows_per_batch, p.c_batch_rows, p.c_row_off) - r0);
+      if constexpr (EPI == QFX_EPI_GATE_RES) use_dma = use_dma && r0 / p.rows_per_batch == r1 / p.rows_per_batch;      // one gate vector
+      if (use_dma) { aux_issue(0, 0, l0); aux_issue(0, 1, l0); }
+    }
     if constexpr (FP8) {
       // ---- MX-FP8 base segment: per K tile (128 fp8 per row) the four B operands (chunks g and g+4 of their rows = the two halves
       // of one scaled-MFMA operand) stay resident, the A operands stream one fragment row ahead; scales (one dword = the 4 MX
@@ -935,28 +985,64 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
       soff_[j] = srow_[j] * 128 + ((sch_[j] ^ (srow_[j] >> 1)) << 4);
       ncol_[j] = n0 + wc * WCOLS + sch_[j] * 8;
     }
+    [[maybe_unused]] u32x4 gvp[NGC];
+    if constexpr (AUXDMA) {
+      if (use_dma) {
+        // (no pending bias on this side: its NI x 4 registers are free during the passes); gate vector(s) of the lane's columns: ONE sample per wave here
+        if constexpr (EPI == QFX_EPI_GATE_RES) {
+          static_assert(NGRP == 1, "one column group per pass");
+          const int bidx = (m0 + wr * WROWS) / p.rows_per_batch;
+#pragma unroll
+          for (int jc = 0; jc < NGC; ++jc) {
+            gvp[jc] = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + ncol_[jc]);
+            asm volatile("" : "+v"(gvp[jc]));      // (arrived before the first counted wait: hipcc puts its own wait here)
+          }
+        }
+      }
+    }
+    // The passes exist twice where the landing buffer is compiled in: DMA = true is straight-line code (every lane slot stores: whole
+    // 16-row groups inside M, whole column range inside N, no row mask), so the request/store order the counted waits rely on is the
+    // program order; DMA = false is the general form.  One wave-uniform branch picks -- a merge INSIDE a pass made hipcc carry the
+    // activation row through scratch and wait vmcnt(0) at the join, which drained the request just issued.
+    auto epi_passes = [&](auto dma_tag) {
+    constexpr bool DMA = decltype(dma_tag)::value;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      if constexpr (DMA) { if (m0 + wr * WROWS + mi * 16 >= p.M) return; }      // wave-uniform: no row of this or any later pass is stored
 #pragma unroll
       for (int gq = 0; gq < NGRP; ++gq) {
 #pragma unroll
         for (int nn = 0; nn < NG; ++nn) {
           const int ni = gq * NG + nn;
           u32x2 u;
-          u[0] = pack2bf(acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]);
-          u[1] = pack2bf(acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]);
+          if constexpr (DMA) {      // (no pending bias on this side: its NI x 4 registers are dead)
+            u[0] = pack2bf(acc[mi][ni][0], acc[mi][ni][1]);
+            u[1] = pack2bf(acc[mi][ni][2], acc[mi][ni][3]);
+          } else {
+            u[0] = pack2bf(acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1]);
+            u[1] = pack2bf(acc[mi][ni][2] + bv[ni][2], acc[mi][ni][3] + bv[ni][3]);
+          }
           *(u32x2*)(stg + lie * 128 + (((nn * 4 + ge) ^ ((lie >> 1) << 1)) << 3)) = u;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (SLOTS < 128 && j * 64 + ln >= SLOTS) continue;
-          const int row = srow_[j], ch = sch_[j];
-          const u32x4 yv = *(const u32x4*)(stg + soff_[j]);
+          int row = srow_[j], ch = sch_[j], soff = soff_[j], ncolj = ncol_[j], lnp = ln;
+          if constexpr (DMA) {
+            // re-derived per lane slot from a lane id hipcc cannot see through: otherwise the addresses of ALL passes are formed ahead
+            // (the passes are unrolled), spill, and every reload's own wait drains the request just issued
+            asm volatile("" : "+v"(lnp));
+            const int slot = j * 64 + lnp;
+            row = slot / CH; ch = slot - row * CH;
+            soff = row * 128 + ((ch ^ (row >> 1)) << 4);
+            ncolj = n0 + wc * WCOLS + ch * 8;
+          }
+          const u32x4 yv = *(const u32x4*)(stg + soff);
           const int m = m0 + wr * WROWS + mi * 16 + row;
-          const int n = ncol_[j] + gq * (16 * NG);
-          if (m >= p.M || n + 7 >= p.N) continue;
-          const int64_t crow = remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
-          if (p.row_mask != nullptr && p.row_mask[m] == 0.f) {
+          const int n = ncolj + gq * (16 * NG);
+          if constexpr (!DMA) { if (m >= p.M || n + 7 >= p.N) continue; }
+          const int64_t crow = DMA ? (int64_t)(m + row_delta) : remap_row(m, p.rows_per_batch, p.c_batch_rows, p.c_row_off);
+          if (!DMA && p.row_mask != nullptr && p.row_mask[m] == 0.f) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             *(u32x4*)(p.C + crow * p.ldc + n) = z;
             if constexpr (FP8 && EPI != QFX_EPI_GATE_RES) { if (cq) quant_store(z, crow, n, ch); }
@@ -978,9 +1064,30 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
             if (!cq_only) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
             if constexpr (FP8) { if (cq) quant_store(o2, crow, n, ch); }
           } else if constexpr (EPI == QFX_EPI_GATE_RES) {
-            const int bidx = m / p.rows_per_batch;
             float gl[8];
             const int jc = NGC == 1 ? 0 : j;
+            u32x4 rv;
+            if constexpr (DMA) {
+              // one sample per wave on this side: the gate vector of the lane's columns was fetched before the passes (packed: 4 registers)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { gl[2 * q] = __uint_as_float(gvp[jc][q] << 16); gl[2 * q + 1] = __uint_as_float(gvp[jc][q] & 0xffff0000u); }
+              // counted wait as in the d(GELU) branch below; with the second output (p.C2) every lane slot stores twice
+              const int pass = mi * NGRP + gq;
+              if (p.C2 == nullptr) {
+                if (pass == 0 && j == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (pass == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+              } else {
+                if (pass == 0 && j == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (pass == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+              }
+              rv = *(const u32x4*)(auxb + j * 1024 + lnp * 16);
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv) :: "memory");
+              constexpr int npass = MI * NGRP;
+              aux_issue(pass + 1 < npass ? pass + 1 : npass - 1, j, lnp);
+            } else {
+            const int bidx = m / p.rows_per_batch;
             if (!GATE_CACHE || bidx != last_b[jc]) {
               const u32x4 gv = *(const u32x4*)(p.gate + (int64_t)bidx * p.gate_bstride + n);
 #pragma unroll
@@ -996,7 +1103,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
             }
             // (aux rows are loaded where they are used: requesting them one to MI passes ahead was measured 1-2 % SLOWER on the whole
             // step -- the extra live registers spill, and other waves already cover the round trip: profiles/r04_gemm_aux_prefetch.json)
-            const u32x4 rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+            rv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+            }
             u32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1006,7 +1114,25 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
             *(u32x4*)(p.C + crow * p.ldc + n) = o;
             if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yv;   // pre-gate linear output (rows UNMAPPED), kept for d(gate)
           } else {  // QFX_EPI_DGELU
-            const u32x4 hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+            u32x4 hv;
+            if constexpr (DMA) {
+              {
+                // operations this wave issued AFTER the request being awaited (in issue order, one instruction each): pass 0, j = 0: the
+                // request of slot (0, 1); pass 0, j = 1: request (1, 0), store (0, 0); every later slot: the other slot's store of the
+                // previous pass, the other slot's request, one more store -- three.  VMEM retires in order: vmcnt(N) = "all but the N
+                // youngest are done".
+                const int pass = mi * NGRP + gq;      // (a constant once the pass loops are unrolled: the branches below fold)
+                if (pass == 0 && j == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else if (pass == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                hv = *(const u32x4*)(auxb + j * 1024 + lnp * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hv) :: "memory");      // the slot is read: it may be overwritten
+                constexpr int npass = MI * NGRP;
+                aux_issue(pass + 1 < npass ? pass + 1 : npass - 1, j, lnp);          // (the last pass re-requests itself: the count stays 3)
+              }
+            } else {
+              hv = *(const u32x4*)(p.aux + (p.aux_unmapped ? (int64_t)m : crow) * p.ldaux + n);
+            }
             u32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1018,6 +1144,13 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
           }
         }
       }
+    }
+    };
+    if constexpr (AUXDMA) {
+      if (use_dma) epi_passes(std::true_type{});
+      else epi_passes(std::false_type{});
+    } else {
+      epi_passes(std::false_type{});
     }
   }
   asm volatile("" :: "v"(pf_sink));

@@ -54,3 +54,22 @@ def test_gemm_epilogue_site_counts_do_not_grow(asm):
         sites = pk_mfma_scan.scan(asm[src])
         worst = max((len(v) for v in sites.values()), default=0)
         assert worst <= cap, (src, worst, cap)
+
+
+def test_gemm_landing_buffer_epilogue_has_only_counted_vector_memory_operations(asm):
+    """Round 6: the d(GELU) epilogue's landing-buffer side waits for its LDS-DMA requests by COUNT (s_waitcnt vmcnt(1 | 2 | 3): vector
+    memory retires in order).  That is only right while the side's vector-memory instructions are exactly one request (D) and one store
+    (S) per lane slot in that order -- a scratch reload or a plain load there shifts the count and its own compiler wait drains the
+    request just issued (seen three times while writing it).  Pin the instruction order of both instantiations that have the buffer:
+    MI 16-row passes x 2 lane slots of 'wait, request, store'."""
+    import gemm_epi_vmem_seq as g
+    text = open(asm["qfx_gemm.hip"]).read()
+    for key, mi in (("dgelu 256x256", 8), ("dgelu 160x192", 5)):
+        side = g.landing_side(g.seq(text, g.KERNELS[key]))
+        want = ["w1", "D", "S", "w2", "D", "S"] + ["w3", "D", "S"] * (2 * mi - 2)
+        # (the last slot's store may sit in another basic block -- hipcc lays the loop's exit path out elsewhere)
+        assert side[:len(want) - 1] == want[:-1], (key, " ".join(side[:len(want) + 6]))
+        assert side[len(want):len(want) + 1] != ["S"], (key, "a store beyond the last lane slot")
+    # the gate + residual epilogue has the buffer only in A/B builds (QFX_GEMM_AUX_DMA bit 1, measured slower)
+    for key in ("gate_res 256x256", "gate_res 160x192"):
+        assert g.landing_side(g.seq(text, g.KERNELS[key])) == [], key

@@ -363,6 +363,90 @@ def test_gemm_every_tile_geometry(geo):
         assert torch.equal(o, base[k][0]), f"{geo} {k}: differs from the 256x128 tile's result"
 
 
+@pytest.mark.parametrize("geo", [g for g in GEOMETRIES if g != "256x128"])
+def test_gemm_dgelu_landing_buffer(geo):
+    """Round 6: on the 256x256 and 160x192 tiles the d(GELU) and gate + residual epilogues take their aux rows (pre-activation / residual)
+    through a per-wave LDS landing buffer (requested one pass ahead by LDS-DMA, completion by counted waits) where every lane slot of the
+    wave stores: no bias left for the epilogue, no row mask, M a multiple of 16, the wave's whole column range inside N, one sample per wave.  Shapes on both sides of each condition (full tiles, a last tile that
+    ends on a 16-row group, M = 2005, a ragged last column group, a bias, a grouped image + text launch, a deep K so that requests of
+    the NEXT tile are issued while the loader waves stream) -- against the fp32 reference and bit-identical to the 256x128 tile, which
+    has no landing buffer."""
+    from qflux_amd import _lib as L
+    ops = _ops()
+    lib = L.lib
+    shapes = [(2432, 3072, 256, False), (2000, 3072, 192, False), (2005, 3072, 192, False), (2432, 3000, 128, False), (512, 768, 2048, False),
+              (2432, 3072, 128, True), (4864, 3072, 128, False), (16, 3072, 128, False)]
+
+    def run_all():
+        outs = {}
+        for M, N, K, with_bias in shapes:
+            a, b = randn(M, K, seed=1).to(BF), randn(N, K, seed=2, scale=0.2).to(BF)
+            hx = randn(M, N, seed=6).to(BF)
+            bias = randn(N, seed=9).to(BF) if with_bias else None
+            hh = hx.float().requires_grad_(True)
+            F.gelu(hh, approximate="tanh").sum().backward()
+            ref = rb(rb(a.float() @ b.float().t() + (bias.float() if with_bias else 0.0)) * hh.grad)
+            out = ops.gemm(a.to(DEV), b.to(DEV), epi=3, aux=hx.to(DEV), bias=bias.to(DEV) if with_bias else None)
+            outs[(M, N, K, with_bias)] = (out.cpu(), ref)
+        gs, keep = [], []
+        N, K = 3072, 192
+        for i, Mi in enumerate((2048, 384)):
+            a, b, hx = randn(Mi, K, seed=10 + i).to(BF), randn(N, K, seed=20 + i, scale=0.2).to(BF), randn(Mi, N, seed=80 + i).to(BF)
+            hh = hx.float().requires_grad_(True)
+            F.gelu(hh, approximate="tanh").sum().backward()
+            t = [x.to(DEV) for x in (a, b, hx)]
+            out = torch.zeros(Mi, N, dtype=BF, device=DEV)
+            g = L.GemmArgs()
+            g.A1, g.B1, g.lda1, g.ldb1, g.K1 = t[0].data_ptr(), t[1].data_ptr(), K, K, K
+            g.M, g.N, g.C, g.ldc, g.rows_per_batch, g.epi, g.aux, g.ldaux = Mi, N, out.data_ptr(), N, Mi, 3, t[2].data_ptr(), N
+            gs.append(g); keep.append((t, out, rb(rb(a.float() @ b.float().t()) * hh.grad)))
+        L.check(lib.qfx_gemm_grouped((L.GemmArgs * 2)(*gs), 2, ops.stream_ptr()), "qfx_gemm_grouped")
+        for i in range(2):
+            outs[f"grouped_{i}"] = (keep[i][1].cpu(), keep[i][2])
+        # gate + residual (the landing-buffer side additionally needs ONE sample per wave and no bias left for the epilogue): two samples
+        # of 1216 rows (the 256-row tile 1024..1279 crosses the boundary: its lower waves fall back) and of 1280, the C row map into a
+        # joint buffer (aux indexed like C: a row delta), with and without the second output, a LoRA K segment with the bias rounded
+        # in before it (landing side) and a plain bias (general side)
+        for Bn, rpb, K, K2, with_c2, with_bias in ((2, 1216, 128, 0, True, False), (2, 1280, 192, 64, True, True), (1, 2432, 128, 0, False, False),
+                                                   (2, 1216, 128, 0, False, True), (1, 2048, 3072, 64, True, True)):
+            M, T, N = Bn * rpb, 24, 3072
+            S = T + rpb
+            a, b = randn(M, K, seed=1).to(BF), randn(N, K, seed=2, scale=0.2).to(BF)
+            gate, res = randn(Bn, N, seed=7).to(BF), randn(M, N, seed=8).to(BF)
+            bias = randn(N, seed=9).to(BF) if with_bias else None
+            y = rb(a.float() @ b.float().t() + (bias.float() if with_bias else 0.0))
+            kw = {}
+            if K2:
+                a2, b2 = randn(M, K2, seed=3).to(BF), randn(N, K2, seed=4, scale=0.1).to(BF)
+                y = rb(y + a2.float() @ b2.float().t())
+                kw = dict(a2=a2.to(DEV), b2=b2.to(DEV))
+            refg = rb(res.float() + rb(gate.float().repeat_interleave(rpb, 0) * y))
+            cj = torch.zeros(Bn * S, N, dtype=BF, device=DEV)
+            resj = torch.zeros(Bn, S, N, dtype=BF)
+            resj[:, T:] = res.view(Bn, rpb, N)
+            c2 = torch.zeros(M, N, dtype=BF, device=DEV) if with_c2 else None
+            ops.gemm(a.to(DEV), b.to(DEV), out=cj, epi=2, aux=resj.view(Bn * S, N).to(DEV), gate=gate.to(DEV), rows_per_batch=rpb, c_map=(S, T),
+                     out2=c2, bias=bias.to(DEV) if with_bias else None, **kw)
+            key = f"gate_res_{Bn}x{rpb}_k{K}+{K2}_c2{int(with_c2)}_b{int(with_bias)}"
+            outs[key] = (cj.view(Bn, S, N)[:, T:].reshape(M, N).cpu(), refg)
+            assert cj.view(Bn, S, N)[:, :T].abs().max().item() == 0.0
+            if with_c2:
+                outs[key + "_pre"] = (c2.cpu(), y)
+        return outs
+
+    try:
+        assert lib.qfx_gemm_tune(b"256x128", None) == 0
+        base = run_all()
+        assert lib.qfx_gemm_tune(geo.encode(), None) == 0
+        got = [run_all() for _ in range(2)]
+    finally:
+        assert lib.qfx_gemm_tune(b"all", None) == 0
+    for k, (o, ref) in got[0].items():
+        check(f"gemm_dgelu_landing_{geo}_{k}", o, ref, 1.5e-2)
+        assert torch.equal(o, base[k][0]), f"{geo} {k}: differs from the 256x128 tile's result"
+        assert torch.equal(o, got[1][k][0]), f"{geo} {k}: two launches differ"
+
+
 # ------------------------------------------------------------------------------------------ LoRA pieces
 def _split(x):
     hi = x.to(BF)
