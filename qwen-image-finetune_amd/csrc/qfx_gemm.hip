@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const qfx_gemm_args p) {
 #ifndef QFX_GEMM_AUX_DMA
 #define QFX_GEMM_AUX_DMA 1      // bit 0: d(GELU) epilogue, bit 1: gate + residual epilogue (measured SLOWER: profiles/r06_gemm_aux_landing.json) -- the aux rows of the next pass come in by LDS-DMA instead of a load inside the pass (0 = rounds 1-5)
 #endif
+#ifndef QFX_GEMM_NT_SAVED
+#define QFX_GEMM_NT_SAVED 0     // non-temporal stores for outputs that are only read in the backward: bit 0 the GELU epilogue's pre-activation, bit 1 the gate epilogue's pre-gate output
+#endif
 #ifndef QFX_GEMM_KSTAGGER
 #define QFX_GEMM_KSTAGGER 0     // K tiles between the starting points of neighbouring tiles' K loops (0 = every tile starts at k = 0), see the loader waves
 #endif
@@ -1060,7 +1063,8 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
             u32x4 o2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) o2[q] = pack2bf(gelu_tanh_f(y[2 * q]), gelu_tanh_f(y[2 * q + 1]));
-            *(u32x4*)(p.C + crow * p.ldc + n) = yv;
+            if constexpr ((QFX_GEMM_NT_SAVED & 1) != 0) __builtin_nontemporal_store(yv, (u32x4*)(p.C + crow * p.ldc + n));      // h is next read a whole forward later
+            else *(u32x4*)(p.C + crow * p.ldc + n) = yv;
             if (!cq_only) *(u32x4*)(p.C2 + crow * p.ldc2 + n) = o2;
             if constexpr (FP8) { if (cq) quant_store(o2, crow, n, ch); }
           } else if constexpr (EPI == QFX_EPI_GATE_RES) {
@@ -1112,7 +1116,10 @@ __global__ __launch_bounds__(WS_THREADS, 1) void gemm256_kernel(const GroupedArg
               o[q] = pack2bf(r0 + rbf(gl[2 * q] * y[2 * q]), r1 + rbf(gl[2 * q + 1] * y[2 * q + 1]));
             }
             *(u32x4*)(p.C + crow * p.ldc + n) = o;
-            if (p.C2) *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yv;   // pre-gate linear output (rows UNMAPPED), kept for d(gate)
+            if (p.C2) {      // pre-gate linear output (rows UNMAPPED), kept for d(gate)
+              if constexpr ((QFX_GEMM_NT_SAVED & 2) != 0) __builtin_nontemporal_store(yv, (u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n));
+              else *(u32x4*)(p.C2 + (int64_t)m * p.ldc2 + n) = yv;
+            }
           } else {  // QFX_EPI_DGELU
             u32x4 hv;
             if constexpr (DMA) {

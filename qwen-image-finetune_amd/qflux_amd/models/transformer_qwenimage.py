@@ -135,6 +135,10 @@ class _Prog:
         """C call issued on the program's side stream (leaf work that overlaps the main stream; joined by explicit events)."""
         self.calls.append((fn, args, True))
 
+    def c_on(self, stream, fn, *args):
+        """C call issued on `stream` (a torch.cuda.Stream kept alive by the caller; forked / joined by explicit events)."""
+        self.calls.append((fn, args, stream))
+
     def py(self, fn):
         self.calls.append((None, fn))
 
@@ -150,7 +154,7 @@ class _Prog:
             if fn is None:
                 args()
             else:
-                rc = fn(*args, self.side.cuda_stream if len(ent) > 2 else st)
+                rc = fn(*args, st if len(ent) < 3 else (self.side if ent[2] is True else ent[2]).cuda_stream)
                 if rc != 0:
                     raise L.QfxError(f"{fn.__name__} failed with code {rc}")
 

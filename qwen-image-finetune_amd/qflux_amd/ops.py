@@ -4,6 +4,7 @@ These are what the per-kernel parity tests call; the model builds cached argumen
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -248,6 +249,33 @@ def emit_attn_backward(p, a, A):
             a.dq_acc, a.dq_turn = ws[0].data_ptr(), ws[1].data_ptr()
             p.c(lib.qfx_attn_bwd_fused, C.byref(a))
             return "1pass"
+    if os.environ.get("QFX_ATTN_BWD_CONC", "0") == "1":
+        # Round 6 lever (default OFF): the two kernels are independent once dsum = rowsum(dO * O) exists (the dQ kernel normally publishes
+        # it for dK / dV), and neither fills whole rounds of the 256 CUs at S = 2432 (456 blocks of 2 rounds, 912 of 4): dsum by the
+        # standalone pass, dQ on a second stream with its own copy of the statistics buffer, dK / dV on the main stream, join.
+        import ctypes
+        st2 = side_stream(torch.device("cuda", torch.cuda.current_device()), 0, slot=1)
+        a2 = type(a)()
+        ctypes.memmove(ctypes.byref(a2), ctypes.byref(a), ctypes.sizeof(a))
+        if "dsum_conc" not in A:
+            A["dsum_conc"] = torch.empty(a.B * a.H * a.S_pad + 1024, dtype=torch.float32, device=st2.device)
+        a2.dsum = A["dsum_conc"].data_ptr()
+        ev_f, ev_j = torch.cuda.Event(), torch.cuda.Event()
+        p.keep += [a2, ev_f, ev_j, st2]
+        p.c(lib.qfx_attn_bwd_prep, C.byref(a))
+
+        def fork(ev=ev_f, s=st2):
+            ev.record(torch.cuda.current_stream())
+            s.wait_event(ev)
+
+        def join(ev=ev_j, s=st2):
+            ev.record(s)
+            torch.cuda.current_stream().wait_event(ev)
+        p.py(fork)
+        p.c_on(st2, lib.qfx_attn_bwd_dq, C.byref(a2))
+        p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
+        p.py(join)
+        return "2pass-concurrent"
     p.c(lib.qfx_attn_bwd_dq, C.byref(a))
     p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
     return "2pass"
@@ -312,10 +340,10 @@ def sumsq_det(g, out, partials):
 _side_streams = {}
 
 
-def side_stream(device, n_cus=16):
+def side_stream(device, n_cus=16, slot=0):
     """Process-wide CU-masked side stream of `device` (qfx_stream_create_cu_masked) as a torch stream object; n_cus = 0 or a driver
-    that refuses the mask -> an ordinary lowest-priority stream."""
-    key = (torch.device(device).index or 0, int(n_cus))
+    that refuses the mask -> an ordinary lowest-priority stream.  slot > 0: further streams, at the main stream's priority (peer work)."""
+    key = (torch.device(device).index or 0, int(n_cus), int(slot))
     if key not in _side_streams:
         st = None
         if n_cus > 0:
@@ -325,7 +353,7 @@ def side_stream(device, n_cus=16):
             if rc == 0 and out.value:
                 st = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", key[0]))
         if st is None:
-            st = torch.cuda.Stream(device=torch.device("cuda", key[0]), priority=1)
+            st = torch.cuda.Stream(device=torch.device("cuda", key[0]), priority=1 if slot == 0 else 0)
         _side_streams[key] = st
     return _side_streams[key]
 
