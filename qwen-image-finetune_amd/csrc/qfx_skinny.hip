@@ -3,6 +3,9 @@
 #include "qfx_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#ifndef QFX_GRAD_HANDOFF
+#define QFX_GRAD_HANDOFF 8      // 8 = chunk partials added by a second launch (product); 0 = by the last block of the strip, with fences: see lora_grad_kernel
+#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -339,6 +342,28 @@ constexpr int GX_ROWB = 288;  // padded LDS row stride (bytes) of the [32 tokens
 #endif
 constexpr int GRAD_CH = QFX_GRAD_CH;   // tokens per block: 4x fewer device-scope fp32 atomics per output element than 128 (the atomics
                                // of the M/CH partial sums, not the 15 MB stream, bounded the 128-token version)
+// G[j, k] += scale * D[j, k] for the 16 NF x 128 tile a block holds in MFMA layout (D[i = rank 4g+r][j = col li] per 16 x 16 fragment)
+template <int NF>
+__device__ __forceinline__ void grad_update(const QFX_AS4 qfx_lora_grad_args& p, const f32x4 (&acc)[NF][2], int k0, int w, int g, int li, bool plain) {
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = nf * 16 + 4 * g + r;
+      const int grp = j / p.group_R, jj = j % p.group_R;
+      if (jj >= p.r_valid) continue;
+      float* G = grp == 0 ? p.G : (grp == 1 ? p.G1 : p.G2);
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) {
+        const int k = k0 + w * 32 + cf * 16 + li;
+        if (k >= p.K) continue;
+        float* gp = G + (int64_t)jj * p.g_sr + (int64_t)k * p.g_sc;
+        if (plain) *gp += acc[nf][cf][r] * p.out_scale;
+        else unsafeAtomicAdd(gp, acc[nf][cf][r] * p.out_scale);
+      }
+    }
+}
+
 template <int NF>
 __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by_value) {
   constexpr int CH = GRAD_CH;
@@ -431,9 +456,13 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
   // D[i = rank 4g+r][j = col li]
   const int nchunk = (p.M + CH - 1) / CH;
   if (p.ws != nullptr && nchunk > 1) {
-    // ---- deterministic form (ABI 7): partial tile -> scratch; the LAST block of this 128-column strip adds the chunks in chunk order.
-    // Hand-off as cdna_hip_programming.md section 5 (split-K reducer): plain slab stores, every wave drains them, ONE agent-scope release
-    // by lane 0, relaxed ticket; the last arriver acquires once and reads plain.
+    // ---- deterministic form (ABI 7): partial tile -> per-problem scratch, added in CHUNK ORDER (the sum does not depend on who
+    // finished when).  QFX_GRAD_HANDOFF = 8 (product): by a second launch, lora_grad_reduce_kernel -- the kernel boundary is the
+    // hand-off, this block is done.  = 0 (round 6, first version): by the LAST block of the 128-column strip in this launch (plain slab
+    // stores, every wave drains them, ONE agent-scope release by lane 0, relaxed ticket, the last arriver acquires once and reads plain
+    // -- cdna_hip_programming.md section 5): correct, but every block's release is a buffer_wbl2 of the XCD's WHOLE L2 next to the main
+    // stream's GEMMs: +1.4 ms per step (profiles/r06_grad_handoff.json; fence-free forms with sc0 sc1 stores, also with a read-back
+    // before the ticket, hand over stale slabs under the 60-block step: the same file).
     const int chunk = (int)blockIdx.y - kb.start[pi];
     const int nstrip = (p.K + 127) / 128;      // the scratch is sized per problem (qfx_lora_grad_ws_floats), not per launch grid
     float* slab = p.ws + ((int64_t)chunk * nstrip + blockIdx.x) * (NF * 2048) + tid * 4;
@@ -441,6 +470,7 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf) *(f32x4*)(slab + (nf * 2 + cf) * 1024) = acc[nf][cf];
+    if constexpr ((QFX_GRAD_HANDOFF & 8) != 0) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = (int*)&sX[0][0];
@@ -461,7 +491,7 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf) acc[nf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunk; ++c) {      // chunk order: the sum does not depend on who arrived when
+    for (int c = 0; c < nchunk; ++c) {
       const float* src = p.ws + ((int64_t)c * nstrip + blockIdx.x) * (NF * 2048) + tid * 4;
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf)
@@ -469,24 +499,35 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
         for (int cf = 0; cf < 2; ++cf) acc[nf][cf] += *(const f32x4*)(src + (nf * 2 + cf) * 1024);
     }
   }
-  const bool plain = p.ws != nullptr;      // one writer per element and launch: no atomic needed (a single chunk included)
+  grad_update<NF>(p, acc, k0, w, g, li, p.ws != nullptr);      // (scratch given: one writer per element and launch, no atomic needed -- a single chunk included)
+}
+
+// Second launch of the deterministic form (QFX_GRAD_HANDOFF = 8): block (strip, problem) adds the token-chunk partials of the first
+// launch in chunk order and updates G.  Same thread -> element map as lora_grad_kernel; the kernel boundary is the hand-off.
+template <int NF>
+__global__ __launch_bounds__(256) void lora_grad_reduce_kernel(const GradBatch batch_by_value) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const QFX_AS4 GradBatch& kb = *(const QFX_AS4 GradBatch*)__builtin_amdgcn_kernarg_segment_ptr();
+  const QFX_AS4 qfx_lora_grad_args& p = kb.a[blockIdx.y];
+  const int k0 = blockIdx.x * 128;
+  const int nchunk = (p.M + GRAD_CH - 1) / GRAD_CH;
+  if (k0 >= p.K || p.ws == nullptr || nchunk < 2) return;
+  const int nstrip = (p.K + 127) / 128;
+  f32x4 acc[NF][2];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = nf * 16 + 4 * g + r;
-      const int grp = j / p.group_R, jj = j % p.group_R;
-      if (jj >= p.r_valid) continue;
-      float* G = grp == 0 ? p.G : (grp == 1 ? p.G1 : p.G2);
+    for (int cf = 0; cf < 2; ++cf) acc[nf][cf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nchunk; ++c) {      // chunk order: the sum does not depend on who finished when
+    const float* src = p.ws + ((int64_t)c * nstrip + blockIdx.x) * (NF * 2048) + tid * 4;
 #pragma unroll
-      for (int cf = 0; cf < 2; ++cf) {
-        const int k = k0 + w * 32 + cf * 16 + li;
-        if (k >= p.K) continue;
-        float* gp = G + (int64_t)jj * p.g_sr + (int64_t)k * p.g_sc;
-        if (plain) *gp += acc[nf][cf][r] * p.out_scale;
-        else unsafeAtomicAdd(gp, acc[nf][cf][r] * p.out_scale);
-      }
-    }
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) acc[nf][cf] += *(const f32x4*)(src + (nf * 2 + cf) * 1024);
+  }
+  grad_update<NF>(p, acc, k0, w, g, li, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -769,6 +810,21 @@ extern "C" int qfx_lora_grad_batch(const qfx_lora_grad_args* list, int32_t n, vo
     default: return QFX_EUNSUPPORTED;
   }
   QFX_CHECK_LAUNCH();
+#if (QFX_GRAD_HANDOFF & 8) != 0
+  bool any = false;
+  for (int i = 0; i < n; ++i) any = any || (list[i].ws && list[i].M > GRAD_CH);
+  if (any) {
+    dim3 rgrid((kmax + 127) / 128, n);
+    switch (list[0].R / 16) {
+      case 1: hipLaunchKernelGGL(lora_grad_reduce_kernel<1>, rgrid, dim3(256), 0, s, b); break;
+      case 2: hipLaunchKernelGGL(lora_grad_reduce_kernel<2>, rgrid, dim3(256), 0, s, b); break;
+      case 3: hipLaunchKernelGGL(lora_grad_reduce_kernel<3>, rgrid, dim3(256), 0, s, b); break;
+      case 4: hipLaunchKernelGGL(lora_grad_reduce_kernel<4>, rgrid, dim3(256), 0, s, b); break;
+      default: hipLaunchKernelGGL(lora_grad_reduce_kernel<6>, rgrid, dim3(256), 0, s, b); break;
+    }
+    QFX_CHECK_LAUNCH();
+  }
+#endif
   return QFX_OK;
 }
 
