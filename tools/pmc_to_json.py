@@ -29,7 +29,7 @@ import re
 import sys
 
 KERNELS = ("gemm256_kernel", "gemm_kernel", "ln_mod_fwd_kernel", "ln_mod_bwd_kernel", "ln_down_kernel", "mod_grad_kernel", "gemm_fp8_kernel", "quant_mxfp8_kernel", "lora_down_kernel",
-           "lora_grad_kernel", "lora_head_reduce_kernel", "attn_fwd_kernel", "attn_fwd64_kernel", "attn_fwd64p_kernel", "attn_bwd_dq_kernel", "attn_bwd_dq64_kernel", "attn_bwd_dkv_kernel", "attn_bwd1_kernel", "attn_dq_finish_kernel", "attn_prep_kernel", "attn_bwd_kernel", "qk_norm_rope_kernel",
+           "lora_grad_kernel", "lora_grad_reduce_kernel", "lora_head_reduce_kernel", "attn_fwd_kernel", "attn_fwd64_kernel", "attn_fwd64p_kernel", "attn_bwd_dq_kernel", "attn_bwd_dq64_kernel", "attn_bwd_dkv_kernel", "attn_bwd1_kernel", "attn_dq_finish_kernel", "attn_prep_kernel", "attn_bwd_kernel", "qk_norm_rope_kernel",
            "mod_gemv_kernel")
 
 

@@ -8,8 +8,8 @@ R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch2 --no-fp8 --no-dropin --no-hostfed --sustained-steps 0"
-CMD2="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch2 --no-fp8 --no-dropin --no-hostfed --sustained-steps 0"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch2 --no-fp8 --no-dropin --no-hostfed --sustained-steps 0 --no-live-traffic"
+CMD2="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch2 --no-fp8 --no-dropin --no-hostfed --sustained-steps 0 --no-live-traffic"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o p -- $CMD2 > $OUT/pmc_$C.log 2>&1
