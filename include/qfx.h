@@ -168,8 +168,10 @@ typedef struct qfx_lora_grad_args {
   float out_scale;                       /* lora_alpha/r for dB, 1 for dA */
   /* ABI 7 (optional; NULL = the round-1..5 behaviour: the partial sums of the token chunks meet in G by fp32 atomics, order-dependent
    * in the last bit).  ws: fp32 scratch of ws_floats >= qfx_lora_grad_ws_floats(M, K, R) elements, ws_count: int32[(K + 127) / 128], ZERO before the
-   * first launch (every launch leaves it zero).  With both set the chunk partials go to ws and the LAST block to arrive at a 128-column
-   * strip adds them up in chunk order and updates G with plain stores: same inputs -> same bits. */
+   * first launch (every launch leaves it zero).  With both set the chunk partials go to ws and are added up in CHUNK ORDER before G is
+   * updated with plain stores: same inputs -> same bits.  The library does that in a second launch on the same stream (the kernel
+   * boundary is the hand-off; ws_count is then not touched); a build with -DQFX_GRAD_HANDOFF=0 lets the last block to arrive at a
+   * 128-column strip do it inside the one launch (tickets in ws_count) -- slower: profiles/r06_grad_handoff.json. */
   float* ws; int32_t* ws_count; int64_t ws_floats;      /* ws_floats = elements allocated behind ws: launches that need more are refused (QFX_EINVAL) */
 } qfx_lora_grad_args;
 
