@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--side", type=int, default=32, help="latent side of the target (and control) image: 32 = 512^2 (S_i = 2048), 64 = 1024^2 (cfg #4 shape)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     from qflux_amd.models import QwenImageTransformer2DModel
@@ -42,7 +43,7 @@ def main():
                 p.normal_(0.0, 0.02)
     dit.add_adapter(LoraConfig(r=16, lora_alpha=16, init_lora_weights="gaussian"), "default", generator=torch.Generator().manual_seed(1))
     step = QwenLoraTrainStep(dit, lr=1e-4)
-    B, side, T = args.batch, 32, 384
+    B, side, T = args.batch, args.side, 384
     emb = dict(image_latents=torch.randn(B, side * side, 64).half().to(dev), control_latents=torch.randn(B, side * side, 64).half().to(dev),
                prompt_embeds=(torch.randn(B, T, 3584) * 4).half().to(dev), prompt_embeds_mask=None, img_shapes=[[(1, side, side)] * 2] * B)
     names = args.variants.split(",")
@@ -85,7 +86,7 @@ def main():
             ms = timed()
             if r:
                 res[n].append(ms)
-    out = {"unit": "ms per step", "steps": args.steps, "batch": B, "variants": {}}
+    out = {"unit": "ms per step", "steps": args.steps, "batch": B, "side": side, "variants": {}}
     base = sorted(res[names[0]])[len(res[names[0]]) // 2]
     for n in names:
         med = sorted(res[n])[len(res[n]) // 2]
