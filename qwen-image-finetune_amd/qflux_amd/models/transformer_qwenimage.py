@@ -679,6 +679,7 @@ class _QwenPlan:
 
     side_grads = False        # see _init_side_grads (plans that do not call it keep every launch on the main stream)
     _side_q = ()
+    _ncopy = 2                # copies of the side launches' scratch operands (see _init_side_grads)
 
     def __init__(self, model, B: int, S_i: int, T: int, shapes, multires: bool = False):
         self._setup(model, B, S_i, T)
@@ -752,23 +753,27 @@ class _QwenPlan:
         self.side_grads = bool(allowed and self.has_lora and os.environ.get("QFX_SIDE_GRADS", "1") != "0"
                                and (not ff or os.environ.get("QFX_SIDE_GRADS_FF", "1") != "0"))
         self._side_q = []              # (event, prefix) of the blocks whose gradient launches are in flight on the side stream
+        # QFX_SIDE_COPIES=3 (round-6 lever): three copies of the side launches' scratch operands instead of two, so that the join with the
+        # launch of block i+2 can sit right in front of the fork of block i (two adjacent barrier packets instead of two separate bubbles)
+        self._ncopy = 3 if (self.side_grads and os.environ.get("QFX_SIDE_COPIES", "2") == "3") else 2
         if self.side_grads:
             dev = self.model.device
             from .. import ops
             # QFX_SIDE_CUS=16 confines the side stream to two CUs per XCD (qfx_stream_create_cu_masked).  Measured: the mask works
             # (tools/cu_mask_probe.py) but the whole step slows from 99.7 to 127.9 ms with such a queue alive -> default: no mask
             self.bwd.side = ops.side_stream(dev, int(os.environ.get("QFX_SIDE_CUS", "0")))
-            self._ev_fork = torch.cuda.Event()
+            self._ev_fork = ops.Event()
             # the scratch operands of those launches (dyg1, dqkv, v^T) alternate between two copies by block parity, so a launch
             # has a whole block of main-stream work to hide under (on the 16 idle CUs it runs ~5x longer than alone)
             A = self.A
             for name in ("dyg1", "dqkv", "Vt", "VtO") + (("dh", "VtF1", "VtF2") if ff else ()):
                 src = A[name]
-                if isinstance(src, dict):
-                    A[name + "#1"] = {s: (tuple(torch.zeros_like(t) for t in v) if isinstance(v, tuple) else torch.zeros_like(v))
-                                      for s, v in src.items()}
-                else:
-                    A[name + "#1"] = torch.zeros_like(src)
+                for c in range(1, self._ncopy):
+                    if isinstance(src, dict):
+                        A[name + f"#{c}"] = {s: (tuple(torch.zeros_like(t) for t in v) if isinstance(v, tuple) else torch.zeros_like(v))
+                                             for s, v in src.items()}
+                    else:
+                        A[name + f"#{c}"] = torch.zeros_like(src)
 
     def _fuse_qk_bwd(self, a, sqk, norms, norm_flags, eps):
         """Backward of the QK RMSNorm + RoPE in the epilogues of qfx_attn_bwd_dq / _dkv (one pass over dqkv and a launch less per
@@ -842,18 +847,18 @@ class _QwenPlan:
 
     def _sb(self, name, par):
         """Scratch buffer `name` of block parity `par` (second copies exist only with side-stream gradient launches)."""
-        return self.A[name + "#1"] if (par and self.side_grads) else self.A.get(name)   # v^T scratch exists only with adapters
+        return self.A[name + f"#{par}"] if (par and self.side_grads) else self.A.get(name)   # v^T scratch exists only with adapters
 
     def _side_fork(self):
         self._ev_fork.record(torch.cuda.current_stream())
-        self.bwd.side.wait_event(self._ev_fork)
+        self._ev_fork.wait(self.bwd.side)
 
     def _side_join(self, p, keep=0):
         """Emit the joins with the oldest in-flight side-stream gradient launches until at most `keep` stay in flight, each
         followed by the mark that its block's gradients are final."""
         while len(self._side_q) > keep:
             ev, prefix = self._side_q.pop(0)
-            p.py(lambda ev=ev: torch.cuda.current_stream().wait_event(ev))
+            p.py(lambda ev=ev: ev.wait(torch.cuda.current_stream()))
             if prefix is not None:
                 p.mark(prefix)
 
@@ -1345,19 +1350,19 @@ class _QwenPlan:
                     (p.c_side if on_side else p.c)(lib.qfx_mod_gemv, _ptr(A["temb"]), B, D, _ptr(P["mod_W"]) + 8 * i0, _ptr(P["mod_b"]) + 8 * i0,
                                                    i1 - i0, 6 * D, 1, A["mods"][i0].data_ptr())
                 gemv(0, 2, False)
-                ev_fork = torch.cuda.Event()
+                ev_fork = ops.Event()
                 p.keep.append(ev_fork)
 
                 def fork(ev=ev_fork, side=side):
                     ev.record(torch.cuda.current_stream())
-                    side.wait_event(ev)
+                    ev.wait(side)
                 p.py(fork)
                 for b0, b1 in ((1, 3), (3, 9), (9, Lyr)):
                     if b0 >= Lyr:
                         break
                     b1 = min(b1, Lyr)
                     gemv(2 * b0, 2 * b1, True)
-                    ev = torch.cuda.Event()
+                    ev = ops.Event()
                     p.keep.append(ev)
                     p.py(lambda ev=ev, side=side: ev.record(side))
                     mod_joins[b0] = ev
@@ -1374,10 +1379,10 @@ class _QwenPlan:
         self.attn_args = []
         for i in range(Lyr):
             if not self.cond and i in mod_joins:      # this block's modulation rows come from the side stream
-                p.py(lambda ev=mod_joins[i]: torch.cuda.current_stream().wait_event(ev))
+                p.py(lambda ev=mod_joins[i]: ev.wait(torch.cuda.current_stream()))
             mods = {"img": A["mods"][2 * i], "txt": A["mods"][2 * i + 1]}   # [B, 6D]: shift1 scale1 gate1 shift2 scale2 gate2
             self._emit_double_fwd(p, P["blocks"][i], A["blk"][i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
-                                  {s: (A["X"][s][i + 1], (0, 0)) for s in ("img", "txt")}, last=(i == Lyr - 1), norm_flags=0, par=i & 1)
+                                  {s: (A["X"][s][i + 1], (0, 0)) for s in ("img", "txt")}, last=(i == Lyr - 1), norm_flags=0, par=i % self._ncopy)
         mo = A["mod_out"][0]  # [B, 2D]: scale | shift  (AdaLayerNormContinuous chunk order)
         p.c(lib.qfx_ln_modulate_fwd, _ptr(A["X"]["img"][Lyr]), _ptr(mo[:, D:2 * D]), _ptr(mo[:, 0:D]), 2 * D, _ptr(A["xn_out"]),
             rows["img"], D, rpb["img"], eps)
@@ -1566,7 +1571,7 @@ class _QwenPlan:
             self._emit_double_bwd(p, P["blocks"][i], A["blk"][i], self.attn_args[i], mods, {s: A["X"][s][i] for s in ("img", "txt")},
                                   dx2={s: A["dX"][s][cur] for s in ("img", "txt")}, out_dx={s: A["dX"][s][nxt] for s in ("img", "txt")},
                                   gate_prev=gate_prev, last=(i == Lyr - 1), first=(i == 0 and not self.full_bwd), norm_flags=0,
-                                  prefix=f"transformer_blocks.{i}.", par=i & 1,
+                                  prefix=f"transformer_blocks.{i}.", par=i % self._ncopy,
                                   dmods=({"img": A["dmods"][2 * i], "txt": A["dmods"][2 * i + 1]} if self.cond else None))
             if not self.side_grads:
                 p.mark(f"transformer_blocks.{i}.")
@@ -1591,7 +1596,7 @@ class _QwenPlan:
         ff_side = self.side_grads and self._ff_side
         dh_ = self._sb("dh", par) if ff_side else A["dh"]
         vtf = {"VtF1": self._sb("VtF1", par) if ff_side else A.get("VtF1"), "VtF2": self._sb("VtF2", par) if ff_side else A.get("VtF2")}
-        if ff_side:
+        if ff_side and self._ncopy == 2:
             self._side_join(p, keep=1)      # the launch of block i+2 read this parity's dh: overwritten by this block's first GEMM
         dq2 = dqkv.view(B * S, 3 * D)
         STREAMS = (("img", 0), ("txt", 1))
@@ -1650,7 +1655,8 @@ class _QwenPlan:
                                    row_mask=self.rmask[s], defer=mg)
                 if mg:
                     self._flush_mod_grad(p, mg)
-            self._side_join(p, keep=1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
+            if self._ncopy == 2:
+                self._side_join(p, keep=1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
                                      A["dx1"][s], dyg1[s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
@@ -1761,9 +1767,11 @@ class _QwenPlan:
                         lnl[-1].dygq, lnl[-1].dygs, lnl[-1].lddygq, lnl[-1].dygs_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
                 self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
         if self.side_grads and gl:
+            if self._ncopy == 3:
+                self._side_join(p, keep=1)   # block i-1 overwrites the copy the launch of block i+2 read
             p.py(self._side_fork)
             self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch, side=True)
-            ev = torch.cuda.Event()
+            ev = ops.Event()
             p.py(lambda ev=ev: ev.record(self.bwd.side))
             self._side_q.append((ev, prefix))
         else:

@@ -260,17 +260,17 @@ def emit_attn_backward(p, a, A):
         if "dsum_conc" not in A:
             A["dsum_conc"] = torch.empty(a.B * a.H * a.S_pad + 1024, dtype=torch.float32, device=st2.device)
         a2.dsum = A["dsum_conc"].data_ptr()
-        ev_f, ev_j = torch.cuda.Event(), torch.cuda.Event()
+        ev_f, ev_j = Event(), Event()
         p.keep += [a2, ev_f, ev_j, st2]
         p.c(lib.qfx_attn_bwd_prep, C.byref(a))
 
         def fork(ev=ev_f, s=st2):
             ev.record(torch.cuda.current_stream())
-            s.wait_event(ev)
+            ev.wait(s)
 
         def join(ev=ev_j, s=st2):
             ev.record(s)
-            torch.cuda.current_stream().wait_event(ev)
+            ev.wait(torch.cuda.current_stream())
         p.py(fork)
         p.c_on(st2, lib.qfx_attn_bwd_dq, C.byref(a2))
         p.c(lib.qfx_attn_bwd_dkv, C.byref(a))
@@ -335,6 +335,56 @@ def sumsq(g, out):
 def sumsq_det(g, out, partials):
     """Deterministic sum of squares (fixed reduction order): out[0] is overwritten; partials = fp32 workspace."""
     L.check(lib.qfx_sumsq_det(_p(g), g.numel(), _p(out), _p(partials), partials.numel(), stream_ptr()), "qfx_sumsq_det")
+
+
+_hip = None
+
+
+class Event:
+    """Stream-ordering event for the launch programs' fork / join points.  Default: a torch.cuda.Event.  QFX_EVENT_NOFENCE=1 (round-6
+    lever): a raw HIP event created with hipEventDisableTiming | hipEventDisableSystemFence -- the record then carries no system-scope
+    release (no L2 write-back for the host's sake) in the middle of the main stream; device-side ordering between streams is all these
+    events are used for."""
+
+    def __init__(self):
+        global _hip
+        self.raw = None
+        if os.environ.get("QFX_EVENT_NOFENCE", "0") == "1":
+            if _hip is None:
+                _hip = C.CDLL("libamdhip64.so")
+                _hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+                _hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+                _hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+                _hip.hipEventDestroy.argtypes = [C.c_void_p]
+            h = C.c_void_p()
+            rc = _hip.hipEventCreateWithFlags(C.byref(h), 0x2 | 0x20000000)
+            if rc != 0 or not h.value:
+                raise L.QfxError(f"hipEventCreateWithFlags failed with code {rc}")
+            self.raw = h
+        else:
+            self.ev = torch.cuda.Event()
+
+    def record(self, stream):
+        if self.raw is None:
+            self.ev.record(stream)
+        else:
+            rc = _hip.hipEventRecord(self.raw, C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise L.QfxError(f"hipEventRecord failed with code {rc}")
+
+    def wait(self, stream):
+        """Make `stream` wait for this event."""
+        if self.raw is None:
+            stream.wait_event(self.ev)
+        else:
+            rc = _hip.hipStreamWaitEvent(C.c_void_p(stream.cuda_stream), self.raw, 0)
+            if rc != 0:
+                raise L.QfxError(f"hipStreamWaitEvent failed with code {rc}")
+
+    def __del__(self):
+        if getattr(self, "raw", None) is not None and _hip is not None:
+            _hip.hipEventDestroy(self.raw)
+            self.raw = None
 
 
 _side_streams = {}
