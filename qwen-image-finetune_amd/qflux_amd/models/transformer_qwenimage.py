@@ -679,6 +679,8 @@ class _QwenPlan:
 
     side_grads = False        # see _init_side_grads (plans that do not call it keep every launch on the main stream)
     _side_q = ()
+    _side_late = False
+    _pending_side = None
     _ncopy = 2                # copies of the side launches' scratch operands (see _init_side_grads)
 
     def __init__(self, model, B: int, S_i: int, T: int, shapes, multires: bool = False):
@@ -756,6 +758,10 @@ class _QwenPlan:
         # QFX_SIDE_COPIES=3 (round-6 lever): three copies of the side launches' scratch operands instead of two, so that the join with the
         # launch of block i+2 can sit right in front of the fork of block i (two adjacent barrier packets instead of two separate bubbles)
         self._ncopy = 3 if (self.side_grads and os.environ.get("QFX_SIDE_COPIES", "2") == "3") else 2
+        # QFX_SIDE_AT_ATTN=1 (round-6 lever): the gradient launches of block i go out in front of block i-1's ATTENTION backward (whose
+        # launches leave CUs idle in their last round) instead of in front of its feed-forward GEMMs (which they slow down by 18 us)
+        self._side_late = bool(self.side_grads and self._ncopy == 2 and os.environ.get("QFX_SIDE_AT_ATTN", "0") == "1")
+        self._pending_side = None
         if self.side_grads:
             dev = self.model.device
             from .. import ops
@@ -1576,6 +1582,7 @@ class _QwenPlan:
             if not self.side_grads:
                 p.mark(f"transformer_blocks.{i}.")
             cur = nxt
+        self._emit_pending_side(p)
         self._side_join(p)
         # head: the embedders' adapters (their inputs carry no gradient: rank-r launches only); d(block-0 input) = A["dX"][s][cur]
         if self.in_grad:
@@ -1597,7 +1604,7 @@ class _QwenPlan:
         dh_ = self._sb("dh", par) if ff_side else A["dh"]
         vtf = {"VtF1": self._sb("VtF1", par) if ff_side else A.get("VtF1"), "VtF2": self._sb("VtF2", par) if ff_side else A.get("VtF2")}
         if ff_side and self._ncopy == 2:
-            self._side_join(p, keep=1)      # the launch of block i+2 read this parity's dh: overwritten by this block's first GEMM
+            self._side_join(p, keep=0 if self._side_late else 1)      # the launch of block i+2 read this parity's dh: overwritten by this block's first GEMM
         dq2 = dqkv.view(B * S, 3 * D)
         STREAMS = (("img", 0), ("txt", 1))
         i = 0 if first else 1
@@ -1656,7 +1663,7 @@ class _QwenPlan:
                 if mg:
                     self._flush_mod_grad(p, mg)
             if self._ncopy == 2:
-                self._side_join(p, keep=1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
+                self._side_join(p, keep=0 if self._side_late else 1)   # the launch of block i+2 read this parity's dyg1 / dqkv / v^T scratch: overwritten from here on
             groups = []
             lnl = [self._ln_bwd_args(A["dxm"][s], bb["x1"][s], mods[s][:, 4 * D:5 * D], 6 * D, dx2[s], mods[s][:, 2 * D:3 * D], 6 * D,
                                      A["dx1"][s], dyg1[s], rows[s], D, rpb[s], eps, None) for s, sidx in live]
@@ -1687,6 +1694,7 @@ class _QwenPlan:
             self._gemm_group(p, groups)
             # ---- attention backward
             q2 = bb["qkv"].view(B * S, 3 * D)
+            self._emit_pending_side(p)          # (QFX_SIDE_AT_ATTN: the previous block's gradient launches start here)
             ops.emit_attn_backward(p, a, A)      # two-pass pair, or the one-pass kernel (QFX_ATTN_BWD)
             if not a.qk_saved:      # (else: the backward of the QK norm + RoPE runs in the epilogues of the two kernels above)
                 nq_t, nk_t, nq_i, nk_i = w["norms"]
@@ -1767,15 +1775,29 @@ class _QwenPlan:
                         lnl[-1].dygq, lnl[-1].dygs, lnl[-1].lddygq, lnl[-1].dygs_rows = _ptr(pq_[0]), _ptr(pq_[1]), D, rows[s]
                 self._flush_ln(p, lnl, L.LnBwdArgs, lib.qfx_ln_modulate_bwd_batch)
         if self.side_grads and gl:
-            if self._ncopy == 3:
-                self._side_join(p, keep=1)   # block i-1 overwrites the copy the launch of block i+2 read
-            p.py(self._side_fork)
-            self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch, side=True)
-            ev = ops.Event()
-            p.py(lambda ev=ev: ev.record(self.bwd.side))
-            self._side_q.append((ev, prefix))
+            if self._side_late:
+                self._emit_pending_side(p)      # (a block without an attention section: nothing may be dropped)
+                self._pending_side = (gl, prefix)
+            else:
+                self._emit_side(p, gl, prefix)
         else:
             self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch)
+
+    def _emit_side(self, p, gl, prefix):
+        """Fork, the block's batched gradient launches on the side stream, the event its join will wait for."""
+        if self._ncopy == 3:
+            self._side_join(p, keep=1)   # block i-1 overwrites the copy the launch of block i+2 read
+        p.py(self._side_fork)
+        self._flush_batch(p, gl, L.LoraGradArgs, lib.qfx_lora_grad_batch, side=True)
+        ev = ops.Event()
+        p.py(lambda ev=ev: ev.record(self.bwd.side))
+        self._side_q.append((ev, prefix))
+
+    def _emit_pending_side(self, p):
+        if self._pending_side is not None:
+            gl, prefix = self._pending_side
+            self._pending_side = None
+            self._emit_side(p, gl, prefix)
 
     def set_multires(self, img_shapes, txt_seq_lens, attention_mask, S_in=None):
         """Per-batch tables of the multi-resolution path (host-side plumbing of transformer_qwen_custom.py:72-150,175-228,
