@@ -403,7 +403,9 @@ def test_gemm_dgelu_landing_buffer(geo):
         L.check(lib.qfx_gemm_grouped((L.GemmArgs * 2)(*gs), 2, ops.stream_ptr()), "qfx_gemm_grouped")
         for i in range(2):
             outs[f"grouped_{i}"] = (keep[i][1].cpu(), keep[i][2])
-        # gate + residual (the landing-buffer side additionally needs ONE sample per wave and no bias left for the epilogue): two samples
+        # gate + residual (its landing-buffer side is compiled in only by -DQFX_GEMM_AUX_DMA=3 -- measured slower, profiles/r06_gemm_aux_landing.json;
+        # on the product build these cases run the general passes of the same kernel; the side additionally needs ONE sample per wave and no
+        # bias left for the epilogue): two samples
         # of 1216 rows (the 256-row tile 1024..1279 crosses the boundary: its lower waves fall back) and of 1280, the C row map into a
         # joint buffer (aux indexed like C: a row delta), with and without the second output, a LoRA K segment with the bias rounded
         # in before it (landing side) and a plain bias (general side)
