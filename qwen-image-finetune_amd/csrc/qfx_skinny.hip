@@ -6,6 +6,9 @@
 #ifndef QFX_GRAD_HANDOFF
 #define QFX_GRAD_HANDOFF 8      // 8 = chunk partials added by a second launch (product); 0 = by the last block of the strip, with fences: see lora_grad_kernel
 #endif
+#ifndef QFX_GRAD_NT_X
+#define QFX_GRAD_NT_X 0      // lora_grad: non-temporal loads of the token-side operand (A/B lever)
+#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -397,7 +400,11 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const GradBatch batch_by
         int m = mb + (quad * 4 + j) * 32 + it * 16 + srow;
         m = m < p.M ? m : p.M - 1;
         const bf16_t* src = p.X + remap_row(m, p.rows_per_batch, p.x_batch_rows, p.x_row_off) * p.ldx + kc;
+#if QFX_GRAD_NT_X
+        dst[j][it] = __builtin_nontemporal_load((const u32x4*)src);      // every X element is read once per launch: keep it out of the GEMMs' L2
+#else
         dst[j][it] = *(const u32x4*)src;
+#endif
       }
   };
   f32x4 acc[NF][2];
