@@ -449,6 +449,37 @@ def test_gemm_dgelu_landing_buffer(geo):
         assert torch.equal(o, got[1][k][0]), f"{geo} {k}: two launches differ"
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_gemm_dgelu_landing_buffer_shape_fuzz(seed):
+    """Random shapes through the d(GELU) epilogue on every tile geometry (the counted waits of the landing-buffer side must hold for any
+    mix of full / partial / dead waves, ragged last row and column tiles, one or more tiles per block): bit-identical across geometries
+    (256x128 has no buffer) and within tolerance of the fp32 product."""
+    import random
+    from qflux_amd import _lib as L
+    ops = _ops()
+    lib = L.lib
+    rnd = random.Random(1000 + seed)
+    M = rnd.choice([16, 48, 160, 256, 272, 1040, 1216, 2000, 2432]) + rnd.choice([0, 0, 0, 5, 16, 32])
+    N = rnd.choice([192, 256, 384, 768, 1536, 3072]) + rnd.choice([0, 0, 8, 64])
+    K = 64 * rnd.randint(1, 12)
+    a, b = randn(M, K, seed=seed).to(BF), randn(N, K, seed=100 + seed, scale=0.2).to(BF)
+    hx = randn(M, N, seed=200 + seed).to(BF)
+    hh = hx.float().requires_grad_(True)
+    F.gelu(hh, approximate="tanh").sum().backward()
+    ref = rb(rb(a.float() @ b.float().t()) * hh.grad)
+    ad, bd, hd = a.to(DEV), b.to(DEV), hx.to(DEV)
+    outs = {}
+    try:
+        for geo in GEOMETRIES:
+            assert lib.qfx_gemm_tune(geo.encode(), None) == 0
+            outs[geo] = ops.gemm(ad, bd, epi=3, aux=hd).cpu()
+    finally:
+        assert lib.qfx_gemm_tune(b"all", None) == 0
+    for geo, o in outs.items():
+        check(f"gemm_dgelu_fuzz_{seed}_{geo}_{M}x{N}x{K}", o, ref, 1.5e-2)
+        assert torch.equal(o, outs["256x128"]), (geo, M, N, K)
+
+
 # ------------------------------------------------------------------------------------------ LoRA pieces
 def _split(x):
     hi = x.to(BF)
