@@ -1226,7 +1226,9 @@ class _QwenPlan:
         by_r = {}
         for a in pending:
             by_r.setdefault(a.R, []).append(a)
-        for _, lst in by_r.items():
+        order = sorted(by_r, reverse=True) if (side and os.environ.get("QFX_SIDE_ORDER", "0") == "wide_first") else list(by_r)
+        for r_ in order:      # (QFX_SIDE_ORDER=wide_first, round-6 lever: the widest rank class of the side-stream launches first)
+            lst = by_r[r_]
             for i in range(0, len(lst), L.MAX_BATCH):
                 chunk = lst[i:i + L.MAX_BATCH]
                 arr = (struct * len(chunk))(*chunk)
@@ -1751,6 +1753,10 @@ class _QwenPlan:
                                               rpb=rpb[s], a_map=(S, off[s]), **kw))
             self._flush_batch(p, dl, L.LoraDownArgs, lib.qfx_lora_down_batch)
             self._flush_head_reduce(p, dhq)
+            if self.side_grads and gl and not self._side_late and os.environ.get("QFX_SIDE_FORK", "late") == "early":
+                # round-6 lever: every operand of the block's gradient launches exists from here on -- fork in front of the q/k/v dX GEMM
+                # instead of behind the block's last LayerNorm backward
+                self._emit_side(p, gl, prefix)
             if i > 0:
                 self._gemm_group(p, groups)
                 if dmods is not None:   # d(shift1, scale1, gate1): dy = d(xm1) (q/k/v dX output), LN input x_in, gate side dx1 * y1
